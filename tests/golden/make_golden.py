@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference/model.py) on seeded inputs.  Runs only in the build container
+(the reference is not present on the GPU box); the .npz outputs are committed.
+
+    python tests/golden/make_golden.py
+
+Inputs and parameters are NOT stored: they are regenerated from seeds by
+oracle/deepspeaker_oracle.py (make_state_dict / make_input, frozen legacy
+numpy RandomState streams), so each fixture holds only the reference's outputs.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, "/root/reference")
+warnings.filterwarnings("ignore")
+
+import deepspeaker_oracle as O          # noqa: E402
+import model as ref                      # noqa: E402  (the reference, unmodified)
+
+torch.set_num_threads(8)
+
+
+def build_ref(sd_np, num_classes):
+    m = ref.DeepSpeakerModel(512, num_classes)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    m.load_state_dict(sd, strict=False)     # strict=False: small model lacks stages 3-4
+    return m
+
+
+def run_prefix(m, x, n_stages):
+    """Stages 1..n_stages + pool + fc + l2norm*10, through the reference's own
+    modules (model.py:185-213); n_stages=4 is exactly DeepSpeakerModel.forward."""
+    r = m.model
+    for i in range(1, n_stages + 1):
+        x = getattr(r, f"conv{i}")(x)
+        x = getattr(r, f"bn{i}")(x)
+        x = r.relu(x)
+        x = getattr(r, f"layer{i}")(x)
+    x = r.avgpool(x)
+    x = x.view(x.size(0), -1)
+    x = r.fc(x)
+    return m.l2_norm(x) * 10
+
+
+def grad_digest(t):
+    a = t.detach().double().numpy().ravel()
+    stride = max(1, a.size // 64)
+    return np.concatenate([[np.sqrt((a * a).sum()), a.sum()], a[:16], a[::stride][:64]])
+
+
+def main():
+    out = {}
+    # ---------------- full model, eval, T=160 (config 1/2 shape, small batch) ----
+    sd = O.make_state_dict(seed=11, num_classes=16)
+    m = build_ref(sd, 16).eval()
+    x = O.make_input(seed=12, batch=6)
+    with torch.no_grad():
+        e = m(torch.from_numpy(x))
+        cls = m.forward_classifier(torch.from_numpy(x))
+    out["full_eval_emb"] = e.numpy()
+    out["full_eval_cls"] = cls.numpy()
+    # intermediate taps through hooks, for per-layer kernel checks
+    with torch.no_grad():
+        r = m.model
+        t = torch.from_numpy(x)
+        t = r.relu(r.bn1(r.conv1(t)))
+        out["full_eval_stage1_a"] = t.numpy()[:1, :, :16].copy()
+        t = r.layer1(t)
+        out["full_eval_stage1_c"] = t.numpy()[:1, :, :16].copy()
+
+    # ---------------- variable length, eval (config 4 shapes incl. odd sizes) ----
+    for T in (100, 237, 402):
+        xv = O.make_input(seed=100 + T, batch=2, frames=T)
+        with torch.no_grad():
+            out[f"full_eval_T{T}_emb"] = m(torch.from_numpy(xv)).numpy()
+
+    # ---------------- ResCNN-small (configs[0]): 2 stages, B=32 ------------------
+    sds = O.make_state_dict(seed=21, num_classes=16, n_stages=2)
+    ms = build_ref(sds, 16).eval()
+    xs = O.make_input(seed=22, batch=32)
+    with torch.no_grad():
+        out["small_eval_emb"] = run_prefix(ms, torch.from_numpy(xs), 2).numpy()
+
+    # ---------------- full model, train mode: fwd, stats, triplet loss, backward --
+    sdt = O.make_state_dict(seed=31, num_classes=16)
+    mt = build_ref(sdt, 16).train()
+    B = 4
+    xa, xp, xn = (O.make_input(seed=32 + i, batch=B) for i in range(3))
+    ea, ep, en = mt(torch.from_numpy(xa)), mt(torch.from_numpy(xp)), mt(torch.from_numpy(xn))
+    loss = ref.TripletMarginLoss(0.1).forward(ea, ep, en)
+    mt.zero_grad()
+    loss.backward()
+    out["full_train_emb_a"] = ea.detach().numpy()
+    out["full_train_emb_p"] = ep.detach().numpy()
+    out["full_train_emb_n"] = en.detach().numpy()
+    out["full_train_loss"] = loss.detach().numpy()
+    for k, v in mt.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            out["full_train_stat/" + k] = v.numpy()
+    for k, p in mt.named_parameters():
+        if p.grad is not None:
+            out["full_train_grad/" + k] = grad_digest(p.grad)
+
+    # single train-mode forward + backward from a fixed embedding gradient
+    # (isolates the network backward from the loss backward)
+    mt2 = build_ref(sdt, 16).train()
+    e1 = mt2(torch.from_numpy(xa))
+    ge = np.random.RandomState(77).randn(B, 512).astype(np.float32)
+    mt2.zero_grad()
+    e1.backward(torch.from_numpy(ge))
+    out["single_train_emb"] = e1.detach().numpy()
+    for k, p in mt2.named_parameters():
+        if p.grad is not None:
+            out["single_train_grad/" + k] = grad_digest(p.grad)
+    for k, v in mt2.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            out["single_train_stat/" + k] = v.numpy()
+
+    # ---------------- loss side on free-standing embeddings ----------------------
+    rs = np.random.RandomState(41)
+    N = 96
+    base = rs.randn(N, 512).astype(np.float32)
+    a = (base / np.linalg.norm(base, axis=1, keepdims=True) * 10).astype(np.float32)
+    p = a + rs.randn(N, 512).astype(np.float32) * 0.05
+    n = a + rs.randn(N, 512).astype(np.float32) * 0.05
+    ta, tp, tn = (torch.from_numpy(v).requires_grad_(True) for v in (a, p, n))
+    pd = ref.PairwiseDistance(2)
+    d_p, d_n = pd.forward(ta, tp), pd.forward(ta, tn)
+    tl = ref.TripletMarginLoss(0.1).forward(ta, tp, tn)
+    tl.backward()
+    out["loss_d_p"], out["loss_d_n"] = d_p.detach().numpy(), d_n.detach().numpy()
+    out["loss_value"] = tl.detach().numpy()
+    out["loss_grad_a"], out["loss_grad_p"], out["loss_grad_n"] = (
+        ta.grad.numpy()[:16].copy(), tp.grad.numpy()[:16].copy(), tn.grad.numpy()[:16].copy())
+    # train_triplet.py:253,262 restated exactly on the reference's own distances
+    allm = (d_n - d_p < 0.1).detach().numpy().flatten()
+    out["loss_selected"] = np.where(allm == 1)[0].astype(np.int64)
+    out["loss_n_correct"] = np.array(len(np.where(allm == 0)[0]))
+    out["loss_mean_diff"] = np.array(np.mean((d_n - d_p).detach().numpy().flatten()))
+    # test(): train_triplet.py:348-350 with 8 crops
+    out["loss_test_scores"] = d_p.detach().numpy().reshape(N // 8, 8).mean(axis=1)
+
+    # filter on model embeddings (near-collinear at random init: SURVEY section 7)
+    d_p2 = pd.forward(ea, ep).detach()
+    d_n2 = pd.forward(ea, en).detach()
+    out["full_train_d_p"], out["full_train_d_n"] = d_p2.numpy(), d_n2.numpy()
+    out["full_train_selected"] = np.where((d_n2 - d_p2 < 0.1).numpy().flatten() == 1)[0].astype(np.int64)
+
+    # CE regime: train_triplet.py:277-287
+    logits = torch.from_numpy(rs.randn(12, 16).astype(np.float32))
+    labels = torch.from_numpy(rs.randint(0, 16, 12).astype(np.int64))
+    out["ce_logits"], out["ce_labels"] = logits.numpy(), labels.numpy()
+    out["ce_value"] = torch.nn.CrossEntropyLoss()(logits, labels).numpy()
+
+    path = os.path.join(HERE, "reference_outputs.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
