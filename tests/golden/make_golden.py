@@ -92,7 +92,7 @@ def main():
     # ---------------- full model, train mode: fwd, stats, triplet loss, backward --
     sdt = O.make_state_dict(seed=31, num_classes=16)
     mt = build_ref(sdt, 16).train()
-    B = 4
+    B = 8
     xa, xp, xn = (O.make_input(seed=32 + i, batch=B) for i in range(3))
     ea, ep, en = mt(torch.from_numpy(xa)), mt(torch.from_numpy(xp)), mt(torch.from_numpy(xn))
     loss = ref.TripletMarginLoss(0.1).forward(ea, ep, en)
@@ -123,6 +123,18 @@ def main():
     for k, v in mt2.state_dict().items():
         if "running" in k or "num_batches" in k:
             out["single_train_stat/" + k] = v.numpy()
+
+    # the same, with the reference evaluated in float64 (model.double()): the fp32 autograd
+    # result above is itself ~1e-2 (elementwise, relative to max) away from this in the
+    # random-init regime, so the fp64 run is the tight pin for backward restatements.
+    mt3 = build_ref(sdt, 16).train().double()
+    e3 = mt3(torch.from_numpy(xa).double())
+    mt3.zero_grad()
+    e3.backward(torch.from_numpy(ge).double())
+    out["single_train64_emb"] = e3.detach().numpy()
+    for k, p in mt3.named_parameters():
+        if p.grad is not None:
+            out["single_train64_grad/" + k] = grad_digest(p.grad)
 
     # ---------------- loss side on free-standing embeddings ----------------------
     rs = np.random.RandomState(41)

@@ -54,7 +54,7 @@ def test_small_model(golden):
 
 def test_train_forward_stats_and_backward(golden):
     sd = O.make_state_dict(seed=31, num_classes=16)
-    B = 4
+    B = 8
     xs = [O.make_input(seed=32 + i, batch=B) for i in range(3)]
     embs, caches = [], []
     cur = dict(sd)
@@ -92,30 +92,38 @@ def test_train_forward_stats_and_backward(golden):
                 continue
             ref = golden[k]
             got = grad_digest(total[name])
-            # B=4 triplets through train-mode BN is ill-conditioned: clip-mask flips under fp32
-            # rounding move early-layer gradients by ~4e-3 (the same restatement run in fp32 vs
-            # fp64 differs by that much), so the reference's own fp32 noise bounds this check.
-            assert np.abs(got - ref).max() <= 1e-2 * max(np.abs(ref).max(), 1e-12), name
+            # The reference's fp32 autograd is itself ~1e-2..4e-2 (elementwise, relative to max)
+            # away from its own float64 evaluation in this random-init regime (BN-backward
+            # cancellation); test_single_backward pins the restatement tightly against the
+            # reference run in float64, this one only bounds the fp32 noise.
+            assert np.abs(got - ref).max() <= 8e-2 * max(np.abs(ref).max(), 1e-12), name
             checked += 1
     assert checked == 38
 
 
 def test_single_backward(golden):
     sd = O.make_state_dict(seed=31, num_classes=16)
-    x = O.make_input(seed=32, batch=4)
+    x = O.make_input(seed=32, batch=8)
     cache, new = {}, {}
     e = O.forward(sd, x, train=True, dtype=np.float64, new_stats=new, cache=cache)
     assert rel_err(e, golden["single_train_emb"]) < TOL
-    ge = np.random.RandomState(77).randn(4, 512).astype(np.float32)
+    ge = np.random.RandomState(77).randn(8, 512).astype(np.float32)
     gr = O.backward(sd, cache, x, ge)
+    assert rel_err(e, golden["single_train64_emb"]) < 1e-11
+    checked = 0
     for k in golden.files:
-        if k.startswith("single_train_grad/"):
+        if k.startswith("single_train64_grad/"):      # reference evaluated in float64: tight pin
             name = k.split("/", 1)[1]
-            if name.startswith("model.classifier"):
-                continue
             ref = golden[k]
             got = grad_digest(gr[name])
-            assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-12), name
+            assert np.abs(got - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-12), name
+            checked += 1
+        elif k.startswith("single_train_grad/"):      # reference in fp32: bounded by its own noise
+            name = k.split("/", 1)[1]
+            ref = golden[k]
+            got = grad_digest(gr[name])
+            assert np.abs(got - ref).max() <= 8e-2 * max(np.abs(ref).max(), 1e-12), name
+    assert checked == 38
 
 
 def test_loss_side(golden):
