@@ -1,0 +1,98 @@
+"""ctypes binding of libdeepspeaker_hip.so (the C ABI declared in include/deepspeaker_hip.h).
+
+The binding is pure plumbing: pointers and sizes in, return codes out.  There is no CPU or
+PyTorch fallback -- if the shared library is missing, `load()` raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libdeepspeaker_hip.so"
+
+DS_EPI_AFFINE, DS_EPI_RESIDUAL, DS_EPI_CLIP, DS_EPI_STATS = 1, 2, 4, 8
+DS_CONV_CK = 8
+
+
+class ConvShape(Structure):
+    """struct ds_conv_shape"""
+    _fields_ = [("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
+                ("Cout", c_int), ("KS", c_int), ("stride", c_int)]
+
+
+class DeepSpeakerHipError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "ds_version": (c_int, []),
+    "ds_error_string": (c_char_p, [c_int]),
+    "ds_nchw_to_nhwc_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_nhwc_to_nchw_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_pack_conv_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_pack_conv1_weight_f32": (c_int, [_P, _P, c_int, _P]),
+    "ds_pack_fc_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_bn_fold_f32": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
+    "ds_bn_stats_finalize_f32": (c_int, [_P, c_int, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P,
+                                         _P, _P, c_int, _P]),
+    "ds_bn_apply_f32": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
+    "ds_conv_out_dims": (c_int, [POINTER(ConvShape), POINTER(c_int), POINTER(c_int)]),
+    "ds_conv_stats_rows": (c_int, [POINTER(ConvShape)]),
+    "ds_conv5x5s2_c1_stats_rows": (c_int, [c_int, c_int]),
+    "ds_conv5x5s2_c1_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv_fwd_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "ds_avgpool_time_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_l2norm_scale_f32": (c_int, [_P, _P, c_int, c_int, c_float, c_float, _P]),
+    "ds_pairwise_distance_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "ds_triplet_margin_fwd_f32": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
+    "ds_triplet_filter_f32": (c_int, [_P, _P, c_float, _P, _P, _P, c_int, _P]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/deepspeaker_hip.h declares."""
+    return sorted(_SIGNATURES)
+
+
+class NativeLib:
+    """A loaded copy of the C ABI with argument types declared."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise DeepSpeakerHipError(
+                f"{path} not found: build it with `make` (hipcc --offload-arch=gfx950); "
+                "this package has no fallback path")
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self._dll, name)        # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_" + name, fn)
+
+    def error_string(self, code: int) -> str:
+        return self._ds_error_string(code).decode()
+
+    def call(self, name: str, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if rc != 0:
+            raise DeepSpeakerHipError(f"{name} failed: {rc} ({self.error_string(rc)})")
+        return rc
+
+    def raw(self, name: str):
+        return getattr(self, "_" + name)
+
+
+_cached = None
+
+
+def load() -> NativeLib:
+    """Load the HIP library that sits next to this file (torch must already be imported so the
+    process-wide libamdhip64 is torch's)."""
+    global _cached
+    if _cached is None:
+        _cached = NativeLib(os.path.join(_HERE, LIB_NAME))
+    return _cached

@@ -1,0 +1,363 @@
+// conv_mfma_f32.hip -- implicit-GEMM convolution on the gfx950 f32 matrix cores.
+//
+// Replaces the cuDNN convolutions the reference launches through nn.Conv2d
+// (reference model.py:47-50 3x3 s1 p1; :98,102,106 5x5 s2 p2; and, as a 1x1 case,
+// the fc GEMM of model.py:209), fused with the BatchNorm affine, the residual add
+// and the clipped ReLU that follow them (model.py:70-80, 188-205).
+//
+// GEMM view (channels-last activations):  M = output pixels, N = Cout,
+// K = taps x Cin.  A workgroup owns an M-tile made of NI "segments" (RT output rows
+// x full width of one image) and an N-tile of output channels.  Per 8-channel chunk
+// of Cin the input halo tile of every segment is staged ONCE into LDS (zero-filled
+// outside the image) and reused by all KS*KS taps; a tap is just a constant LDS
+// offset.  Weights stream from L2 straight into registers in the exact fragment
+// order (one fully coalesced 1 KiB load per 32x8 slice).  The arithmetic is
+// v_mfma_f32_32x32x2_f32 -- exact f32, the parity path.
+//
+// One kernel serves forward 3x3/5x5/1x1 (and, through the tap table and the
+// input/output strides, the data-gradient convolutions).
+#include <ds_device.h>
+#include "ds_common.h"
+
+namespace {
+
+constexpr int CK = DS_CONV_CK;      // input channels per staged chunk
+constexpr int LDS_PS = 12;          // floats per staged pixel: 8 channels + 4 pad.  48 B keeps
+                                    // ds_read_b128 aligned and walks all 64 banks over 16 pixels
+constexpr int MAX_STAGE_IT = 8;     // per-thread float4 staging slots
+constexpr int MAX_TAPS = 25;
+
+struct ConvK {
+    const float *x, *w;
+    float *y;
+    const float *scale, *shift, *res;
+    float *stats;
+    int H, W, Cin;          // input tensor (per image)
+    int Hr, Wc;             // virtual output grid per image (rows, cols)
+    int Ho, Wo, Cout;       // output tensor (per image)
+    int IS, OS, OH0, OW0;   // input stride; output stride / origin (data-gradient classes)
+    int NT;                 // taps
+    int dh_min, dw_min;     // input-tile origin relative to (IS*r0, 0)
+    int rows_in, cols_in, seg_pix;
+    int RT, NI, segs_per_img, n_segs;
+    int n_ntiles;
+    int flags;
+    short tap_off[MAX_TAPS + 7];   // LDS pixel offset of each tap inside a segment
+};
+
+template <int MSUB, int NSUB, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK p) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MT = MSUB * WM * 32;
+    constexpr int NTILE = NSUB * WN * 32;
+
+    float *lds = ds_dynamic_lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile_n = blockIdx.x % p.n_ntiles;
+    const int tile_m = blockIdx.x / p.n_ntiles;
+    const int seg0 = tile_m * p.NI;
+    const int pix_per_seg = p.RT * p.Wc;
+    const int tile_pix = p.NI * p.seg_pix;
+    int *out_off = (int *)(lds + tile_pix * LDS_PS);       // [MT] output element offsets, -1 = masked
+    float *red = (float *)(out_off + MT);                  // [WM][NTILE][2] statistics scratch
+
+    // ---- row -> output offset table (one division chain per row, not per accumulator) ----
+    for (int m = tid; m < MT; m += NTHR) {
+        const int seg = m / pix_per_seg;
+        const int rem = m - seg * pix_per_seg;
+        const int r = rem / p.Wc, c = rem - r * p.Wc;
+        const int gseg = seg0 + seg;
+        int off = -1;
+        if (seg < p.NI && gseg < p.n_segs) {
+            const int b = gseg / p.segs_per_img;
+            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
+            if (rr < p.Hr) off = ((b * p.Ho + p.OH0 + p.OS * rr) * p.Wo + p.OW0 + p.OS * c) * p.Cout;
+        }
+        out_off[m] = off;
+    }
+
+    // ---- per-lane A-fragment base: this lane's pixel of each 32-row sub-tile ----
+    int a_off[MSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int m = (wm * MSUB + ms) * 32 + l31;
+        const int seg = m / pix_per_seg;
+        const int rem = m - seg * pix_per_seg;
+        const int r = rem / p.Wc, c = rem - r * p.Wc;
+        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.cols_in + p.IS * c : 0;
+        a_off[ms] = pix * LDS_PS + 4 * lhi;
+    }
+
+    // ---- staging descriptors: which global float4 lands in which LDS slot (chunk-invariant) ----
+    int g_off[MAX_STAGE_IT], l_off[MAX_STAGE_IT];
+    const int n_items = tile_pix * (CK / 4);
+#pragma unroll
+    for (int it = 0; it < MAX_STAGE_IT; ++it) {
+        const int idx = tid + it * NTHR;
+        g_off[it] = -1;
+        l_off[it] = -1;
+        if (idx < n_items) {
+            const int pix = idx >> 1, q = idx & 1;
+            const int seg = pix / p.seg_pix;
+            const int pr = pix - seg * p.seg_pix;
+            const int rr = pr / p.cols_in, cc = pr - rr * p.cols_in;
+            const int gseg = seg0 + seg;
+            l_off[it] = pix * LDS_PS + q * 4;
+            if (gseg < p.n_segs) {
+                const int b = gseg / p.segs_per_img;
+                const int r0 = (gseg - b * p.segs_per_img) * p.RT;
+                const int h = p.IS * r0 + p.dh_min + rr, w = p.dw_min + cc;
+                if (h >= 0 && h < p.H && w >= 0 && w < p.W) g_off[it] = ((b * p.H + h) * p.W + w) * p.Cin + q * 4;
+            }
+        }
+    }
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+
+    const int n_chunks = p.Cin / CK;
+    const int n_base = tile_n * NTILE + wn * NSUB * 32;
+    const float *wlane = p.w + (size_t)(n_base + l31) * CK + 4 * lhi;
+    const size_t w_tap_stride = (size_t)p.Cout * CK;
+    const int total_taps = n_chunks * p.NT;
+
+    f32x4 st[MAX_STAGE_IT];
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int it = 0; it < MAX_STAGE_IT; ++it)
+        st[it] = (g_off[it] >= 0) ? *(const f32x4 *)(p.x + g_off[it]) : zero4;
+
+    f32x4 bcur[NSUB], bnext[NSUB];
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+        bcur[ns] = *(const f32x4 *)(wlane + (size_t)ns * 32 * CK);
+        bnext[ns] = bcur[ns];
+    }
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        __syncthreads();                       // previous chunk's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < MAX_STAGE_IT; ++it)
+            if (l_off[it] >= 0) *(f32x4 *)(lds + l_off[it]) = st[it];
+        __syncthreads();
+        if (chunk + 1 < n_chunks) {            // next chunk's pixels fly while this one computes
+#pragma unroll
+            for (int it = 0; it < MAX_STAGE_IT; ++it)
+                st[it] = (g_off[it] >= 0) ? *(const f32x4 *)(p.x + g_off[it] + (chunk + 1) * CK) : zero4;
+        }
+        for (int t = 0; t < p.NT; ++t) {
+            const int g = chunk * p.NT + t;
+            if (g + 1 < total_taps) {
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                    bnext[ns] = *(const f32x4 *)(wlane + (size_t)(g + 1) * w_tap_stride + (size_t)ns * 32 * CK);
+            }
+            const int toff = (int)p.tap_off[t] * LDS_PS;
+            f32x4 a[MSUB];
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms) a[ms] = *(const f32x4 *)(lds + a_off[ms] + toff);
+            // k-step j multiplies channels {j, 4+j} of the chunk: lanes 0-31 carry channels
+            // 0..3, lanes 32-63 channels 4..7, for the A and the B fragment alike.
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < NSUB; ++ns)
+                        acc[ms][ns] = ds_mfma_32x32x2_f32(a[ms][j], bcur[ns][j], acc[ms][ns]);
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) bcur[ns] = bnext[ns];
+        }
+    }
+
+    // ---- epilogue: BatchNorm affine / residual / clipped ReLU, optional raw statistics ----
+    const int flags = p.flags;
+    float sc[NSUB], sh[NSUB], s1[NSUB], s2[NSUB];
+    int col[NSUB];
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+        col[ns] = n_base + ns * 32 + l31;
+        sc[ns] = (flags & DS_EPI_AFFINE) ? p.scale[col[ns]] : 1.0f;
+        sh[ns] = (flags & DS_EPI_AFFINE) ? p.shift[col[ns]] : 0.0f;
+        s1[ns] = 0.0f;
+        s2[ns] = 0.0f;
+    }
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int off = out_off[row];
+            if (off >= 0) {
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) {
+                    float v = acc[ms][ns][r];
+                    s1[ns] += v;
+                    s2[ns] += v * v;
+                    if (flags & DS_EPI_AFFINE) v = v * sc[ns] + sh[ns];
+                    if (flags & DS_EPI_RESIDUAL) v += p.res[(size_t)off + col[ns]];
+                    if (flags & DS_EPI_CLIP) v = fminf(fmaxf(v, 0.0f), 20.0f);
+                    p.y[(size_t)off + col[ns]] = v;
+                }
+            }
+        }
+    }
+    if (flags & DS_EPI_STATS) {
+        // column sums: fold the two lane halves, then the WM row-waves in a fixed order
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+            s1[ns] += ds_shfl_xor(s1[ns], 32);
+            s2[ns] += ds_shfl_xor(s2[ns], 32);
+            if (lhi == 0) {
+                const int c = wn * NSUB * 32 + ns * 32 + l31;
+                red[(wm * NTILE + c) * 2 + 0] = s1[ns];
+                red[(wm * NTILE + c) * 2 + 1] = s2[ns];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < NTILE; c += NTHR) {
+            float a1 = 0.0f, a2 = 0.0f;
+            for (int k = 0; k < WM; ++k) {
+                a1 += red[(k * NTILE + c) * 2 + 0];
+                a2 += red[(k * NTILE + c) * 2 + 1];
+            }
+            float *dst = p.stats + ((size_t)tile_m * p.Cout + tile_n * NTILE + c) * 2;
+            dst[0] = a1;
+            dst[1] = a2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side tiling plan
+// ------------------------------------------------------------------------------------------
+struct TileCfg { int MT, NTILE, NTHR, WM; };
+constexpr TileCfg kCfg[2] = {
+    {128, 64, 256, 2},     // conv_mfma_f32_kernel<2,1,2,2>
+    {160, 128, 256, 1},    // conv_mfma_f32_kernel<5,1,1,4>
+};
+
+struct ConvPlan {
+    int cfg;
+    int grid;
+    size_t lds_bytes;
+    int n_mtiles;
+    ConvK k;
+};
+
+// Choose (cfg, RT, NI): maximise the fraction of MFMA rows that are real pixels, then the
+// segment height (less halo re-staging).  Full-width segments only.
+static int plan_tiles(ConvPlan &pl, int B, int Hr, int Wc, int IS, int ext_h, int ext_w, int Cout,
+                      bool stats) {
+    double best_eff = -1.0;
+    int best_cfg = -1, best_rt = 0, best_ni = 0;
+    for (int c = 0; c < 2; ++c) {
+        const TileCfg &cf = kCfg[c];
+        if (Cout % cf.NTILE) continue;
+        for (int rt = 1; rt <= Hr; ++rt) {
+            if ((long long)rt * Wc > cf.MT) break;
+            const int segs_per_img = ds_ceil_div(Hr, rt);
+            const long long n_segs = (long long)B * segs_per_img;
+            int ni = cf.MT / (rt * Wc);
+            if (ni > n_segs) ni = (int)n_segs;
+            const int rows_in = IS * (rt - 1) + ext_h, cols_in = IS * (Wc - 1) + ext_w;
+            while (ni > 1 && (long long)ni * rows_in * cols_in * (CK / 4) > (long long)MAX_STAGE_IT * cf.NTHR) --ni;
+            if ((long long)ni * rows_in * cols_in * (CK / 4) > (long long)MAX_STAGE_IT * cf.NTHR) continue;
+            const long long n_mt = ds_ceil_div_ll(n_segs, ni);
+            double eff = (double)B * Hr * Wc / ((double)n_mt * cf.MT);
+            eff += 1e-9 * rt + (c == 1 ? 1e-6 : 0.0);   // ties: wider N tile, taller segment
+            if (eff > best_eff) { best_eff = eff; best_cfg = c; best_rt = rt; best_ni = ni; }
+        }
+    }
+    if (best_cfg < 0) return DS_ERR_UNSUPPORTED;
+    const TileCfg &cf = kCfg[best_cfg];
+    ConvK &k = pl.k;
+    k.RT = best_rt;
+    k.NI = best_ni;
+    k.segs_per_img = ds_ceil_div(Hr, best_rt);
+    k.n_segs = B * k.segs_per_img;
+    k.rows_in = IS * (best_rt - 1) + ext_h;
+    k.cols_in = IS * (Wc - 1) + ext_w;
+    k.seg_pix = k.rows_in * k.cols_in;
+    k.n_ntiles = Cout / cf.NTILE;
+    pl.cfg = best_cfg;
+    pl.n_mtiles = ds_ceil_div(k.n_segs, best_ni);
+    pl.grid = pl.n_mtiles * k.n_ntiles;
+    pl.lds_bytes = (size_t)k.NI * k.seg_pix * LDS_PS * 4 + (size_t)cf.MT * 4 +
+                   (stats ? (size_t)cf.WM * cf.NTILE * 2 * 4 : 0);
+    return DS_OK;
+}
+
+static int plan_forward(ConvPlan &pl, const ds_conv_shape *s, bool stats) {
+    DS_REQUIRE(s != nullptr, DS_ERR_NULL);
+    DS_REQUIRE(s->B > 0 && s->H > 0 && s->W > 0 && s->Cin > 0 && s->Cout > 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(s->KS == 1 || s->KS == 3 || s->KS == 5, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(s->stride == 1 || s->stride == 2, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(s->Cin % CK == 0 && s->Cout % 64 == 0, DS_ERR_BAD_SHAPE);
+    const int pad = s->KS / 2;
+    const int Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
+    const int Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
+    DS_REQUIRE(Ho > 0 && Wo > 0 && Wo <= 128, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 31), DS_ERR_BAD_SHAPE);
+    ConvK &k = pl.k;
+    k.H = s->H; k.W = s->W; k.Cin = s->Cin;
+    k.Hr = Ho; k.Wc = Wo; k.Ho = Ho; k.Wo = Wo; k.Cout = s->Cout;
+    k.IS = s->stride; k.OS = 1; k.OH0 = 0; k.OW0 = 0;
+    k.NT = s->KS * s->KS;
+    k.dh_min = -pad; k.dw_min = -pad;
+    int rc = plan_tiles(pl, s->B, Ho, Wo, s->stride, s->KS, s->KS, s->Cout, stats);
+    if (rc != DS_OK) return rc;
+    for (int kh = 0; kh < s->KS; ++kh)
+        for (int kw = 0; kw < s->KS; ++kw) k.tap_off[kh * s->KS + kw] = (short)(kh * k.cols_in + kw);
+    return DS_OK;
+}
+
+static int launch(const ConvPlan &pl, void *stream) {
+    if (pl.cfg == 0)
+        DS_LAUNCH((conv_mfma_f32_kernel<2, 1, 2, 2>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    else
+        DS_LAUNCH((conv_mfma_f32_kernel<5, 1, 1, 4>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    return ds_last_launch_error();
+}
+
+}  // namespace
+
+extern "C" int ds_conv_out_dims(const ds_conv_shape *s, int *Ho, int *Wo) {
+    DS_REQUIRE(s && Ho && Wo, DS_ERR_NULL);
+    DS_REQUIRE(s->KS >= 1 && (s->stride == 1 || s->stride == 2), DS_ERR_UNSUPPORTED);
+    const int pad = s->KS / 2;
+    *Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
+    *Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
+    return (*Ho > 0 && *Wo > 0) ? DS_OK : DS_ERR_BAD_SHAPE;
+}
+
+extern "C" int ds_conv_stats_rows(const ds_conv_shape *s) {
+    ConvPlan pl;
+    int rc = plan_forward(pl, s, true);
+    return rc == DS_OK ? pl.n_mtiles : rc;
+}
+
+extern "C" int ds_conv_fwd_f32(const ds_conv_shape *s, const float *x, const float *w_packed,
+                               const float *scale, const float *shift, const float *residual,
+                               float *y, float *stats_partial, int flags, void *stream) {
+    DS_REQUIRE(x && w_packed && y, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_AFFINE) || (scale && shift), DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_RESIDUAL) || residual, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_STATS) || stats_partial, DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(w_packed) && DS_ALIGNED16(y), DS_ERR_ALIGNMENT);
+    ConvPlan pl;
+    int rc = plan_forward(pl, s, (flags & DS_EPI_STATS) != 0);
+    if (rc != DS_OK) return rc;
+    pl.k.x = x; pl.k.w = w_packed; pl.k.y = y;
+    pl.k.scale = scale; pl.k.shift = shift; pl.k.res = residual; pl.k.stats = stats_partial;
+    pl.k.flags = flags;
+    return launch(pl, stream);
+}

@@ -1,0 +1,37 @@
+// ds_device.h -- the thin layer between the kernels and the gfx950 toolchain:
+// MFMA / cross-lane intrinsics, the dynamic-LDS base and the launch macro.
+// Kernels include it as <ds_device.h>; tests/emul/ provides a host stand-in of the
+// same name so the unmodified kernel sources can be exercised lane-by-lane on a CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, exact f32 (fma chain over k).
+// lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+__device__ __forceinline__ f32x16 ds_mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// cross-lane exchange inside one 64-lane wavefront
+__device__ __forceinline__ float ds_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float ds_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ int ds_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ unsigned long long ds_ballot(int pred) { return __ballot(pred); }
+
+// 16-byte aligned base of the dynamic LDS allocation (no static __shared__ objects are
+// declared anywhere, so the base is the start of the workgroup's LDS segment)
+__device__ __forceinline__ float *ds_dynamic_lds() {
+    extern __shared__ __attribute__((aligned(16))) float ds_lds_base[];
+    return ds_lds_base;
+}
+
+#define DS_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__)
+
+static inline int ds_last_launch_error() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -1,0 +1,188 @@
+// tail_loss.hip -- the HBM-bound row kernels around the convolution stack:
+//   * temporal average pool (reference model.py:111,207-208)
+//   * L2 normalisation x alpha (model.py:172-183,210-213)
+//   * PairwiseDistance / TripletMarginLoss forward (model.py:13-18, 27-33)
+//   * the triplet filter of the training loop (train_triplet.py:251-262)
+// One 64-lane wavefront owns one embedding row; row reductions are wave shuffles.
+#include <ds_device.h>
+#include "ds_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += ds_shfl_xor(v, m);
+    return v;
+}
+
+// ---- temporal average pool: [B,Hr,Wc,C] -> [B, Wc*C] -------------------------------------------
+__global__ void __launch_bounds__(256) avgpool_time_kernel(const float *x, float *pooled, int B, int Hr,
+                                                           int row_elems /* Wc*C */) {
+    const int vec_per_row = row_elems >> 2;
+    const long long n = (long long)B * vec_per_row;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / vec_per_row), v = (int)(i - (long long)b * vec_per_row);
+        const f32x4 *src = (const f32x4 *)(x + (size_t)b * Hr * row_elems) + v;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < Hr; ++h) s += src[(size_t)h * vec_per_row];
+        const float hr = (float)Hr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = s[j] / hr;
+        ((f32x4 *)(pooled + (size_t)b * row_elems))[v] = s;
+    }
+}
+
+// ---- e = alpha * f / sqrt(sum f^2 + eps) ---------------------------------------------------------
+__global__ void __launch_bounds__(256) l2norm_scale_kernel(const float *f, float *e, int B, int D, float alpha,
+                                                           float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = row < B;
+    const float *src = f + (size_t)(live ? row : 0) * D;
+    float ss = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float v = src[k];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss + eps);
+    if (live) {
+        float *dst = e + (size_t)row * D;
+        for (int k = lane; k < D; k += 64) dst[k] = (src[k] / nrm) * alpha;
+    }
+}
+
+// ---- pairwise distance rows ------------------------------------------------------------------------
+__device__ __forceinline__ float row_sqdist(const float *a, const float *b, int D, int lane) {
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float d = fabsf(a[k] - b[k]);
+        s += d * d;
+    }
+    return wave_sum(s);
+}
+
+__global__ void __launch_bounds__(256) pairwise_distance_kernel(const float *x1, const float *x2, float *d, int N,
+                                                                int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = row < N ? row : 0;
+    const float s = row_sqdist(x1 + (size_t)r * D, x2 + (size_t)r * D, D, lane);
+    if (row < N && lane == 0) d[row] = sqrtf(s + eps);
+}
+
+__global__ void __launch_bounds__(256) triplet_dist_kernel(const float *a, const float *p, const float *n, float *d_p,
+                                                           float *d_n, int N, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = row < N ? row : 0;
+    const float sp = row_sqdist(a + (size_t)r * D, p + (size_t)r * D, D, lane);
+    const float sn = row_sqdist(a + (size_t)r * D, n + (size_t)r * D, D, lane);
+    if (row < N && lane == 0) {
+        d_p[row] = sqrtf(sp + eps);
+        d_n[row] = sqrtf(sn + eps);
+    }
+}
+
+// block-wide sum of one float per thread, fixed order (deterministic); result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float *scratch) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return r;
+}
+
+// loss = mean_i max(0, margin + d_p[i] - d_n[i]); single workgroup, fixed summation order
+__global__ void __launch_bounds__(256) hinge_mean_kernel(const float *d_p, const float *d_n, float margin, float *loss,
+                                                         int N) {
+    float *scratch = ds_dynamic_lds();
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) acc += fmaxf(margin + d_p[i] - d_n[i], 0.0f);
+    const float tot = block_sum_256(acc, scratch);
+    if (threadIdx.x == 0) loss[0] = tot / (float)N;
+}
+
+// ordered compaction of {i : d_n[i] - d_p[i] < margin}; single workgroup
+__global__ void __launch_bounds__(256) triplet_filter_kernel(const float *d_p, const float *d_n, float margin,
+                                                             long long *idx, int *count, float *mean_diff, int N) {
+    float *scratch = ds_dynamic_lds();
+    int *iscratch = (int *)(scratch + 8);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    float dsum = 0.f;
+    for (int i0 = 0; i0 < N; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        float diff = 0.f;
+        int sel = 0;
+        if (i < N) {
+            diff = d_n[i] - d_p[i];
+            sel = diff < margin;
+        }
+        dsum += diff;
+        const unsigned long long m = ds_ballot(sel);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) iscratch[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += iscratch[w];
+        const int tot = iscratch[0] + iscratch[1] + iscratch[2] + iscratch[3];
+        if (sel) idx[base + woff + before] = i;
+        base += tot;
+        __syncthreads();
+    }
+    const float tot = block_sum_256(dsum, scratch);
+    if (threadIdx.x == 0) {
+        count[0] = base;
+        mean_diff[0] = tot / (float)N;
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_avgpool_time_f32(const float *x, float *pooled, int B, int Hr, int Wc, int C, void *stream) {
+    DS_REQUIRE(x && pooled, DS_ERR_NULL);
+    DS_REQUIRE(B > 0 && Hr > 0 && Wc > 0 && C > 0 && (C % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(pooled), DS_ERR_ALIGNMENT);
+    const long long n = (long long)B * (Wc * C / 4);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    DS_LAUNCH(avgpool_time_kernel, grid, 256, 0, stream, x, pooled, B, Hr, Wc * C);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_l2norm_scale_f32(const float *f, float *e, int B, int D, float alpha, float eps, void *stream) {
+    DS_REQUIRE(f && e, DS_ERR_NULL);
+    DS_REQUIRE(B > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(l2norm_scale_kernel, ds_ceil_div(B, 4), 256, 0, stream, f, e, B, D, alpha, eps);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_pairwise_distance_f32(const float *x1, const float *x2, float *d, int N, int D, void *stream) {
+    DS_REQUIRE(x1 && x2 && d, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    const float eps = (float)(1e-4 / (double)D);     // model.py:15
+    DS_LAUNCH(pairwise_distance_kernel, ds_ceil_div(N, 4), 256, 0, stream, x1, x2, d, N, D, eps);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_triplet_margin_fwd_f32(const float *a, const float *p, const float *n, float margin, float *d_p,
+                                         float *d_n, float *loss, int N, int D, void *stream) {
+    DS_REQUIRE(a && p && n && d_p && d_n && loss, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    const float eps = (float)(1e-4 / (double)D);
+    DS_LAUNCH(triplet_dist_kernel, ds_ceil_div(N, 4), 256, 0, stream, a, p, n, d_p, d_n, N, D, eps);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(hinge_mean_kernel, 1, 256, 64, stream, (const float *)d_p, (const float *)d_n, margin, loss, N);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_triplet_filter_f32(const float *d_p, const float *d_n, float margin, long long *idx, int *count,
+                                     float *mean_diff, int N, void *stream) {
+    DS_REQUIRE(d_p && d_n && idx && count && mean_diff, DS_ERR_NULL);
+    DS_REQUIRE(N > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(triplet_filter_kernel, 1, 256, 64, stream, d_p, d_n, margin, idx, count, mean_diff, N);
+    return ds_last_launch_error();
+}

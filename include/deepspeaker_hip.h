@@ -1,0 +1,133 @@
+/*
+ * deepspeaker_hip.h -- C ABI of libdeepspeaker_hip.so (MI355X / gfx950).
+ *
+ * The reference (qqueing/DeepSpeaker-pytorch) is pure Python: it has no FFI or
+ * plugin interface.  Its hot path is the Python surface of model.py as used by
+ * train_triplet.py; every tensor op that surface executes
+ * through ATen/cuDNN is replaced here by one entry point.  Each declaration
+ * cites the reference line(s) whose arithmetic it takes over.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers and sizes, no torch types; `stream` is a hipStream_t
+ *     passed as void* (the caller's current stream).  Work is only enqueued; the
+ *     library never synchronises, allocates, frees or keeps mutable global state,
+ *     so every call is re-entrant and hipGraph-capturable.
+ *   - the caller owns all buffers (inputs, outputs, scratch).
+ *   - return value: 0 = DS_OK, negative = argument error (below), positive = the
+ *     hipError_t of a failed launch.  Nothing throws, aborts or prints.
+ *   - activations are channels-last fp32:  [B, T', F', C]  (the reference's NCHW
+ *     tensors [B, C, T', F'] permuted; for the network input C = 1, so the
+ *     reference's [B,1,T,64] buffer is consumed bit-for-bit as [B,T,64,1]).
+ *     ds_nchw_to_nhwc_f32 / ds_nhwc_to_nchw_f32 convert for per-op use.
+ *   - convolution weights are consumed in a packed layout produced once per
+ *     weight version by ds_pack_* from the reference's OIHW / [out,in] tensors.
+ *   - pointers must be 16-byte aligned (every torch allocation is).
+ */
+#ifndef DEEPSPEAKER_HIP_H
+#define DEEPSPEAKER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_OK               0
+#define DS_ERR_BAD_SHAPE   (-1)
+#define DS_ERR_ALIGNMENT   (-2)
+#define DS_ERR_NULL        (-3)
+#define DS_ERR_UNSUPPORTED (-4)
+
+/* epilogue flags of the convolution entry points */
+#define DS_EPI_AFFINE   1   /* y = acc * scale[c] + shift[c]   (BatchNorm with fixed statistics) */
+#define DS_EPI_RESIDUAL 2   /* y += residual                    (model.py:79)                      */
+#define DS_EPI_CLIP     4   /* y = min(max(y, 0), 20)           (model.py:36-44)                   */
+#define DS_EPI_STATS    8   /* also emit per-tile column sums {sum, sum of squares} of the RAW
+                               accumulator (train-mode BatchNorm statistics)                       */
+
+#define DS_CONV_CK      8   /* input-channel chunk of the packed weight layout */
+
+int ds_version(void);
+const char *ds_error_string(int code);
+
+/* ---- layout ---------------------------------------------------------------------------------- */
+int ds_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
+int ds_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
+
+/* ---- weight packing (one-off per weight version; not on the per-batch path) ------------------- */
+/* OIHW [Cout,Cin,KS,KS] -> [Cin/8][KS*KS][Cout][8].  dgrad != 0 packs the transposed, spatially
+ * flipped filter bank used by ds_conv_dgrad_f32 (Cout and Cin swap roles).
+ * Replaces: nothing in the reference (cuDNN picks its own filter layout, model.py:47-50,93-106). */
+int ds_pack_conv_weight_f32(const float *w_oihw, float *w_packed, int Cout, int Cin, int KS,
+                            int dgrad, void *stream);
+/* conv1 weight [64,1,5,5] -> [25][64]  (model.py:93) */
+int ds_pack_conv1_weight_f32(const float *w_oihw, float *w_packed, int Cout, void *stream);
+/* fc weight [N, C*F] indexed c*F+f (model.py:164,208) -> 1x1-conv packing over k' = f*C + c,
+ * the order in which ds_avgpool_time_f32 emits the pooled features. */
+int ds_pack_fc_weight_f32(const float *w, float *w_packed, int N, int C, int F, void *stream);
+
+/* ---- BatchNorm ---------------------------------------------------------------------------------- */
+/* eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
+ * (model.py:70,74,188,193,198,203 with module.eval()). */
+int ds_bn_fold_f32(const float *gamma, const float *beta, const float *running_mean,
+                   const float *running_var, float eps, float *scale, float *shift, int C,
+                   void *stream);
+/* train mode: reduce the per-tile partial sums written under DS_EPI_STATS, produce batch mean /
+ * invstd, the affine (scale, shift) that normalises with them, and update the running statistics
+ * in place (momentum, unbiased variance) exactly like nn.BatchNorm2d.train() -- SURVEY 8(a) a2. */
+int ds_bn_stats_finalize_f32(const float *partial, int n_partial, long long count,
+                             const float *gamma, const float *beta, float eps, float momentum,
+                             float *running_mean, float *running_var, float *batch_mean,
+                             float *batch_invstd, float *scale, float *shift, int C, void *stream);
+/* y = [clip]( x * scale[c] + shift[c] [+ residual] ) over n_pix pixels of C channels. */
+int ds_bn_apply_f32(const float *x, const float *scale, const float *shift, const float *residual,
+                    float *y, long long n_pix, int C, int flags, void *stream);
+
+/* ---- convolutions ------------------------------------------------------------------------------- */
+typedef struct ds_conv_shape {
+    int B, H, W, Cin;   /* input  [B,H,W,Cin]                        */
+    int Cout, KS;       /* square KS x KS filter, padding KS/2       */
+    int stride;         /* 1 or 2                                    */
+} ds_conv_shape;
+
+int ds_conv_out_dims(const ds_conv_shape *s, int *Ho, int *Wo);
+/* number of [Cout][2] partial-statistics rows DS_EPI_STATS writes for this shape */
+int ds_conv_stats_rows(const ds_conv_shape *s);
+
+int ds_conv5x5s2_c1_stats_rows(int B, int H);
+/* conv1: 5x5 stride 2 pad 2, Cin = 1 -> 64 channels (model.py:93,187) fused with the following
+ * BatchNorm affine + clipped ReLU (model.py:188-189).  x is the network input [B,H,W]. */
+int ds_conv5x5s2_c1_fwd_f32(const float *x, const float *w_packed, const float *scale,
+                            const float *shift, float *y, float *stats_partial, int B, int H,
+                            int W, int Cout, int flags, void *stream);
+/* generic implicit-GEMM convolution on the f32 matrix cores: 3x3 s1 p1 (model.py:47-50,69,73),
+ * 5x5 s2 p2 (model.py:98,102,106 / :192,197,202) and 1x1 (the fc GEMM, model.py:209), with the
+ * BatchNorm / residual / clipped-ReLU epilogue selected by `flags`. */
+int ds_conv_fwd_f32(const ds_conv_shape *s, const float *x, const float *w_packed,
+                    const float *scale, const float *shift, const float *residual, float *y,
+                    float *stats_partial, int flags, void *stream);
+
+/* ---- tail: temporal average pool, L2 normalisation --------------------------------------------- */
+/* x [B,Hr,Wc,C] -> pooled [B, Wc*C] (index f*C + c), mean over Hr  (model.py:111,207-208) */
+int ds_avgpool_time_f32(const float *x, float *pooled, int B, int Hr, int Wc, int C, void *stream);
+/* e = alpha * f / sqrt(sum f^2 + eps) per row  (model.py:172-183, 210-213) */
+int ds_l2norm_scale_f32(const float *f, float *e, int B, int D, float alpha, float eps,
+                        void *stream);
+
+/* ---- loss side ----------------------------------------------------------------------------------- */
+/* d[i] = sqrt(sum_k (x1[i,k]-x2[i,k])^2 + 1e-4/D)   (PairwiseDistance, model.py:13-18, p = 2) */
+int ds_pairwise_distance_f32(const float *x1, const float *x2, float *d, int N, int D,
+                             void *stream);
+/* TripletMarginLoss.forward (model.py:27-33): writes d_p[N], d_n[N] and loss[1] = mean hinge. */
+int ds_triplet_margin_fwd_f32(const float *a, const float *p, const float *n, float margin,
+                              float *d_p, float *d_n, float *loss, int N, int D, void *stream);
+/* the reference's triplet "mining" (train_triplet.py:251-262): idx = ascending i with
+ * d_n[i] - d_p[i] < margin; count[0] = number selected; mean_diff[0] = mean(d_n - d_p). */
+int ds_triplet_filter_f32(const float *d_p, const float *d_n, float margin, long long *idx,
+                          int *count, float *mean_diff, int N, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPSPEAKER_HIP_H */

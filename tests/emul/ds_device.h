@@ -1,0 +1,60 @@
+// TEST INFRASTRUCTURE -- host stand-in for csrc/ds_device.h (same API, emulated semantics).
+// The MFMA model follows the documented gfx950 fragment layout of v_mfma_f32_32x32x2_f32:
+//   lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+//   D[row = (reg&3) + 8*(reg>>2) + 4*(l>>5)][col = l&31], k accumulated in order with fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline f32x16 ds_mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    float A[64], B[64];
+    emu::wave_exchange(a, A);
+    emu::wave_exchange(b, B);
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        acc = fmaf(A[row], B[col], acc);                 // k = 0
+        acc = fmaf(A[row + 32], B[col + 32], acc);       // k = 1
+        c[r] = acc;
+    }
+    return c;
+}
+
+static inline float ds_shfl_xor(float v, int mask) {
+    float all[64];
+    emu::wave_exchange(v, all);
+    return all[(threadIdx.x & 63) ^ mask];
+}
+static inline float ds_shfl_down(float v, int d) {
+    float all[64];
+    emu::wave_exchange(v, all);
+    const int l = (threadIdx.x & 63) + d;
+    return l < 64 ? all[l] : v;
+}
+static inline int ds_shfl_xor_i(int v, int mask) {
+    float f, all[64];
+    memcpy(&f, &v, 4);
+    emu::wave_exchange(f, all);
+    int r;
+    memcpy(&r, &all[(threadIdx.x & 63) ^ mask], 4);
+    return r;
+}
+static inline unsigned long long ds_ballot(int pred) {
+    float all[64];
+    emu::wave_exchange(pred ? 1.0f : 0.0f, all);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (all[l] != 0.0f) m |= 1ull << l;
+    return m;
+}
+
+static inline float *ds_dynamic_lds() { return emu::dynamic_lds(); }
+
+#define DS_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
+    emu::launch((int)(grid), (int)(block), (size_t)(lds_bytes), [=]() { kernel(__VA_ARGS__); })
+
+static inline int ds_last_launch_error() { return 0; }

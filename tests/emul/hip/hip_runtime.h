@@ -1,0 +1,43 @@
+// TEST INFRASTRUCTURE -- host stand-in for <hip/hip_runtime.h>.
+//
+// Lets the unmodified kernel sources under deepspeaker-pytorch_amd/csrc/ be compiled with the
+// host clang++ and executed lane-by-lane on a CPU: every GPU thread becomes a cooperative
+// fiber, a workgroup is a set of fibers scheduled round-robin, wavefront collectives and
+// __syncthreads() are rendezvous points (emu_runtime.cpp).  Used only by tests/ to debug
+// indexing / fragment-layout logic without a GPU; it is never loaded by the product package.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+namespace emu {
+struct Dim3 { unsigned x, y, z; };
+struct Idx {
+    static Dim3 &tid();
+    static Dim3 &bid();
+    static Dim3 &bdim();
+    static Dim3 &gdim();
+};
+void syncthreads();
+float *dynamic_lds();
+void launch(int grid, int block, size_t lds_bytes, const std::function<void()> &body);
+// wavefront collectives (64 lanes)
+void wave_exchange(float mine, float *all64);          // all64[l] = lane l's `mine`
+}  // namespace emu
+
+#define threadIdx (emu::Idx::tid())
+#define blockIdx (emu::Idx::bid())
+#define blockDim (emu::Idx::bdim())
+#define gridDim (emu::Idx::gdim())
+
+static inline void __syncthreads() { emu::syncthreads(); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+typedef void *hipStream_t;
