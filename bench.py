@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: embeddings/s of the Deep Speaker hot path on MI355X.
+
+One step = BASELINE.json configs[1]: eval-mode forward of the full ResCNN (64/128/256/512) on 256
+synthetic triplets -- three batches (anchor / positive / negative) of 256 [1,160,64] fbank
+utterances, i.e. 768 embeddings -- followed by the triplet margin loss and the triplet filter
+(reference model.py:185-218, 27-33; train_triplet.py:251-262), inputs resident in HBM.  With
+--gpus N > 1 every rank runs the same per-GPU work on its own triplets (weak scaling) and the
+embeddings are all-gathered over RCCL so every rank holds the global batch for mining.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+BATCH_TRIPLETS = 256
+FRAMES = 160
+FWD_FLOPS_PER_EMB = 2 * 1153335296
+F32_MFMA_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(sd_np, budget_s=12.0):
+    """The reference's CPU forward (torch ATen/oneDNN; restated in oracle/torch_restatement.py because
+    /root/reference is absent on the GPU box), eval mode, fp32, on all host cores.  Bounded sample."""
+    import torch_restatement as TR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
+    B = 64
+    x = torch.randn(B, 1, FRAMES, 64)
+    with torch.no_grad():
+        TR.forward_eval(sd, x)                                   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            TR.forward_eval(sd, x)
+            n += B
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= 64 * B:
+                break
+    return {"value": round(n / dt, 1), "unit": "embeddings/s", "cores": cores, "kind": "port",
+            "sample": f"{n} utterances [1,{FRAMES},64] in batches of {B}, eval forward, fp32, "
+                      f"torch {torch.__version__} CPU ({cores} threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
+
+    import deepspeaker_oracle as O
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss, get_engine
+    from deepspeaker_pytorch_amd.mining import select_triplets
+
+    sd_np = O.make_state_dict(seed=0, num_classes=1211)
+    model = DeepSpeakerModel(512, 1211)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
+    model = model.to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    data = [torch.randn(BATCH_TRIPLETS, 1, FRAMES, 64, generator=g).to(dev) for _ in range(3)]
+    loss_fn = TripletMarginLoss(0.1)
+    eng = get_engine()
+    gathered = [torch.empty(world * BATCH_TRIPLETS, 512, device=dev) for _ in range(3)] if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            embs = [model(x) for x in data]
+            if world > 1:
+                for buf, e in zip(gathered, embs):
+                    dist.all_gather_into_tensor(buf, e)
+            loss = loss_fn.forward(*embs)
+            sel = select_triplets(*embs, margin=0.1)
+        return loss, sel
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof, eng.profile = eng.profile, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        emb_per_step = 3 * BATCH_TRIPLETS * world
+        value = emb_per_step * args.steps / elapsed
+        # live roofline of the dominant kernel family (the f32-MFMA implicit-GEMM convolution):
+        # algorithmic FLOPs of every launch / its event-measured duration on the launch stream
+        flops = sum(p[1] for p in prof)
+        ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        by = {}
+        for label, fl, e0, e1 in prof:
+            d = by.setdefault(label, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += e0.elapsed_time(e1)
+            d[2] += 1
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out = {
+            "metric": "embeddings/sec (64-fbank x 160-frame utterances)",
+            "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: full DeepSpeaker ResCNN (64/128/256/512) eval forward + "
+                                   "triplet loss + filter, 256 triplets = 768 x [1,160,64] utterances per GPU per step",
+                       "batch_triplets": BATCH_TRIPLETS, "utterances_per_step_per_gpu": 3 * BATCH_TRIPLETS,
+                       "frames": FRAMES, "parallelism": f"dp{world}",
+                       "arith": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations"},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel (implicit-GEMM 3x3/5x5/1x1, both tile shapes)",
+                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": len(prof), "avg_launch_ms": round(ms / max(len(prof), 1), 4),
+                         "conv_ms_per_step": round(ms / args.steps, 3),
+                         "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}},
+            "whole_forward_tflops": round(value * FWD_FLOPS_PER_EMB / 1e12, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd_np)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

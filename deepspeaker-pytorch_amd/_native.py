@@ -49,6 +49,10 @@ _SIGNATURES = {
     "ds_pairwise_distance_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_margin_fwd_f32": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_filter_f32": (c_int, [_P, _P, c_float, _P, _P, _P, c_int, _P]),
+    "ds_pairwise_distance_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "ds_triplet_margin_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P]),
+    "ds_l2norm_scale_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "ds_avgpool_time_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
 }
 
 

@@ -139,7 +139,122 @@ __global__ void __launch_bounds__(256) triplet_filter_kernel(const float *d_p, c
     }
 }
 
+// ---- backward of the loss side (autograd of model.py:13-18, 27-33) -------------------------------
+// d = sqrt(sum (x1-x2)^2 + eps)  ->  dx1 = gd * (x1-x2)/d, dx2 = -dx1
+__global__ void __launch_bounds__(256) pairwise_distance_bwd_kernel(const float *x1, const float *x2, const float *d,
+                                                                    const float *gd, float *g1, float *g2, int N,
+                                                                    int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < N) {
+        const float c = gd[row] / d[row];
+        const size_t o = (size_t)row * D;
+        for (int k = lane; k < D; k += 64) {
+            const float g = c * (x1[o + k] - x2[o + k]);
+            g1[o + k] = g;
+            g2[o + k] = -g;
+        }
+    }
+}
+
+// loss = mean_i max(0, margin + d_p - d_n); clamp(min=0) passes gradient where its input >= 0
+__global__ void __launch_bounds__(256) triplet_margin_bwd_kernel(const float *a, const float *p, const float *n,
+                                                                 const float *d_p, const float *d_n, float margin,
+                                                                 const float *gloss, float *ga, float *gp, float *gn,
+                                                                 int N, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < N) {
+        const float act = (margin + d_p[row] - d_n[row]) >= 0.0f ? gloss[0] / (float)N : 0.0f;
+        const float cp = act / d_p[row], cn = act / d_n[row];
+        const size_t o = (size_t)row * D;
+        for (int k = lane; k < D; k += 64) {
+            const float av = a[o + k];
+            const float tp = cp * (av - p[o + k]);
+            const float tn = cn * (av - n[o + k]);
+            ga[o + k] = tp - tn;
+            gp[o + k] = -tp;
+            gn[o + k] = tn;
+        }
+    }
+}
+
+// f -> e = alpha f / |f|:  gf = alpha * (ge / nrm - f * <ge,f> / nrm^3)
+__global__ void __launch_bounds__(256) l2norm_scale_bwd_kernel(const float *f, const float *ge, float *gf, int B, int D,
+                                                               float alpha, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t o = (size_t)(row < B ? row : 0) * D;
+    float ss = 0.f, dot = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float v = f[o + k];
+        ss += v * v;
+        dot += v * ge[o + k];
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float nrm = sqrtf(ss + eps);
+    const float inv = 1.0f / nrm, c = dot / (nrm * nrm * nrm);
+    if (row < B)
+        for (int k = lane; k < D; k += 64) gf[o + k] = alpha * (ge[o + k] * inv - f[o + k] * c);
+}
+
+// pooled-gradient broadcast: gx[b,h,:,:] = gpooled[b,:] / Hr for every h, gated by the clip mask of the
+// stage output `out` (0 < out < 20), i.e. the backward of clip -> mean over time in one pass
+__global__ void __launch_bounds__(256) avgpool_time_bwd_kernel(const float *gpooled, const float *out, float *gx, int B,
+                                                               int Hr, int row_elems) {
+    const int vec_per_row = row_elems >> 2;
+    const long long n = (long long)B * Hr * vec_per_row;
+    const float hr = (float)Hr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i % vec_per_row);
+        const int b = (int)(i / ((long long)Hr * vec_per_row));
+        f32x4 g = ((const f32x4 *)(gpooled + (size_t)b * row_elems))[v];
+        const f32x4 o = ((const f32x4 *)out)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (o[j] > 0.0f && o[j] < 20.0f) ? g[j] / hr : 0.0f;
+        ((f32x4 *)gx)[i] = g;
+    }
+}
+
 }  // namespace
+
+extern "C" int ds_pairwise_distance_bwd_f32(const float *x1, const float *x2, const float *d, const float *gd,
+                                            float *g1, float *g2, int N, int D, void *stream) {
+    DS_REQUIRE(x1 && x2 && d && gd && g1 && g2, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(pairwise_distance_bwd_kernel, ds_ceil_div(N, 4), 256, 0, stream, x1, x2, d, gd, g1, g2, N, D);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_triplet_margin_bwd_f32(const float *a, const float *p, const float *n, const float *d_p,
+                                         const float *d_n, float margin, const float *grad_loss, float *ga,
+                                         float *gp, float *gn, int N, int D, void *stream) {
+    DS_REQUIRE(a && p && n && d_p && d_n && grad_loss && ga && gp && gn, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(triplet_margin_bwd_kernel, ds_ceil_div(N, 4), 256, 0, stream, a, p, n, d_p, d_n, margin, grad_loss, ga,
+              gp, gn, N, D);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_l2norm_scale_bwd_f32(const float *f, const float *ge, float *gf, int B, int D, float alpha,
+                                       float eps, void *stream) {
+    DS_REQUIRE(f && ge && gf, DS_ERR_NULL);
+    DS_REQUIRE(B > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(l2norm_scale_bwd_kernel, ds_ceil_div(B, 4), 256, 0, stream, f, ge, gf, B, D, alpha, eps);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_avgpool_time_bwd_f32(const float *gpooled, const float *out, float *gx, int B, int Hr, int Wc,
+                                       int C, void *stream) {
+    DS_REQUIRE(gpooled && out && gx, DS_ERR_NULL);
+    DS_REQUIRE(B > 0 && Hr > 0 && Wc > 0 && C > 0 && (C % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(gpooled) && DS_ALIGNED16(out) && DS_ALIGNED16(gx), DS_ERR_ALIGNMENT);
+    const long long n = (long long)B * Hr * (Wc * C / 4);
+    long long g = (n + 255) / 256;
+    DS_LAUNCH(avgpool_time_bwd_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, gpooled, out, gx, B, Hr, Wc * C);
+    return ds_last_launch_error();
+}
 
 extern "C" int ds_avgpool_time_f32(const float *x, float *pooled, int B, int Hr, int Wc, int C, void *stream) {
     DS_REQUIRE(x && pooled, DS_ERR_NULL);

@@ -1,0 +1,327 @@
+"""Host-side orchestration of the HIP kernels for the Deep Speaker ResCNN.
+
+`Engine` turns one call of the reference's `DeepSpeakerModel.forward` (reference model.py:185-218)
+into the sequence of C-ABI launches declared in include/deepspeaker_hip.h.  It owns no arithmetic:
+every tensor op is a kernel in libdeepspeaker_hip.so; torch supplies buffers and the stream.
+
+Data layout in HBM: activations are channels-last fp32 `[B, T', F', C]`; the network
+input `[B,1,T,64]` is consumed in place (C = 1).  Filters are packed once per weight version.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ._native import (ConvShape, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_RESIDUAL, DS_EPI_STATS, NativeLib)
+
+STAGE_CHANNELS = (64, 128, 256, 512)        # reference model.py:93-107
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+L2_EPS = 1e-10                               # reference model.py:176
+ALPHA = 10.0                                 # reference model.py:212
+
+
+def conv_out(n: int, k: int, stride: int) -> int:
+    return (n + 2 * (k // 2) - k) // stride + 1
+
+
+@dataclass
+class BNParams:
+    weight: torch.Tensor
+    bias: torch.Tensor
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+
+
+@dataclass
+class StageWeights:
+    conv: torch.Tensor              # packed 5x5 (stage 1: [25][64])
+    l_conv1: torch.Tensor           # packed 3x3
+    l_conv2: torch.Tensor
+    conv_dgrad: Optional[torch.Tensor] = None
+    l_conv1_dgrad: Optional[torch.Tensor] = None
+    l_conv2_dgrad: Optional[torch.Tensor] = None
+
+
+@dataclass
+class PackedWeights:
+    stages: List[StageWeights]
+    fc: torch.Tensor                # packed as a 1x1 convolution over k' = f*C + c
+    fc_bias: torch.Tensor
+    fc_ones: torch.Tensor
+
+
+@dataclass
+class SavedForward:
+    """What the backward pass needs from one train-mode forward (all channels-last)."""
+    x: torch.Tensor
+    acts: Dict[str, torch.Tensor] = field(default_factory=dict)      # post-activation tensors
+    raws: Dict[str, torch.Tensor] = field(default_factory=dict)      # raw conv outputs (BN inputs)
+    stats: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = field(default_factory=dict)
+    pooled: Optional[torch.Tensor] = None
+    fc_out: Optional[torch.Tensor] = None
+    dims: List[Tuple[int, int]] = field(default_factory=list)
+
+
+class Engine:
+    def __init__(self, lib: NativeLib):
+        self.lib = lib
+        # When set to a list, every implicit-GEMM convolution launch is bracketed by two events on the
+        # launch stream and (label, flops, start, end) is appended (bench.py's live roofline).
+        self.profile: Optional[list] = None
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _stream(t: torch.Tensor):
+        if t.is_cuda:
+            return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return None
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _check(t: torch.Tensor, name: str):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError(f"{name}: expected a contiguous float32 tensor, got {t.dtype}, "
+                             f"contiguous={t.is_contiguous()}")
+
+    # ------------------------------------------------------------------ weights
+    def pack_weights(self, sd: Dict[str, torch.Tensor], n_stages: int = 4,
+                     with_dgrad: bool = False) -> PackedWeights:
+        """OIHW / [out,in] parameters (reference shapes) -> kernel layouts."""
+        lib = self.lib
+        stages = []
+        for s in range(n_stages):
+            i = s + 1
+            w = sd[f"model.conv{i}.weight"].detach()
+            self._check(w, f"model.conv{i}.weight")
+            st = self._stream(w)
+            co, ci = w.shape[0], w.shape[1]
+            pc = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+            if i == 1:
+                lib.call("ds_pack_conv1_weight_f32", self._p(w), self._p(pc), co, st)
+            else:
+                lib.call("ds_pack_conv_weight_f32", self._p(w), self._p(pc), co, ci, 5, 0, st)
+            packs = []
+            for j in (1, 2):
+                wl = sd[f"model.layer{i}.0.conv{j}.weight"].detach()
+                self._check(wl, f"model.layer{i}.0.conv{j}.weight")
+                pl = torch.empty(wl.numel(), dtype=torch.float32, device=wl.device)
+                lib.call("ds_pack_conv_weight_f32", self._p(wl), self._p(pl), co, co, 3, 0, st)
+                packs.append(pl)
+            sw = StageWeights(pc, packs[0], packs[1])
+            if with_dgrad:
+                if i > 1:
+                    sw.conv_dgrad = torch.empty_like(pc)
+                    lib.call("ds_pack_conv_weight_f32", self._p(w), self._p(sw.conv_dgrad), co, ci, 5, 1, st)
+                for j, attr in ((1, "l_conv1_dgrad"), (2, "l_conv2_dgrad")):
+                    wl = sd[f"model.layer{i}.0.conv{j}.weight"].detach()
+                    pd = torch.empty(wl.numel(), dtype=torch.float32, device=wl.device)
+                    lib.call("ds_pack_conv_weight_f32", self._p(wl), self._p(pd), co, co, 3, 1, st)
+                    setattr(sw, attr, pd)
+            stages.append(sw)
+        wfc = sd["model.fc.weight"].detach()
+        bfc = sd["model.fc.bias"].detach()
+        self._check(wfc, "model.fc.weight")
+        c_last = STAGE_CHANNELS[n_stages - 1]
+        f_bins = wfc.shape[1] // c_last
+        pfc = torch.empty(wfc.numel(), dtype=torch.float32, device=wfc.device)
+        lib.call("ds_pack_fc_weight_f32", self._p(wfc), self._p(pfc), wfc.shape[0], c_last, f_bins,
+                 self._stream(wfc))
+        ones = torch.ones(wfc.shape[0], dtype=torch.float32, device=wfc.device)
+        return PackedWeights(stages, pfc, bfc.contiguous(), ones)
+
+    def bn_fold(self, bn: BNParams) -> Tuple[torch.Tensor, torch.Tensor]:
+        c = bn.weight.numel()
+        scale = torch.empty(c, dtype=torch.float32, device=bn.weight.device)
+        shift = torch.empty_like(scale)
+        self.lib.call("ds_bn_fold_f32", self._p(bn.weight.detach()), self._p(bn.bias.detach()),
+                      self._p(bn.running_mean), self._p(bn.running_var), BN_EPS, self._p(scale),
+                      self._p(shift), c, self._stream(scale))
+        return scale, shift
+
+    # ------------------------------------------------------------------ single launches
+    def conv(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, cin: int, cout: int,
+             ks: int, stride: int, scale=None, shift=None, residual=None, flags: int = 0,
+             want_stats: bool = False):
+        shp = ConvShape(B, H, W, cin, cout, ks, stride)
+        ho, wo = conv_out(H, ks, stride), conv_out(W, ks, stride)
+        y = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=x.device)
+        stats = None
+        if want_stats:
+            rows = self.lib.raw("ds_conv_stats_rows")(ctypes.byref(shp))
+            if rows <= 0:
+                raise RuntimeError(f"ds_conv_stats_rows failed: {rows}")
+            stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
+            flags |= DS_EPI_STATS
+        prof = self.profile is not None and x.is_cuda
+        if prof:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        self.lib.call("ds_conv_fwd_f32", ctypes.byref(shp), self._p(x), self._p(wp), self._p(scale),
+                      self._p(shift), self._p(residual), self._p(y), self._p(stats), flags, self._stream(x))
+        if prof:
+            ev1.record()
+            self.profile.append((f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}",
+                                 2.0 * B * ho * wo * cout * cin * ks * ks, ev0, ev1))
+        return y, stats
+
+    def conv1(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, scale=None, shift=None,
+              flags: int = 0, want_stats: bool = False):
+        ho, wo = conv_out(H, 5, 2), conv_out(W, 5, 2)
+        y = torch.empty((B, ho, wo, 64), dtype=torch.float32, device=x.device)
+        stats = None
+        if want_stats:
+            rows = self.lib.raw("ds_conv5x5s2_c1_stats_rows")(B, H)
+            stats = torch.empty((rows, 64, 2), dtype=torch.float32, device=x.device)
+            flags |= DS_EPI_STATS
+        self.lib.call("ds_conv5x5s2_c1_fwd_f32", self._p(x), self._p(wp), self._p(scale), self._p(shift),
+                      self._p(y), self._p(stats), B, H, W, 64, flags, self._stream(x))
+        return y, stats
+
+    def bn_finalize(self, stats: torch.Tensor, count: int, bn: BNParams, update_running: bool = True):
+        c = bn.weight.numel()
+        dev = stats.device
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        scale = torch.empty_like(mean)
+        shift = torch.empty_like(mean)
+        self.lib.call("ds_bn_stats_finalize_f32", self._p(stats), stats.shape[0], count,
+                      self._p(bn.weight.detach()), self._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM,
+                      self._p(bn.running_mean) if update_running else None,
+                      self._p(bn.running_var) if update_running else None,
+                      self._p(mean), self._p(invstd), self._p(scale), self._p(shift), c, self._stream(stats))
+        return mean, invstd, scale, shift
+
+    def bn_apply(self, x: torch.Tensor, scale, shift, residual=None, flags: int = 0):
+        y = torch.empty_like(x)
+        c = x.shape[-1]
+        self.lib.call("ds_bn_apply_f32", self._p(x), self._p(scale), self._p(shift), self._p(residual),
+                      self._p(y), x.numel() // c, c, flags, self._stream(x))
+        return y
+
+    # ------------------------------------------------------------------ tail
+    def tail(self, a: torch.Tensor, pw: PackedWeights, saved: Optional[SavedForward] = None):
+        B, hr, wc, c = a.shape
+        pooled = torch.empty((B, wc * c), dtype=torch.float32, device=a.device)
+        self.lib.call("ds_avgpool_time_f32", self._p(a), self._p(pooled), B, hr, wc, c, self._stream(a))
+        n_out = pw.fc_bias.numel()
+        # fc as a 1x1 convolution over a [1, B, 1, K] image (reference model.py:209)
+        f, _ = self.conv(pooled, pw.fc, 1, B, 1, wc * c, n_out, 1, 1, scale=pw.fc_ones,
+                         shift=pw.fc_bias.detach(), flags=DS_EPI_AFFINE)
+        f = f.view(B, n_out)
+        e = torch.empty_like(f)
+        self.lib.call("ds_l2norm_scale_f32", self._p(f), self._p(e), B, n_out, ALPHA, L2_EPS, self._stream(f))
+        if saved is not None:
+            saved.pooled, saved.fc_out = pooled, f
+        return e
+
+    # ------------------------------------------------------------------ forward passes
+    def forward_eval(self, x: torch.Tensor, pw: PackedWeights, folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]],
+                     taps: Optional[dict] = None) -> torch.Tensor:
+        """Eval-mode forward: BatchNorm (running statistics), residual add and clipped ReLU all live in
+        the convolution epilogues -- 3 launches per stage, no intermediate normalisation pass."""
+        self._check(x, "input")
+        B, one, T, F = x.shape
+        if one != 1:
+            raise ValueError("input must be [B,1,T,F] (reference model.py:185, SURVEY F1)")
+        h, w, cin = T, F, 1
+        a = x
+        AC = DS_EPI_AFFINE | DS_EPI_CLIP
+        for s, sw in enumerate(pw.stages):
+            i, c = s + 1, STAGE_CHANNELS[s]
+            sc, sh = folded[f"model.bn{i}"]
+            if i == 1:
+                a, _ = self.conv1(a, sw.conv, B, h, w, sc, sh, AC)
+            else:
+                a, _ = self.conv(a, sw.conv, B, h, w, cin, c, 5, 2, sc, sh, None, AC)
+            h, w, cin = conv_out(h, 5, 2), conv_out(w, 5, 2), c
+            if taps is not None:
+                taps[f"stage{i}.a"] = a
+            sc, sh = folded[f"model.layer{i}.0.bn1"]
+            y, _ = self.conv(a, sw.l_conv1, B, h, w, c, c, 3, 1, sc, sh, None, AC)
+            if taps is not None:
+                taps[f"stage{i}.b"] = y
+            sc, sh = folded[f"model.layer{i}.0.bn2"]
+            a, _ = self.conv(y, sw.l_conv2, B, h, w, c, c, 3, 1, sc, sh, a, AC | DS_EPI_RESIDUAL)
+            if taps is not None:
+                taps[f"stage{i}.c"] = a
+        return self.tail(a, pw)
+
+    def forward_train(self, x: torch.Tensor, pw: PackedWeights, bns: Dict[str, BNParams],
+                      save: bool = True) -> Tuple[torch.Tensor, Optional[SavedForward]]:
+        """Train-mode forward: each convolution emits its raw output plus per-tile column sums, a
+        finalize kernel turns them into batch statistics (and updates the running ones), and one
+        elementwise pass normalises + adds the residual + clips (nn.BatchNorm2d.train() semantics)."""
+        self._check(x, "input")
+        B, one, T, F = x.shape
+        if one != 1:
+            raise ValueError("input must be [B,1,T,F]")
+        saved = SavedForward(x=x) if save else None
+        h, w, cin = T, F, 1
+        a = x
+        for s, sw in enumerate(pw.stages):
+            i, c = s + 1, STAGE_CHANNELS[s]
+            if i == 1:
+                z, st = self.conv1(a, sw.conv, B, h, w, want_stats=True)
+            else:
+                z, st = self.conv(a, sw.conv, B, h, w, cin, c, 5, 2, want_stats=True)
+            h, w, cin = conv_out(h, 5, 2), conv_out(w, 5, 2), c
+            count = B * h * w
+            name = f"model.bn{i}"
+            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name])
+            a = self.bn_apply(z, sc, sh, None, DS_EPI_CLIP)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, (mean, invstd, sc), a
+            name = f"model.layer{i}.0.bn1"
+            z, st = self.conv(a, sw.l_conv1, B, h, w, c, c, 3, 1, want_stats=True)
+            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name])
+            y = self.bn_apply(z, sc, sh, None, DS_EPI_CLIP)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, (mean, invstd, sc), y
+            name = f"model.layer{i}.0.bn2"
+            z, st = self.conv(y, sw.l_conv2, B, h, w, c, c, 3, 1, want_stats=True)
+            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name])
+            a = self.bn_apply(z, sc, sh, a, DS_EPI_CLIP | DS_EPI_RESIDUAL)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, (mean, invstd, sc), a
+                saved.dims.append((h, w))
+        e = self.tail(a, pw, saved)
+        return e, saved
+
+    # ------------------------------------------------------------------ loss side
+    def pairwise_distance(self, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+        assert x1.size() == x2.size()                       # reference model.py:14
+        self._check(x1, "x1"), self._check(x2, "x2")
+        n, d = x1.shape
+        out = torch.empty(n, dtype=torch.float32, device=x1.device)
+        self.lib.call("ds_pairwise_distance_f32", self._p(x1), self._p(x2), self._p(out), n, d, self._stream(x1))
+        return out
+
+    def triplet_margin(self, a, p, n, margin: float):
+        for t, nm in ((a, "anchor"), (p, "positive"), (n, "negative")):
+            self._check(t, nm)
+        assert a.size() == p.size() == n.size()
+        rows, d = a.shape
+        d_p = torch.empty(rows, dtype=torch.float32, device=a.device)
+        d_n = torch.empty_like(d_p)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        self.lib.call("ds_triplet_margin_fwd_f32", self._p(a), self._p(p), self._p(n), float(margin),
+                      self._p(d_p), self._p(d_n), self._p(loss), rows, d, self._stream(a))
+        return loss, d_p, d_n
+
+    def triplet_filter(self, d_p: torch.Tensor, d_n: torch.Tensor, margin: float):
+        """train_triplet.py:251-262 on the device: returns (idx[int64, N] of which the first `count`
+        entries are valid & ascending, count[int32,1], mean_diff[float32,1]) without synchronising."""
+        n = d_p.numel()
+        idx = torch.empty(n, dtype=torch.int64, device=d_p.device)
+        count = torch.empty(1, dtype=torch.int32, device=d_p.device)
+        mean_diff = torch.empty(1, dtype=torch.float32, device=d_p.device)
+        self.lib.call("ds_triplet_filter_f32", self._p(d_p), self._p(d_n), float(margin), self._p(idx),
+                      self._p(count), self._p(mean_diff), n, self._stream(d_p))
+        return idx, count, mean_diff

@@ -1,0 +1,33 @@
+"""Triplet selection on the device.
+
+`select_triplets` is the reference's per-triplet filter (train_triplet.py:249-274): keep triplet i
+iff d(a_i,n_i) - d(a_i,p_i) < margin, indices ascending as `np.where` returns them.  The reference
+round-trips embeddings AND raw inputs through NumPy on the host to do this; here the distances,
+the mask and the ordered compaction are kernels and only the selected-row count crosses PCIe.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from .model import _require_cuda, get_engine
+
+
+@dataclass
+class TripletSelection:
+    indices: torch.Tensor        # int64 [n_selected], ascending (train_triplet.py:262)
+    d_p: torch.Tensor            # [N]  (train_triplet.py:251)
+    d_n: torch.Tensor            # [N]  (train_triplet.py:252)
+    n_correct: int               # triplets already satisfying the margin (train_triplet.py:256-257)
+    mean_diff: torch.Tensor      # mean(d_n - d_p), 1-element device tensor (train_triplet.py:259-260)
+
+
+def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tensor, margin: float) -> TripletSelection:
+    _require_cuda(out_a, "select_triplets")
+    eng = get_engine()
+    a, p, n = (t.detach().contiguous() for t in (out_a, out_p, out_n))
+    _, d_p, d_n = eng.triplet_margin(a, p, n, margin)
+    idx, count, mean_diff = eng.triplet_filter(d_p, d_n, margin)
+    k = int(count.item())                      # the one host sync: the reference branches on it (:263)
+    return TripletSelection(idx[:k], d_p, d_n, a.shape[0] - k, mean_diff)

@@ -1,0 +1,312 @@
+"""Drop-in replacement for the reference's `model.py` surface.
+
+Same names, constructor arguments, attributes and `state_dict` keys as
+qqueing/DeepSpeaker-pytorch `model.py` (file:line cited per symbol), so that
+`train_triplet.py`-style code (`model(data_a)`, `TripletMarginLoss(m).forward(a, p, n)`,
+`l2_dist.forward(a, b)`, `model.state_dict()`, `optim.Adagrad(model.parameters())`) runs unchanged.
+The arithmetic is done by HIP kernels through `engine.Engine`; the `nn.Conv2d` / `nn.BatchNorm2d` /
+`nn.Linear` children below are parameter containers only (they give identical keys, shapes and
+initialisation) and are never called.
+
+There is no CPU path: tensors must live on a ROCm device, otherwise a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native
+from .engine import ALPHA, BNParams, Engine, L2_EPS, STAGE_CHANNELS
+
+_engine: Optional[Engine] = None
+
+
+def get_engine() -> Engine:
+    """Engine bound to libdeepspeaker_hip.so; raises if the library has not been built."""
+    global _engine
+    if _engine is None:
+        _engine = Engine(_native.load())
+    return _engine
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; deepspeaker-pytorch_amd computes only on an "
+                           "MI355X (ROCm) device and has no CPU fallback -- move the model and inputs with .cuda()")
+
+
+# ---------------------------------------------------------------------------------------------
+# loss side (reference model.py:8-33)
+# ---------------------------------------------------------------------------------------------
+class _PairwiseDistanceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2):
+        eng = get_engine()
+        x1c, x2c = x1.contiguous(), x2.contiguous()
+        d = eng.pairwise_distance(x1c, x2c)
+        ctx.save_for_backward(x1c, x2c, d)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        x1, x2, d = ctx.saved_tensors
+        eng = get_engine()
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
+        gd = gd.contiguous()
+        eng.lib.call("ds_pairwise_distance_bwd_f32", eng._p(x1), eng._p(x2), eng._p(d), eng._p(gd), eng._p(g1),
+                     eng._p(g2), x1.shape[0], x1.shape[1], eng._stream(x1))
+        return g1, g2
+
+
+class PairwiseDistance:
+    """reference model.py:8-18.  `PairwiseDistance(2).forward(x1, x2)` -> [N] distances
+    sqrt(sum |x1-x2|^2 + 1e-4/D).  Only p = 2 exists in the reference's call sites
+    (train_triplet.py:119, model.py:24)."""
+
+    def __init__(self, p):
+        if p != 2:
+            raise NotImplementedError("only the L2 distance (p=2) is used by the reference and implemented")
+        self.norm = p
+
+    def forward(self, x1, x2):
+        assert x1.size() == x2.size()                       # reference model.py:14
+        _require_cuda(x1, "PairwiseDistance")
+        return _PairwiseDistanceFn.apply(x1, x2)
+
+    __call__ = forward
+
+
+class _TripletMarginFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, p, n, margin):
+        eng = get_engine()
+        a, p, n = a.contiguous(), p.contiguous(), n.contiguous()
+        loss, d_p, d_n = eng.triplet_margin(a, p, n, margin)
+        ctx.save_for_backward(a, p, n, d_p, d_n)
+        ctx.margin = margin
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        a, p, n, d_p, d_n = ctx.saved_tensors
+        eng = get_engine()
+        ga, gp, gn = torch.empty_like(a), torch.empty_like(p), torch.empty_like(n)
+        gl = gl.reshape(1).contiguous().float()
+        eng.lib.call("ds_triplet_margin_bwd_f32", eng._p(a), eng._p(p), eng._p(n), eng._p(d_p), eng._p(d_n),
+                     float(ctx.margin), eng._p(gl), eng._p(ga), eng._p(gp), eng._p(gn), a.shape[0], a.shape[1],
+                     eng._stream(a))
+        return ga, gp, gn, None
+
+
+class TripletMarginLoss:
+    """reference model.py:19-33: mean(clamp(margin + d(a,p) - d(a,n), min=0))."""
+
+    def __init__(self, margin):
+        self.margin = margin
+        self.pdist = PairwiseDistance(2)
+
+    def forward(self, anchor, positive, negative):
+        _require_cuda(anchor, "TripletMarginLoss")
+        return _TripletMarginFn.apply(anchor, positive, negative, float(self.margin))
+
+    __call__ = forward
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers mirroring the reference's module tree (model.py:36-130)
+# ---------------------------------------------------------------------------------------------
+class ReLU(nn.Hardtanh):
+    """reference model.py:36-44: clipped ReLU, min(max(x,0),20).  Container only; the clip is fused into the
+    convolution / normalisation kernels."""
+
+    def __init__(self, inplace=False):
+        super().__init__(0, 20, inplace)
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    """reference model.py:47-50"""
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """reference model.py:53-82 (parameters only)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("BasicBlock is a parameter container; call DeepSpeakerModel.forward")
+
+
+class myResNet(nn.Module):
+    """reference model.py:85-120 (parameters + initialisation only).  `n_stages` < 4 builds the
+    "ResCNN-small" prefix of BASELINE.json configs[0]."""
+
+    def __init__(self, block=BasicBlock, layers=(1, 1, 1, 1), n_stages: int = 4):
+        super().__init__()
+        self.relu = ReLU(inplace=True)
+        cin = 1
+        for s in range(n_stages):
+            c, i = STAGE_CHANNELS[s], s + 1
+            setattr(self, f"conv{i}", nn.Conv2d(cin, c, kernel_size=5, stride=2, padding=2, bias=False))
+            setattr(self, f"bn{i}", nn.BatchNorm2d(c))
+            setattr(self, f"layer{i}", nn.Sequential(block(c, c)))
+            cin = c
+        self.avgpool = nn.AdaptiveAvgPool2d((1, None))
+        for m in self.modules():                                    # reference model.py:114-120
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def forward(self, x):
+        raise RuntimeError("myResNet is a parameter container; call DeepSpeakerModel.forward")
+
+
+# ---------------------------------------------------------------------------------------------
+# the network function
+# ---------------------------------------------------------------------------------------------
+class _ResCNNTrainFn(torch.autograd.Function):
+    """Train-mode forward/backward of the whole embedding network as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        eng = get_engine()
+        pw = model._packed(with_dgrad=True)
+        e, saved = eng.forward_train(x, pw, model._bn_params(), save=True)
+        for bn in model._bn_modules():
+            bn.num_batches_tracked += 1                             # nn.BatchNorm2d.train() bookkeeping
+        ctx.saved_forward = saved
+        ctx.model = model
+        ctx.pw = pw
+        ctx.param_names = model._param_names
+        return e
+
+    @staticmethod
+    def backward(ctx, ge):
+        from .backward import backward_train
+        grads = backward_train(get_engine(), ctx.model, ctx.pw, ctx.saved_forward, ge.contiguous())
+        ctx.saved_forward = None
+        return (None, None) + tuple(grads.get(n) for n in ctx.param_names)
+
+
+class DeepSpeakerModel(nn.Module):
+    """reference model.py:153-223.
+
+    `DeepSpeakerModel(embedding_size, num_classes, feature_dim=64)`; `.forward(x[B,1,T,64]) -> [B,512]`
+    L2-normalised x10 embedding (also cached on `.features`, model.py:210-213);
+    `.forward_classifier(x)`; `.l2_norm(t)`.  `state_dict()` has the reference's 76 keys.
+    """
+
+    def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4):
+        super().__init__()
+        if feature_dim != 64:
+            # the reference's feature_dim == 40 branch is dead code that cannot run
+            raise NotImplementedError("only feature_dim=64 is functional in the reference and implemented here")
+        self.embedding_size = embedding_size
+        self.n_stages = n_stages
+        self.model = myResNet(BasicBlock, [1, 1, 1, 1], n_stages=n_stages)
+        c_last = STAGE_CHANNELS[n_stages - 1]
+        f_bins = 64 >> n_stages
+        self.model.fc = nn.Linear(c_last * f_bins, self.embedding_size)       # 512*4 (model.py:164)
+        self.model.classifier = nn.Linear(self.embedding_size, num_classes)   # model.py:167
+        self._pack_cache = None
+        self._pack_key = None
+        self._fold_cache = None
+        self._fold_key = None
+        self._param_names = [n for n, _ in self.named_parameters() if not n.startswith("model.classifier")]
+
+    # ---- caches of derived tensors, invalidated by parameter version counters ----
+    def _bn_modules(self):
+        out = []
+        for i in range(1, self.n_stages + 1):
+            blk = getattr(self.model, f"layer{i}")[0]
+            out += [getattr(self.model, f"bn{i}"), blk.bn1, blk.bn2]
+        return out
+
+    def _bn_names(self):
+        out = []
+        for i in range(1, self.n_stages + 1):
+            out += [f"model.bn{i}", f"model.layer{i}.0.bn1", f"model.layer{i}.0.bn2"]
+        return out
+
+    def _bn_params(self) -> Dict[str, BNParams]:
+        return {n: BNParams(m.weight, m.bias, m.running_mean, m.running_var)
+                for n, m in zip(self._bn_names(), self._bn_modules())}
+
+    def _conv_fc_tensors(self):
+        sd = {}
+        for i in range(1, self.n_stages + 1):
+            blk = getattr(self.model, f"layer{i}")[0]
+            sd[f"model.conv{i}.weight"] = getattr(self.model, f"conv{i}").weight
+            sd[f"model.layer{i}.0.conv1.weight"] = blk.conv1.weight
+            sd[f"model.layer{i}.0.conv2.weight"] = blk.conv2.weight
+        sd["model.fc.weight"] = self.model.fc.weight
+        sd["model.fc.bias"] = self.model.fc.bias
+        return sd
+
+    def _packed(self, with_dgrad: bool = False):
+        sd = self._conv_fc_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (with_dgrad,)
+        if self._pack_key != key:
+            self._pack_cache = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad)
+            self._pack_key = key
+        return self._pack_cache
+
+    def _folded(self):
+        mods = self._bn_modules()
+        key = tuple((t.data_ptr(), t._version) for m in mods
+                    for t in (m.weight, m.bias, m.running_mean, m.running_var))
+        if self._fold_key != key:
+            eng = get_engine()
+            self._fold_cache = {n: eng.bn_fold(b) for n, b in self._bn_params().items()}
+            self._fold_key = key
+        return self._fold_cache
+
+    # ---- reference surface ----
+    def l2_norm(self, input):
+        """reference model.py:172-183: x / sqrt(sum x^2 + 1e-10) (no alpha)."""
+        _require_cuda(input, "l2_norm")
+        eng = get_engine()
+        x = input.contiguous().view(input.size(0), -1)
+        out = torch.empty_like(x)
+        eng.lib.call("ds_l2norm_scale_f32", eng._p(x), eng._p(out), x.shape[0], x.shape[1], 1.0, L2_EPS,
+                     eng._stream(x))
+        return out.view(input.size())
+
+    def forward(self, x):
+        _require_cuda(x, "DeepSpeakerModel.forward")
+        if x.dim() != 4 or x.size(1) != 1 or x.size(3) != 64:
+            raise ValueError(f"expected input [B,1,T,64] (reference model.py:185; SURVEY F1), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        if self.training:
+            params = [p for n, p in self.named_parameters() if not n.startswith("model.classifier")]
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                self.features = _ResCNNTrainFn.apply(x, self, *params)
+            else:
+                e, _ = get_engine().forward_train(x, self._packed(), self._bn_params(), save=False)
+                for bn in self._bn_modules():
+                    bn.num_batches_tracked += 1
+                self.features = e
+        else:
+            self.features = get_engine().forward_eval(x, self._packed(), self._folded())
+        return self.features
+
+    def forward_classifier(self, x):
+        """reference model.py:220-223.  The 512 -> num_classes head stays a library GEMM for now
+        ("next")."""
+        features = self.forward(x)
+        return torch.nn.functional.linear(features, self.model.classifier.weight, self.model.classifier.bias)

@@ -127,6 +127,21 @@ int ds_triplet_margin_fwd_f32(const float *a, const float *p, const float *n, fl
 int ds_triplet_filter_f32(const float *d_p, const float *d_n, float margin, long long *idx,
                           int *count, float *mean_diff, int N, void *stream);
 
+
+/* ---- backward of the loss side and the tail (torch autograd of the lines cited above; the
+ *      reference obtains them from loss.backward(), train_triplet.py:223,290) ------------------- */
+int ds_pairwise_distance_bwd_f32(const float *x1, const float *x2, const float *d, const float *gd,
+                                 float *g1, float *g2, int N, int D, void *stream);
+/* grad_loss points at ONE device float (dL/dloss); clamp(min=0) passes gradient at exactly 0. */
+int ds_triplet_margin_bwd_f32(const float *a, const float *p, const float *n, const float *d_p,
+                              const float *d_n, float margin, const float *grad_loss, float *ga,
+                              float *gp, float *gn, int N, int D, void *stream);
+int ds_l2norm_scale_bwd_f32(const float *f, const float *ge, float *gf, int B, int D, float alpha,
+                            float eps, void *stream);
+/* backward of [clip(0,20) -> mean over time]: gx = (0 < out < 20) ? gpooled / Hr : 0 */
+int ds_avgpool_time_bwd_f32(const float *gpooled, const float *out, float *gx, int B, int Hr, int Wc,
+                            int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,96 @@
+"""Host orchestration (Engine) + unmodified kernels on the host emulator vs the numpy oracle.
+CPU tensors are handed to the emulated library here ONLY to test host logic and kernel indexing
+without a GPU; the product module refuses non-CUDA tensors."""
+import numpy as np
+import pytest
+import torch
+
+import deepspeaker_oracle as O
+from conftest import rel_err
+from emul_util import emul_lib
+from deepspeaker_pytorch_amd.engine import BNParams, Engine
+
+
+def torch_sd(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def bn_names(n_stages):
+    out = []
+    for i in range(1, n_stages + 1):
+        out += [f"model.bn{i}", f"model.layer{i}.0.bn1", f"model.layer{i}.0.bn2"]
+    return out
+
+
+def make_bns(tsd, n_stages):
+    return {n: BNParams(tsd[n + ".weight"], tsd[n + ".bias"], tsd[n + ".running_mean"], tsd[n + ".running_var"])
+            for n in bn_names(n_stages)}
+
+
+@pytest.mark.parametrize("n_stages,B,T", [(4, 2, 32), (2, 3, 21), (4, 1, 50)])
+def test_forward_eval(n_stages, B, T):
+    eng = Engine(emul_lib())
+    sd = O.make_state_dict(seed=5 + n_stages, num_classes=4, n_stages=n_stages)
+    x = O.make_input(seed=6, batch=B, frames=T)
+    tsd = torch_sd(sd)
+    pw = eng.pack_weights(tsd, n_stages)
+    folded = {n: eng.bn_fold(b) for n, b in make_bns(tsd, n_stages).items()}
+    taps = {}
+    e = eng.forward_eval(torch.from_numpy(x), pw, folded, taps)
+    otaps = {}
+    ref = O.forward(sd, x, n_stages=n_stages, dtype=np.float64, taps=otaps)
+    for k, v in taps.items():
+        got = v.numpy().transpose(0, 3, 1, 2)
+        assert rel_err(got, otaps[k]) < 1e-5, k
+    assert rel_err(e.numpy(), ref) < 1e-5
+
+
+def test_forward_train_matches_oracle_and_updates_running_stats():
+    eng = Engine(emul_lib())
+    n_stages, B, T = 4, 2, 32
+    sd = O.make_state_dict(seed=9, num_classes=4)
+    x = O.make_input(seed=10, batch=B, frames=T)
+    tsd = torch_sd(sd)
+    pw = eng.pack_weights(tsd, n_stages)
+    bns = make_bns(tsd, n_stages)
+    e, saved = eng.forward_train(torch.from_numpy(x), pw, bns)
+    new = {}
+    ref = O.forward(sd, x, train=True, dtype=np.float64, new_stats=new)
+    assert rel_err(e.numpy(), ref) < 2e-5
+    for n in bn_names(n_stages):
+        assert rel_err(bns[n].running_mean.numpy(), new[n + ".running_mean"]) < 1e-5, n
+        assert rel_err(bns[n].running_var.numpy(), new[n + ".running_var"]) < 1e-5, n
+    assert set(saved.raws) == set(bn_names(n_stages))
+
+
+def test_loss_side(golden):
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(41)
+    N = 96
+    base = rs.randn(N, 512).astype(np.float32)
+    a = (base / np.linalg.norm(base, axis=1, keepdims=True) * 10).astype(np.float32)
+    p = a + rs.randn(N, 512).astype(np.float32) * 0.05
+    n = a + rs.randn(N, 512).astype(np.float32) * 0.05
+    ta, tp, tn = (torch.from_numpy(v) for v in (a, p, n))
+    loss, d_p, d_n = eng.triplet_margin(ta, tp, tn, 0.1)
+    assert rel_err(d_p.numpy(), golden["loss_d_p"]) < 1e-6
+    assert rel_err(d_n.numpy(), golden["loss_d_n"]) < 1e-6
+    assert abs(float(loss) - float(golden["loss_value"])) < 1e-6
+    idx, count, mean_diff = eng.triplet_filter(d_p, d_n, 0.1)
+    k = int(count)
+    np.testing.assert_array_equal(idx.numpy()[:k], golden["loss_selected"])
+    assert abs(float(mean_diff) - float(golden["loss_mean_diff"])) < 1e-6
+    assert rel_err(eng.pairwise_distance(ta, tp).numpy(), golden["loss_d_p"]) < 1e-6
+
+
+@pytest.mark.parametrize("N", [1, 5, 256, 700])
+def test_filter_sizes(N):
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(N)
+    d_p = torch.from_numpy(rs.rand(N).astype(np.float32))
+    d_n = torch.from_numpy(rs.rand(N).astype(np.float32))
+    idx, count, mean_diff = eng.triplet_filter(d_p, d_n, 0.1)
+    ref, _, md = O.triplet_filter(d_p.numpy(), d_n.numpy(), 0.1)
+    assert int(count) == len(ref)
+    np.testing.assert_array_equal(idx.numpy()[:len(ref)], ref)
+    assert abs(float(mean_diff) - md) < 1e-6

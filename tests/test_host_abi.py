@@ -1,0 +1,85 @@
+"""CPU-side checks of the boundary: the HIP shared library loads and exports every symbol that
+include/deepspeaker_hip.h declares (no compute is launched without a GPU), the Python surface mirrors
+the reference's, and the product path refuses to run without a GPU instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "deepspeaker_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from deepspeaker_pytorch_amd import _native
+    assert header_symbols() == _native.exported_symbols()
+
+
+def test_hip_library_exports_every_declared_symbol():
+    from deepspeaker_pytorch_amd import _native
+    path = os.path.join(ROOT, "deepspeaker-pytorch_amd", _native.LIB_NAME)
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _native.NativeLib(path)            # resolves every symbol or raises AttributeError
+    assert lib.raw("ds_version")() >= 100
+    assert lib.error_string(-1) == "bad shape"
+    # argument validation happens before any launch, so it is testable without a GPU
+    shp = _native.ConvShape(1, 8, 8, 7, 64, 3, 1)
+    assert lib.raw("ds_conv_stats_rows")(shp) == -1
+    shp = _native.ConvShape(256, 80, 32, 64, 64, 3, 1)
+    assert lib.raw("ds_conv_stats_rows")(shp) == 256 * 20
+
+
+def test_python_surface_matches_reference_contract():
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, PairwiseDistance, TripletMarginLoss
+    m = DeepSpeakerModel(512, 1211)
+    sd = m.state_dict()
+    assert len(sd) == 76
+    assert sum(p.numel() for p in m.parameters()) == 12245371
+    assert sd["model.conv1.weight"].shape == (64, 1, 5, 5)
+    assert sd["model.layer4.0.conv2.weight"].shape == (512, 512, 3, 3)
+    assert sd["model.fc.weight"].shape == (512, 2048) and sd["model.classifier.weight"].shape == (1211, 512)
+    assert m.embedding_size == 512
+    for attr in ("conv1", "bn1", "layer1", "conv4", "bn4", "layer4", "avgpool", "fc", "classifier", "relu"):
+        assert hasattr(m.model, attr)
+    # checkpoint round trip with an optimizer, as train_triplet.py:325-327 / :177-186 do
+    opt = torch.optim.Adagrad(m.parameters(), lr=0.1, lr_decay=1e-4)
+    ck = {"epoch": 1, "state_dict": m.state_dict(), "optimizer": opt.state_dict()}
+    m2 = DeepSpeakerModel(512, 1211)
+    m2.load_state_dict(ck["state_dict"])
+    assert TripletMarginLoss(0.1).margin == 0.1 and PairwiseDistance(2).norm == 2
+    with pytest.raises(NotImplementedError):
+        PairwiseDistance(1)
+
+
+def test_no_cpu_fallback():
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, PairwiseDistance
+    m = DeepSpeakerModel(512, 4).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 160, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PairwiseDistance(2).forward(torch.zeros(2, 8), torch.zeros(2, 8))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from deepspeaker_pytorch_amd import _native
+    with pytest.raises(_native.DeepSpeakerHipError, match="no fallback"):
+        _native.NativeLib(str(tmp_path / "libdeepspeaker_hip.so"))
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "deepspeaker-pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "deepspeaker_oracle" not in txt and "torch_restatement" not in txt, f
+                assert "/root/reference" not in txt, f

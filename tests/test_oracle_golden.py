@@ -185,3 +185,20 @@ def test_mine_semihard_brute_force():
         semi = ok & (d > d_p[i])
         pool = semi if semi.any() else ok
         assert j[i] == np.where(pool)[0][np.argmin(d[pool])]
+
+
+def test_torch_restatement(golden):
+    """The torch-functional restatement bench.py times as cpu_baseline reproduces the reference."""
+    import torch
+    import torch_restatement as TR
+    sd = O.make_state_dict(seed=11, num_classes=16)
+    tsd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    x = torch.from_numpy(O.make_input(seed=12, batch=6))
+    with torch.no_grad():
+        e = TR.forward_eval(tsd, x)
+    assert rel_err(e.numpy(), golden["full_eval_emb"]) < 1e-6
+    sds = O.make_state_dict(seed=21, num_classes=16, n_stages=2)
+    tsds = {k: torch.from_numpy(np.array(v)) for k, v in sds.items()}
+    with torch.no_grad():
+        es = TR.forward_eval(tsds, torch.from_numpy(O.make_input(seed=22, batch=32)), n_stages=2)
+    assert rel_err(es.numpy(), golden["small_eval_emb"]) < 1e-6
