@@ -41,11 +41,14 @@ _SIGNATURES = {
     "ds_bn_apply_f32": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "ds_conv_out_dims": (c_int, [POINTER(ConvShape), POINTER(c_int), POINTER(c_int)]),
     "ds_conv_stats_rows": (c_int, [POINTER(ConvShape)]),
+    "ds_conv_plan_describe": (c_int, [POINTER(ConvShape), POINTER(c_int)]),
     "ds_conv5x5s2_c1_stats_rows": (c_int, [c_int, c_int]),
     "ds_conv5x5s2_c1_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv_fwd_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_avgpool_time_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_l2norm_scale_f32": (c_int, [_P, _P, c_int, c_int, c_float, c_float, _P]),
+    "ds_fc_workspace_floats": (c_longlong, [c_int, c_int, c_int]),
+    "ds_fc_l2norm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "ds_pairwise_distance_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_margin_fwd_f32": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_filter_f32": (c_int, [_P, _P, c_float, _P, _P, _P, c_int, _P]),

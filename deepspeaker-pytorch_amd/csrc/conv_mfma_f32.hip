@@ -24,7 +24,7 @@ namespace {
 constexpr int CK = DS_CONV_CK;      // input channels per staged chunk
 constexpr int LDS_PS = 12;          // floats per staged pixel: 8 channels + 4 pad.  48 B keeps
                                     // ds_read_b128 aligned and walks all 64 banks over 16 pixels
-constexpr int MAX_STAGE_IT = 8;     // per-thread float4 staging slots
+constexpr int MAX_STAGE_IT = 8;     // upper bound of per-thread float4 staging slots (NIT)
 constexpr int MAX_TAPS = 25;
 
 struct ConvK {
@@ -42,10 +42,26 @@ struct ConvK {
     int RT, NI, segs_per_img, n_segs;
     int n_ntiles;
     int flags;
-    short tap_off[MAX_TAPS + 7];   // LDS pixel offset of each tap inside a segment
+    int tap_off[MAX_TAPS + 3];     // LDS pixel offset of each tap inside a segment (table-driven path)
 };
 
-template <int MSUB, int NSUB, int WM, int WN>
+// Tap schedule.  KS > 0: the KS*KS taps of a forward convolution are unrolled at compile time and
+// the B (filter) fragments run through a register ring RING taps deep, refilled one tap after use,
+// so every filter load is issued >= RING-1 taps (one whole 3x3 chunk / one 5x5 filter row) before
+// its MFMAs and is always OLDER than the activation staging loads it would otherwise queue behind
+// (vmcnt retires in order).  KS == 0: table-driven taps (1x1 and the data-gradient classes), double
+// buffered.
+template <int KS, int MSUB>
+struct TapSchedule {
+    static constexpr int NT = KS * KS;
+    // small wave tiles (few MFMAs per tap) prefetch a whole 3x3 chunk of filters, big ones 3 taps
+    static constexpr int RING = (KS == 3) ? (MSUB <= 2 ? 9 : 3) : (KS == 5 ? 5 : 1);
+    // ... and also double-buffer the pixel fragments; big wave tiles have the MFMA depth (and the
+    // register budget only) for single buffering
+    static constexpr bool APREF = MSUB <= 2;
+};
+
+template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT>
 __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = MSUB * WM * 32;
@@ -90,14 +106,19 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK
         a_off[ms] = pix * LDS_PS + 4 * lhi;
     }
 
-    // ---- staging descriptors: which global float4 lands in which LDS slot (chunk-invariant) ----
-    int g_off[MAX_STAGE_IT], l_off[MAX_STAGE_IT];
+    // ---- staging descriptors: which global float4 lands in which LDS slot (chunk-invariant).
+    //      NIT (compile time) float4 per thread; slots outside the tile / image load from offset 0,
+    //      are zeroed by a select and land in a dump slot, so the sequence is branch-free. ----
+    int g_off[NIT], l_off[NIT];
+    bool g_ok[NIT];
     const int n_items = tile_pix * (CK / 4);
+    const int dump_off = tile_pix * LDS_PS + MT + 2 * WM * NTILE;      // 16-byte slot past all tables
 #pragma unroll
-    for (int it = 0; it < MAX_STAGE_IT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * NTHR;
-        g_off[it] = -1;
-        l_off[it] = -1;
+        g_off[it] = 0;
+        g_ok[it] = false;
+        l_off[it] = dump_off;
         if (idx < n_items) {
             const int pix = idx >> 1, q = idx & 1;
             const int seg = pix / p.seg_pix;
@@ -109,7 +130,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK
                 const int b = gseg / p.segs_per_img;
                 const int r0 = (gseg - b * p.segs_per_img) * p.RT;
                 const int h = p.IS * r0 + p.dh_min + rr, w = p.dw_min + cc;
-                if (h >= 0 && h < p.H && w >= 0 && w < p.W) g_off[it] = ((b * p.H + h) * p.W + w) * p.Cin + q * 4;
+                if (h >= 0 && h < p.H && w >= 0 && w < p.W) {
+                    g_off[it] = ((b * p.H + h) * p.W + w) * p.Cin + q * 4;
+                    g_ok[it] = true;
+                }
             }
         }
     }
@@ -126,54 +150,110 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK
     const int n_base = tile_n * NTILE + wn * NSUB * 32;
     const float *wlane = p.w + (size_t)(n_base + l31) * CK + 4 * lhi;
     const size_t w_tap_stride = (size_t)p.Cout * CK;
-    const int total_taps = n_chunks * p.NT;
+    const int NT = (KS > 0) ? KS * KS : p.NT;
+    const int last_tap = n_chunks * NT - 1;
 
-    f32x4 st[MAX_STAGE_IT];
+    f32x4 st[NIT];
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int it = 0; it < MAX_STAGE_IT; ++it)
-        st[it] = (g_off[it] >= 0) ? *(const f32x4 *)(p.x + g_off[it]) : zero4;
+    for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
 
-    f32x4 bcur[NSUB], bnext[NSUB];
+    constexpr int RING = TapSchedule<KS, MSUB>::RING;
+    constexpr bool APREF = TapSchedule<KS, MSUB>::APREF;
+    f32x4 bq[RING][NSUB];
 #pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns) {
-        bcur[ns] = *(const f32x4 *)(wlane + (size_t)ns * 32 * CK);
-        bnext[ns] = bcur[ns];
-    }
+    for (int d = 0; d < RING; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+            const int g = d < last_tap ? d : last_tap;
+            bq[d][ns] = *(const f32x4 *)(wlane + (size_t)g * w_tap_stride + (size_t)ns * 32 * CK);
+        }
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         __syncthreads();                       // previous chunk's fragment reads are done
 #pragma unroll
-        for (int it = 0; it < MAX_STAGE_IT; ++it)
-            if (l_off[it] >= 0) *(f32x4 *)(lds + l_off[it]) = st[it];
+        for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = g_ok[it] ? st[it] : zero4;
         __syncthreads();
-        if (chunk + 1 < n_chunks) {            // next chunk's pixels fly while this one computes
+        {   // next chunk's pixels fly while this one computes (the last chunk re-reads its own)
+            const int cn = chunk + 1 < n_chunks ? chunk + 1 : chunk;
 #pragma unroll
-            for (int it = 0; it < MAX_STAGE_IT; ++it)
-                st[it] = (g_off[it] >= 0) ? *(const f32x4 *)(p.x + g_off[it] + (chunk + 1) * CK) : zero4;
+            for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + cn * CK);
         }
-        for (int t = 0; t < p.NT; ++t) {
-            const int g = chunk * p.NT + t;
-            if (g + 1 < total_taps) {
+        if constexpr (KS > 0) {
+            const int g0 = chunk * NT;
+            f32x4 a[2][MSUB];
 #pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns)
-                    bnext[ns] = *(const f32x4 *)(wlane + (size_t)(g + 1) * w_tap_stride + (size_t)ns * 32 * CK);
-            }
-            const int toff = (int)p.tap_off[t] * LDS_PS;
-            f32x4 a[MSUB];
+            for (int ms = 0; ms < MSUB; ++ms) a[0][ms] = *(const f32x4 *)(lds + a_off[ms]);
 #pragma unroll
-            for (int ms = 0; ms < MSUB; ++ms) a[ms] = *(const f32x4 *)(lds + a_off[ms] + toff);
-            // k-step j multiplies channels {j, 4+j} of the chunk: lanes 0-31 carry channels
-            // 0..3, lanes 32-63 channels 4..7, for the A and the B fragment alike.
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ms = 0; ms < MSUB; ++ms)
+            for (int t = 0; t < KS * KS; ++t) {
+                const int slot = t % RING;
+                const int cur = APREF ? (t & 1) : 0;
+                // (1) refill the ring slot the PREVIOUS tap consumed with the tap RING-1 ahead of this
+                // one, (2) fetch pixel fragments from LDS (the next tap's when double-buffered), then
+                // (3) run this tap's MFMAs.  The scheduling fences keep the loads in front of the
+                // matrix work they overlap with.
+                if (t > 0) {
+                    int gn = g0 + t - 1 + RING;
+                    gn = gn < last_tap ? gn : last_tap;
 #pragma unroll
                     for (int ns = 0; ns < NSUB; ++ns)
-                        acc[ms][ns] = ds_mfma_32x32x2_f32(a[ms][j], bcur[ns][j], acc[ms][ns]);
+                        bq[(t - 1) % RING][ns] =
+                            *(const f32x4 *)(wlane + (size_t)gn * w_tap_stride + (size_t)ns * 32 * CK);
+                }
+                if constexpr (APREF) {
+                    if (t + 1 < KS * KS) {
+                        const int toff = (((t + 1) / KS) * p.cols_in + ((t + 1) % KS)) * LDS_PS;
 #pragma unroll
-            for (int ns = 0; ns < NSUB; ++ns) bcur[ns] = bnext[ns];
+                        for (int ms = 0; ms < MSUB; ++ms)
+                            a[(t + 1) & 1][ms] = *(const f32x4 *)(lds + a_off[ms] + toff);
+                    }
+                } else if (t > 0) {
+                    const int toff = ((t / KS) * p.cols_in + (t % KS)) * LDS_PS;
+#pragma unroll
+                    for (int ms = 0; ms < MSUB; ++ms) a[0][ms] = *(const f32x4 *)(lds + a_off[ms] + toff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // k-step j multiplies channels {j, 4+j} of the chunk: lanes 0-31 carry channels
+                // 0..3, lanes 32-63 channels 4..7, for the A and the B fragment alike.
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                        for (int ns = 0; ns < NSUB; ++ns)
+                            acc[ms][ns] = ds_mfma_32x32x2_f32(a[cur][ms][j], bq[slot][ns][j], acc[ms][ns]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {   // the last tap's slot, refilled for the next chunk
+                int gn = g0 + KS * KS - 1 + RING;
+                gn = gn < last_tap ? gn : last_tap;
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                    bq[(KS * KS - 1) % RING][ns] =
+                        *(const f32x4 *)(wlane + (size_t)gn * w_tap_stride + (size_t)ns * 32 * CK);
+            }
+        } else {
+            f32x4 bnext[NSUB];
+            for (int t = 0; t < NT; ++t) {
+                int gn = chunk * NT + t + 1;
+                gn = gn < last_tap ? gn : last_tap;
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                    bnext[ns] = *(const f32x4 *)(wlane + (size_t)gn * w_tap_stride + (size_t)ns * 32 * CK);
+                const int toff = p.tap_off[t] * LDS_PS;
+                f32x4 a[MSUB];
+#pragma unroll
+                for (int ms = 0; ms < MSUB; ++ms) a[ms] = *(const f32x4 *)(lds + a_off[ms] + toff);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                        for (int ns = 0; ns < NSUB; ++ns)
+                            acc[ms][ns] = ds_mfma_32x32x2_f32(a[ms][j], bq[0][ns][j], acc[ms][ns]);
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) bq[0][ns] = bnext[ns];
+            }
         }
     }
 
@@ -238,27 +318,32 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK
 // ------------------------------------------------------------------------------------------
 // host-side tiling plan
 // ------------------------------------------------------------------------------------------
-struct TileCfg { int MT, NTILE, NTHR, WM; };
-constexpr TileCfg kCfg[2] = {
-    {128, 64, 256, 2},     // conv_mfma_f32_kernel<2,1,2,2>
-    {160, 128, 256, 1},    // conv_mfma_f32_kernel<5,1,1,4>
+struct TileCfg { int MT, NTILE, NTHR, WM, wg_per_cu; };
+constexpr int kNumCfg = 3;
+constexpr int kNumCU = 256;
+constexpr TileCfg kCfg[kNumCfg] = {
+    // wg_per_cu: resident workgroups per CU allowed by the register budget (120 / 256 / 208 regs)
+    {128, 64, 256, 2, 4},     // conv_mfma_f32_kernel<KS,2,1,2,2,*>
+    {160, 128, 256, 1, 2},    // conv_mfma_f32_kernel<KS,5,1,1,4,*>
+    {256, 64, 256, 2, 2},     // conv_mfma_f32_kernel<KS,4,1,2,2,*>
 };
 
 struct ConvPlan {
     int cfg;
+    int nit;            // float4 staging slots per thread: 2, 4 or 8
     int grid;
     size_t lds_bytes;
     int n_mtiles;
     ConvK k;
 };
 
-// Choose (cfg, RT, NI): maximise the fraction of MFMA rows that are real pixels, then the
-// segment height (less halo re-staging).  Full-width segments only.
+// Choose (cfg, RT, NI): maximise (fraction of MFMA rows that are real pixels) x (occupancy of the
+// last round of workgroups), then tile size and segment height.  Full-width segments only.
 static int plan_tiles(ConvPlan &pl, int B, int Hr, int Wc, int IS, int ext_h, int ext_w, int Cout,
                       bool stats) {
     double best_eff = -1.0;
     int best_cfg = -1, best_rt = 0, best_ni = 0;
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < kNumCfg; ++c) {
         const TileCfg &cf = kCfg[c];
         if (Cout % cf.NTILE) continue;
         for (int rt = 1; rt <= Hr; ++rt) {
@@ -272,7 +357,15 @@ static int plan_tiles(ConvPlan &pl, int B, int Hr, int Wc, int IS, int ext_h, in
             if ((long long)ni * rows_in * cols_in * (CK / 4) > (long long)MAX_STAGE_IT * cf.NTHR) continue;
             const long long n_mt = ds_ceil_div_ll(n_segs, ni);
             double eff = (double)B * Hr * Wc / ((double)n_mt * cf.MT);
-            eff += 1e-9 * rt + (c == 1 ? 1e-6 : 0.0);   // ties: wider N tile, taller segment
+            // wave quantisation: the grid runs in rounds of (CUs x resident workgroups); a half-empty
+            // last round idles matrix cores just like masked rows do
+            // (measured: 768 workgroups at 2/CU run at 0.84 of the rate of 256 or 512).  A grid that
+            // fits in one round is spread evenly over the CUs by the dispatcher.
+            const long long blocks = n_mt * (Cout / cf.NTILE), slots = (long long)kNumCU * cf.wg_per_cu;
+            if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, kNumCU) * kNumCU);
+            else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
+            // ties: bigger tiles (more MFMAs per staged byte and per barrier), taller segments
+            eff += 1e-9 * rt + 1e-6 * (c == 1 ? 2 : (c == 2 ? 1 : 0));
             if (eff > best_eff) { best_eff = eff; best_cfg = c; best_rt = rt; best_ni = ni; }
         }
     }
@@ -290,8 +383,12 @@ static int plan_tiles(ConvPlan &pl, int B, int Hr, int Wc, int IS, int ext_h, in
     pl.cfg = best_cfg;
     pl.n_mtiles = ds_ceil_div(k.n_segs, best_ni);
     pl.grid = pl.n_mtiles * k.n_ntiles;
-    pl.lds_bytes = (size_t)k.NI * k.seg_pix * LDS_PS * 4 + (size_t)cf.MT * 4 +
-                   (stats ? (size_t)cf.WM * cf.NTILE * 2 * 4 : 0);
+    const int items = k.NI * k.seg_pix * (CK / 4);
+    const int its = ds_ceil_div(items, cf.NTHR);
+    pl.nit = its <= 2 ? 2 : (its <= 4 ? 4 : 8);
+    // pixel tile + row table + statistics scratch + the 16-byte dump slot
+    pl.lds_bytes = (size_t)k.NI * k.seg_pix * LDS_PS * 4 + (size_t)cf.MT * 4 + (size_t)cf.WM * cf.NTILE * 2 * 4 + 16;
+    (void)stats;
     return DS_OK;
 }
 
@@ -316,15 +413,32 @@ static int plan_forward(ConvPlan &pl, const ds_conv_shape *s, bool stats) {
     int rc = plan_tiles(pl, s->B, Ho, Wo, s->stride, s->KS, s->KS, s->Cout, stats);
     if (rc != DS_OK) return rc;
     for (int kh = 0; kh < s->KS; ++kh)
-        for (int kw = 0; kw < s->KS; ++kw) k.tap_off[kh * s->KS + kw] = (short)(kh * k.cols_in + kw);
+        for (int kw = 0; kw < s->KS; ++kw) k.tap_off[kh * s->KS + kw] = kh * k.cols_in + kw;
     return DS_OK;
 }
 
-static int launch(const ConvPlan &pl, void *stream) {
-    if (pl.cfg == 0)
-        DS_LAUNCH((conv_mfma_f32_kernel<2, 1, 2, 2>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+template <int KS, int MSUB, int NSUB, int WM, int WN>
+static void launch_nit(const ConvPlan &pl, void *stream) {
+    if (pl.nit == 2)
+        DS_LAUNCH((conv_mfma_f32_kernel<KS, MSUB, NSUB, WM, WN, 2>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    else if (pl.nit == 4)
+        DS_LAUNCH((conv_mfma_f32_kernel<KS, MSUB, NSUB, WM, WN, 4>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
     else
-        DS_LAUNCH((conv_mfma_f32_kernel<5, 1, 1, 4>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH((conv_mfma_f32_kernel<KS, MSUB, NSUB, WM, WN, 8>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+}
+
+template <int KS>
+static void launch_ks(const ConvPlan &pl, void *stream) {
+    if (pl.cfg == 0) launch_nit<KS, 2, 1, 2, 2>(pl, stream);
+    else if (pl.cfg == 1) launch_nit<KS, 5, 1, 1, 4>(pl, stream);
+    else launch_nit<KS, 4, 1, 2, 2>(pl, stream);
+}
+
+// ks_unrolled = 3 or 5 selects the compile-time tap schedule; anything else the table-driven one
+static int launch(const ConvPlan &pl, int ks_unrolled, void *stream) {
+    if (ks_unrolled == 3) launch_ks<3>(pl, stream);
+    else if (ks_unrolled == 5) launch_ks<5>(pl, stream);
+    else launch_ks<0>(pl, stream);
     return ds_last_launch_error();
 }
 
@@ -345,6 +459,16 @@ extern "C" int ds_conv_stats_rows(const ds_conv_shape *s) {
     return rc == DS_OK ? pl.n_mtiles : rc;
 }
 
+extern "C" int ds_conv_plan_describe(const ds_conv_shape *s, int *out8) {
+    DS_REQUIRE(out8, DS_ERR_NULL);
+    ConvPlan pl;
+    int rc = plan_forward(pl, s, false);
+    if (rc != DS_OK) return rc;
+    out8[0] = kCfg[pl.cfg].MT; out8[1] = kCfg[pl.cfg].NTILE; out8[2] = pl.k.RT; out8[3] = pl.k.NI;
+    out8[4] = pl.grid; out8[5] = (int)pl.lds_bytes; out8[6] = pl.nit; out8[7] = pl.n_mtiles;
+    return DS_OK;
+}
+
 extern "C" int ds_conv_fwd_f32(const ds_conv_shape *s, const float *x, const float *w_packed,
                                const float *scale, const float *shift, const float *residual,
                                float *y, float *stats_partial, int flags, void *stream) {
@@ -359,5 +483,5 @@ extern "C" int ds_conv_fwd_f32(const ds_conv_shape *s, const float *x, const flo
     pl.k.x = x; pl.k.w = w_packed; pl.k.y = y;
     pl.k.scale = scale; pl.k.shift = shift; pl.k.res = residual; pl.k.stats = stats_partial;
     pl.k.flags = flags;
-    return launch(pl, stream);
+    return launch(pl, s->KS, stream);
 }

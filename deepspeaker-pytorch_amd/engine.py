@@ -211,12 +211,16 @@ class Engine:
         pooled = torch.empty((B, wc * c), dtype=torch.float32, device=a.device)
         self.lib.call("ds_avgpool_time_f32", self._p(a), self._p(pooled), B, hr, wc, c, self._stream(a))
         n_out = pw.fc_bias.numel()
-        # fc as a 1x1 convolution over a [1, B, 1, K] image (reference model.py:209)
-        f, _ = self.conv(pooled, pw.fc, 1, B, 1, wc * c, n_out, 1, 1, scale=pw.fc_ones,
-                         shift=pw.fc_bias.detach(), flags=DS_EPI_AFFINE)
-        f = f.view(B, n_out)
+        k = wc * c
+        ws_floats = self.lib.raw("ds_fc_workspace_floats")(B, k, n_out)
+        if ws_floats <= 0:
+            raise RuntimeError(f"ds_fc_workspace_floats({B},{k},{n_out}) failed: {ws_floats}")
+        ws = torch.empty(ws_floats, dtype=torch.float32, device=a.device)
+        f = torch.empty((B, n_out), dtype=torch.float32, device=a.device)
         e = torch.empty_like(f)
-        self.lib.call("ds_l2norm_scale_f32", self._p(f), self._p(e), B, n_out, ALPHA, L2_EPS, self._stream(f))
+        # projection (reference model.py:209) + L2 norm x alpha (model.py:210-213) in two launches
+        self.lib.call("ds_fc_l2norm_fwd_f32", self._p(pooled), self._p(pw.fc), self._p(pw.fc_bias.detach()),
+                      self._p(ws), self._p(f), self._p(e), B, k, n_out, ALPHA, L2_EPS, self._stream(a))
         if saved is not None:
             saved.pooled, saved.fc_out = pooled, f
         return e

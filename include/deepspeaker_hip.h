@@ -95,6 +95,9 @@ int ds_conv_out_dims(const ds_conv_shape *s, int *Ho, int *Wo);
 /* number of [Cout][2] partial-statistics rows DS_EPI_STATS writes for this shape */
 int ds_conv_stats_rows(const ds_conv_shape *s);
 
+/* tiling the planner picks for a shape: out8 = {M tile, N tile, rows per segment, segments per tile,
+ * workgroups, LDS bytes, staging slots per thread, M tiles} (introspection for tests / DESIGN.md) */
+int ds_conv_plan_describe(const ds_conv_shape *s, int *out8);
 int ds_conv5x5s2_c1_stats_rows(int B, int H);
 /* conv1: 5x5 stride 2 pad 2, Cin = 1 -> 64 channels (model.py:93,187) fused with the following
  * BatchNorm affine + clipped ReLU (model.py:188-189).  x is the network input [B,H,W]. */
@@ -114,6 +117,14 @@ int ds_avgpool_time_f32(const float *x, float *pooled, int B, int Hr, int Wc, in
 /* e = alpha * f / sqrt(sum f^2 + eps) per row  (model.py:172-183, 210-213) */
 int ds_l2norm_scale_f32(const float *f, float *e, int B, int D, float alpha, float eps,
                         void *stream);
+
+/* fused projection + normalisation: f = pooled . W^T + b  (model.py:209), e = alpha f / |f|
+ * (model.py:210-213).  Split-K MFMA GEMM + a deterministic reduce; `workspace` holds
+ * ds_fc_workspace_floats(B,K,N) floats; `e` may be NULL (projection only). */
+long long ds_fc_workspace_floats(int B, int K, int N);
+int ds_fc_l2norm_fwd_f32(const float *pooled, const float *w_packed, const float *bias,
+                         float *workspace, float *f, float *e, int B, int K, int N, float alpha,
+                         float eps, void *stream);
 
 /* ---- loss side ----------------------------------------------------------------------------------- */
 /* d[i] = sqrt(sum_k (x1[i,k]-x2[i,k])^2 + 1e-4/D)   (PairwiseDistance, model.py:13-18, p = 2) */

@@ -41,3 +41,5 @@ void wave_exchange(float mine, float *all64);          // all64[l] = lane l's `m
 static inline void __syncthreads() { emu::syncthreads(); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 typedef void *hipStream_t;
+// scheduling hints are no-ops on the host
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
