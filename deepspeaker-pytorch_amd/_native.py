@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ds_pack_conv_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_pack_conv1_weight_f32": (c_int, [_P, _P, c_int, _P]),
     "ds_pack_fc_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_pack_fc_weight_dgrad_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_bn_fold_f32": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
     "ds_bn_stats_finalize_f32": (c_int, [_P, c_int, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P,
                                          _P, _P, c_int, _P]),
@@ -52,6 +53,13 @@ _SIGNATURES = {
     "ds_pairwise_distance_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_margin_fwd_f32": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_filter_f32": (c_int, [_P, _P, c_float, _P, _P, _P, c_int, _P]),
+    "ds_pack_conv_dgrad_s2_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ds_conv_dgrad_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P]),
+    "ds_conv_wgrad_workspace_floats": (c_longlong, [POINTER(ConvShape)]),
+    "ds_conv_wgrad_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, c_int, _P]),
+    "ds_bn_bwd_partial_rows": (c_int, [c_longlong]),
+    "ds_bn_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
+    "ds_colsum_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "ds_pairwise_distance_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_margin_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_l2norm_scale_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),

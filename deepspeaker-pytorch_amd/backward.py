@@ -1,0 +1,116 @@
+"""Backward pass of the train-mode ResCNN as a sequence of C-ABI launches.
+
+Restates what torch autograd derives for `loss.backward()` (reference train_triplet.py:223,290) over
+`DeepSpeakerModel.forward` (model.py:185-218): l2-norm, fc, temporal mean, and per stage
+clip / BatchNorm(train) / 3x3 conv x2 with the identity residual, then clip / BatchNorm / 5x5 s2 conv.
+Every op is a HIP kernel (include/deepspeaker_hip.h, "backward" sections); this file only orders them.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict
+
+import torch
+
+from ._native import ConvShape
+from .engine import ALPHA, L2_EPS, STAGE_CHANNELS, Engine, PackedWeights, SavedForward
+
+
+def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma):
+    """(masked upstream gradient gy, gz = dL/d(conv output), dgamma, dbeta)."""
+    mean, invstd, _ = stats
+    c = z.shape[-1]
+    n_pix = z.numel() // c
+    dev = z.device
+    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix)
+    gy = torch.empty_like(z)
+    gz = torch.empty_like(z)
+    partial = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)
+    coef = torch.empty(3 * c, dtype=torch.float32, device=dev)
+    gg = torch.empty(c, dtype=torch.float32, device=dev)
+    gb = torch.empty_like(gg)
+    eng.lib.call("ds_bn_bwd_f32", eng._p(g1), eng._p(g2), eng._p(act), eng._p(z), eng._p(mean), eng._p(invstd),
+                 eng._p(gamma.detach()), eng._p(gy), eng._p(partial), eng._p(coef), eng._p(gg), eng._p(gb),
+                 eng._p(gz), n_pix, c, eng._stream(z))
+    return gy, gz, gg, gb
+
+
+def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0):
+    n_ws = eng.lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp))
+    if n_ws <= 0:
+        raise RuntimeError(f"ds_conv_wgrad_workspace_floats failed: {n_ws}")
+    ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
+    gw = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+    eng.lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), eng._p(x), eng._p(gz), eng._p(ws), eng._p(gw), fc_f,
+                 eng._stream(x))
+    return gw
+
+
+def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad):
+    gx = torch.empty((shp.B, shp.H, shp.W, shp.Cin), dtype=torch.float32, device=gz.device)
+    eng.lib.call("ds_conv_dgrad_f32", ctypes.byref(shp), eng._p(gz), eng._p(w_dgrad), eng._p(gx), eng._stream(gz))
+    return gx
+
+
+def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
+                   ge: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512]."""
+    lib = eng.lib
+    grads: Dict[str, torch.Tensor] = {}
+    n_stages = len(pw.stages)
+    f = saved.fc_out
+    B, n_out = f.shape
+    st = eng._stream(f)
+    # ---- l2-norm x alpha (model.py:210-213) ----
+    gf = torch.empty_like(f)
+    lib.call("ds_l2norm_scale_bwd_f32", eng._p(f), eng._p(ge), eng._p(gf), B, n_out, ALPHA, L2_EPS, st)
+    # ---- fc (model.py:209): bias, weight, input ----
+    pooled = saved.pooled
+    k = pooled.shape[1]
+    gb = torch.empty(n_out, dtype=torch.float32, device=f.device)
+    lib.call("ds_colsum_f32", eng._p(gf), eng._p(gb), B, n_out, st)
+    grads["model.fc.bias"] = gb
+    c_last = STAGE_CHANNELS[n_stages - 1]
+    f_bins = k // c_last
+    grads["model.fc.weight"] = _wgrad(eng, ConvShape(1, B, 1, k, n_out, 1, 1), pooled, gf, (n_out, k), f_bins)
+    ws = torch.empty(lib.raw("ds_fc_workspace_floats")(B, n_out, k), dtype=torch.float32, device=f.device)
+    gpooled = torch.empty((B, k), dtype=torch.float32, device=f.device)
+    lib.call("ds_fc_l2norm_fwd_f32", eng._p(gf), eng._p(pw.fc_dgrad), None, eng._p(ws), eng._p(gpooled), None, B,
+             n_out, k, 1.0, 0.0, st)
+    # ---- temporal mean + the clip of the last stage output (model.py:205-207) ----
+    out = saved.acts[f"stage{n_stages}.c"]
+    _, hr, wc, c = out.shape
+    g = torch.empty_like(out)
+    lib.call("ds_avgpool_time_bwd_f32", eng._p(gpooled), eng._p(out), eng._p(g), B, hr, wc, c, st)
+    g_is_masked = True
+    for s in reversed(range(n_stages)):
+        i, c = s + 1, STAGE_CHANNELS[s]
+        h, w = saved.dims[s]
+        cin = 1 if s == 0 else STAGE_CHANNELS[s - 1]
+        a_act, b_act, c_act = (saved.acts[f"stage{i}.{t}"] for t in "abc")
+        shp3 = ConvShape(B, h, w, c, c, 3, 1)
+        # out = clip(bn2(conv2(y)) + r)            (model.py:73-80)
+        name = f"model.layer{i}.0.bn2"
+        g_out, gz, gg, gbeta = _bn_bwd(eng, g, None, None if g_is_masked else c_act, saved.raws[name],
+                                       saved.stats[name], bn_weights[name])
+        grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
+        grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3))
+        g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad)
+        # y = clip(bn1(conv1(r)))                  (model.py:69-71)
+        name = f"model.layer{i}.0.bn1"
+        _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name])
+        grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
+        grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3))
+        g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad)
+        # r = clip(bn_i(conv_i(x)));  dL/dr = conv-path + residual path   (model.py:187-189, 67, 79)
+        name = f"model.bn{i}"
+        _, gz, gg, gbeta = _bn_bwd(eng, g_r, g_out, a_act, saved.raws[name], saved.stats[name], bn_weights[name])
+        grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
+        h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
+        shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)
+        x_in = saved.x if s == 0 else saved.acts[f"stage{s}.c"]
+        grads[f"model.conv{i}.weight"] = _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5))
+        if s > 0:
+            g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad)        # unmasked: the next bn2 step masks it
+            g_is_masked = False
+    return grads

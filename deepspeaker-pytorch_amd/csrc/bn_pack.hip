@@ -105,6 +105,33 @@ __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float *w, f
     }
 }
 
+// 5x5 stride-2 data-gradient packing: four parity classes (ph,pw) in order (0,0),(0,1),(1,0),(1,1),
+// class taps = {kh = ph mod 2} x {kw = pw mod 2} in ascending kernel index; each class block is
+// [Cout/8][taps][Cin][8] (K = Cout, N = Cin) -- see ds_conv_dgrad_f32.
+__global__ void __launch_bounds__(256) pack_conv_dgrad_s2_kernel(const float *w, float *out, int Cout, int Cin) {
+    const long long n = (long long)Cout * Cin * 25;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        int ph = 0, pw = 0, nh = 3, nw = 3;
+        for (int c = 0; c < 4; ++c) {
+            ph = c >> 1; pw = c & 1;
+            nh = ph ? 2 : 3; nw = pw ? 2 : 3;
+            const long long sz = (long long)nh * nw * Cout * Cin;
+            if (r < sz) break;
+            r -= sz;
+        }
+        const int kk = (int)(r & 7);
+        r >>= 3;
+        const int ci = (int)(r % Cin);
+        r /= Cin;
+        const int t = (int)(r % (nh * nw));
+        const int kc = (int)(r / (nh * nw));
+        const int co = kc * 8 + kk;
+        const int kh = ph + 2 * (t / nw), kw = pw + 2 * (t % nw);
+        out[i] = w[(((size_t)co * Cin + ci) * 5 + kh) * 5 + kw];
+    }
+}
+
 __global__ void __launch_bounds__(256) pack_conv1_weight_kernel(const float *w, float *out, int Cout) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // out[t][co] = w[co][0][t]
     if (i < 25 * Cout) {
@@ -124,6 +151,21 @@ __global__ void __launch_bounds__(256) pack_fc_weight_kernel(const float *w, flo
         const int kp = kc * 8 + kk;
         const int f = kp / C, c = kp - f * C;
         out[i] = w[(size_t)nn * C * F + (size_t)c * F + f];
+    }
+}
+
+// fc data-gradient packing: gpooled[b][k'] = sum_n gf[b][n] * W[n][c*F+f]  ->  [N/8][1][K'][8]
+__global__ void __launch_bounds__(256) pack_fc_weight_dgrad_kernel(const float *w, float *out, int N, int C, int F) {
+    const long long n = (long long)N * C * F;
+    const int K = C * F;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int kk = (int)(i & 7);
+        long long r = i >> 3;
+        const int kp = (int)(r % K);
+        const int nc = (int)(r / K);
+        const int nn = nc * 8 + kk;
+        const int f = kp / C, c = kp - f * C;
+        out[i] = w[(size_t)nn * K + (size_t)c * F + f];
     }
 }
 
@@ -199,6 +241,14 @@ extern "C" int ds_pack_conv_weight_f32(const float *w_oihw, float *w_packed, int
     return ds_last_launch_error();
 }
 
+extern "C" int ds_pack_conv_dgrad_s2_f32(const float *w_oihw, float *w_packed, int Cout, int Cin, void *stream) {
+    DS_REQUIRE(w_oihw && w_packed, DS_ERR_NULL);
+    DS_REQUIRE(Cout > 0 && Cin > 0 && (Cout % 8) == 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(pack_conv_dgrad_s2_kernel, grid_for((long long)Cout * Cin * 25), 256, 0, stream, w_oihw, w_packed, Cout,
+              Cin);
+    return ds_last_launch_error();
+}
+
 extern "C" int ds_pack_conv1_weight_f32(const float *w_oihw, float *w_packed, int Cout, void *stream) {
     DS_REQUIRE(w_oihw && w_packed, DS_ERR_NULL);
     DS_REQUIRE(Cout > 0, DS_ERR_BAD_SHAPE);
@@ -210,6 +260,13 @@ extern "C" int ds_pack_fc_weight_f32(const float *w, float *w_packed, int N, int
     DS_REQUIRE(w && w_packed, DS_ERR_NULL);
     DS_REQUIRE(N > 0 && C > 0 && F > 0 && ((C * F) % 8) == 0, DS_ERR_BAD_SHAPE);
     DS_LAUNCH(pack_fc_weight_kernel, grid_for((long long)N * C * F), 256, 0, stream, w, w_packed, N, C, F);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_pack_fc_weight_dgrad_f32(const float *w, float *w_packed, int N, int C, int F, void *stream) {
+    DS_REQUIRE(w && w_packed, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && C > 0 && F > 0 && (N % 8) == 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(pack_fc_weight_dgrad_kernel, grid_for((long long)N * C * F), 256, 0, stream, w, w_packed, N, C, F);
     return ds_last_launch_error();
 }
 
@@ -238,4 +295,154 @@ extern "C" const char *ds_error_string(int code) {
         case DS_ERR_UNSUPPORTED: return "unsupported configuration";
         default: return code > 0 ? "HIP runtime error (hipError_t)" : "unknown error";
     }
+}
+
+// =================================================================================================
+// backward kernels of BatchNorm (train mode) -- autograd of reference model.py:70,74,188,... as
+// executed by loss.backward() (train_triplet.py:223,290); formulas: SURVEY 8(a) a13
+// =================================================================================================
+namespace {
+
+// gy = (g1 [+ g2]) * [0 < act < 20]   (the clipped-ReLU mask; act == nullptr: no mask)
+// partial[blk][c] = { sum gy, sum gy * xhat },  xhat = (z - mean) * invstd.   gy is also written out.
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *g1, const float *g2, const float *act,
+                                                            const float *z, const float *mean, const float *invstd,
+                                                            float *gy, float *partial, long long n_pix, int C,
+                                                            int pix_per_block) {
+    float *red = ds_dynamic_lds();                         // [slots][C][2]
+    const int cvec = C >> 2;
+    const int slots = 256 / cvec;
+    const int cg = threadIdx.x % cvec, slot = threadIdx.x / cvec;
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    long long p1 = p0 + pix_per_block;
+    if (p1 > n_pix) p1 = n_pix;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (slot < slots) {
+        const f32x4 mu = ((const f32x4 *)mean)[cg], is = ((const f32x4 *)invstd)[cg];
+        for (long long p = p0 + slot; p < p1; p += slots) {
+            const size_t i = (size_t)p * cvec + cg;
+            f32x4 g = ((const f32x4 *)g1)[i];
+            if (g2) g += ((const f32x4 *)g2)[i];
+            if (act) {
+                const f32x4 a = ((const f32x4 *)act)[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = (a[j] > 0.0f && a[j] < 20.0f) ? g[j] : 0.0f;
+            }
+            ((f32x4 *)gy)[i] = g;
+            const f32x4 xh = (((const f32x4 *)z)[i] - mu) * is;
+            s1 += g;
+            s2 += g * xh;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[((slot * C) + cg * 4 + j) * 2 + 0] = s1[j];
+            red[((slot * C) + cg * 4 + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int s = 0; s < slots; ++s) {
+            a1 += red[(s * C + c) * 2 + 0];
+            a2 += red[(s * C + c) * 2 + 1];
+        }
+        partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a1;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = a2;
+    }
+}
+
+// fold the partials (double precision, fixed order): ggamma = sum gy*xhat, gbeta = sum gy,
+// coef = { gamma*invstd, sum gy / N, sum gy*xhat / N }
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float *partial, int n_partial, double count,
+                                                              const float *gamma, const float *invstd,
+                                                              float *ggamma, float *gbeta, float *coef, int C) {
+    double *red = (double *)ds_dynamic_lds();              // [8][32][2]
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rl; r < n_partial; r += 8) {
+            s1 += (double)partial[((size_t)r * C + c) * 2 + 0];
+            s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
+        }
+    red[(rl * 32 + cl) * 2 + 0] = s1;
+    red[(rl * 32 + cl) * 2 + 1] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            t1 += red[(k * 32 + cl) * 2 + 0];
+            t2 += red[(k * 32 + cl) * 2 + 1];
+        }
+        gbeta[c] = (float)t1;
+        ggamma[c] = (float)t2;
+        coef[c] = gamma[c] * invstd[c];
+        coef[C + c] = (float)(t1 / count);
+        coef[2 * C + c] = (float)(t2 / count);
+    }
+}
+
+// gz = gamma*invstd * (gy - mean(gy) - xhat * mean(gy*xhat))
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *gy, const float *z, const float *mean,
+                                                           const float *invstd, const float *coef, float *gz,
+                                                           long long n_vec, int C) {
+    const int cvec = C >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % cvec);
+        const f32x4 mu = ((const f32x4 *)mean)[c4], is = ((const f32x4 *)invstd)[c4];
+        const f32x4 k1 = ((const f32x4 *)coef)[c4], k2 = ((const f32x4 *)(coef + C))[c4],
+                    k3 = ((const f32x4 *)(coef + 2 * C))[c4];
+        const f32x4 xh = (((const f32x4 *)z)[i] - mu) * is;
+        ((f32x4 *)gz)[i] = k1 * (((const f32x4 *)gy)[i] - k2 - xh * k3);
+    }
+}
+
+// out[c] = sum_r x[r][c]   (bias gradient of the fc layer); one workgroup per 256 columns
+__global__ void __launch_bounds__(256) colsum_kernel(const float *x, float *out, int R, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += x[(size_t)r * C + c];
+        out[c] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_bn_bwd_partial_rows(long long n_pix) {
+    if (n_pix <= 0) return DS_ERR_BAD_SHAPE;
+    long long blocks = (n_pix + 255) / 256;            // >= 256 pixels per workgroup
+    if (blocks > 2048) blocks = 2048;
+    return (int)blocks;
+}
+
+extern "C" int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act, const float *z, const float *mean,
+                             const float *invstd, const float *gamma, float *gy, float *partial, float *coef,
+                             float *ggamma, float *gbeta, float *gz, long long n_pix, int C, void *stream) {
+    DS_REQUIRE(g1 && z && mean && invstd && gamma && gy && partial && coef && ggamma && gbeta && gz, DS_ERR_NULL);
+    DS_REQUIRE(n_pix > 0 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) && DS_ALIGNED16(gz) && DS_ALIGNED16(mean) &&
+                   DS_ALIGNED16(invstd) && DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
+    const int blocks = ds_bn_bwd_partial_rows(n_pix);
+    const int ppb = (int)((n_pix + blocks - 1) / blocks);
+    const int slots = 256 / (C / 4);
+    DS_LAUNCH(bn_bwd_reduce_kernel, blocks, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd, gy,
+              partial, n_pix, C, ppb);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(bn_bwd_finalize_kernel, ds_ceil_div(C, 32), 256, 8 * 32 * 2 * sizeof(double), stream,
+              (const float *)partial, blocks, (double)n_pix, gamma, invstd, ggamma, gbeta, coef, C);
+    rc = ds_last_launch_error();
+    if (rc) return rc;
+    const long long n_vec = n_pix * (C / 4);
+    DS_LAUNCH(bn_bwd_apply_kernel, grid_for(n_vec), 256, 0, stream, (const float *)gy, z, mean, invstd,
+              (const float *)coef, gz, n_vec, C);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_colsum_f32(const float *x, float *out, int R, int C, void *stream) {
+    DS_REQUIRE(x && out, DS_ERR_NULL);
+    DS_REQUIRE(R > 0 && C > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(colsum_kernel, ds_ceil_div(C, 256), 256, 0, stream, x, out, R, C);
+    return ds_last_launch_error();
 }

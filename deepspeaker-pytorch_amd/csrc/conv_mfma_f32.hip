@@ -459,6 +459,76 @@ extern "C" int ds_conv_stats_rows(const ds_conv_shape *s) {
     return rc == DS_OK ? pl.n_mtiles : rc;
 }
 
+// ------------------------------------------------------------------------------------------
+// data gradient (autograd of nn.Conv2d, reference model.py:69,73,192,197,202 under
+// loss.backward(), train_triplet.py:223,290)
+//   stride 1: a plain convolution of dY with the flipped, transposed filter bank.
+//   stride 2: dX[2r+ph, 2c+pw] only receives the taps kh = ph (mod 2), kw = pw (mod 2), so the
+//   transposed convolution splits into four dense stride-1 convolutions over the dY grid (3x3,
+//   3x2, 2x3 and 2x2 taps) whose outputs interleave -- no zero-stuffing, no wasted MFMAs.
+// ------------------------------------------------------------------------------------------
+namespace {
+// taps of parity class p in ascending kernel index; returns count, fills k[] and d[] (input offset)
+int s2_class_taps(int p, int *k, int *d) {
+    int n = 0;
+    for (int kk = p; kk < 5; kk += 2) { k[n] = kk; d[n] = (p + 2 - kk) / 2; ++n; }
+    return n;
+}
+}  // namespace
+
+extern "C" int ds_conv_dgrad_f32(const ds_conv_shape *s, const float *gy, const float *w_dgrad_packed, float *gx,
+                                 void *stream) {
+    DS_REQUIRE(s && gy && w_dgrad_packed && gx, DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(gy) && DS_ALIGNED16(w_dgrad_packed) && DS_ALIGNED16(gx), DS_ERR_ALIGNMENT);
+    int Ho, Wo;
+    int rc = ds_conv_out_dims(s, &Ho, &Wo);
+    if (rc != DS_OK) return rc;
+    if (s->stride == 1) {
+        ds_conv_shape t = *s;
+        t.Cin = s->Cout;
+        t.Cout = s->Cin;
+        ConvPlan pl;
+        rc = plan_forward(pl, &t, false);
+        if (rc != DS_OK) return rc;
+        pl.k.x = gy; pl.k.w = w_dgrad_packed; pl.k.y = gx;
+        pl.k.scale = pl.k.shift = pl.k.res = nullptr; pl.k.stats = nullptr;
+        pl.k.flags = 0;
+        return launch(pl, t.KS, stream);
+    }
+    DS_REQUIRE(s->KS == 5 && s->stride == 2, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(s->Cout % CK == 0 && s->Cin % 64 == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
+    size_t w_off = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            int kh[3], dh[3], kw[3], dw[3];
+            const int nh = s2_class_taps(ph, kh, dh), nw = s2_class_taps(pw, kw, dw);
+            const int nt = nh * nw;
+            const int Hr = (s->H - ph + 1) / 2, Wc = (s->W - pw + 1) / 2;
+            const size_t w_this = w_off;
+            w_off += (size_t)nt * s->Cout * s->Cin;
+            if (Hr <= 0 || Wc <= 0) continue;
+            ConvPlan pl;
+            ConvK &k = pl.k;
+            k.H = Ho; k.W = Wo; k.Cin = s->Cout;
+            k.Hr = Hr; k.Wc = Wc; k.Ho = s->H; k.Wo = s->W; k.Cout = s->Cin;
+            k.IS = 1; k.OS = 2; k.OH0 = ph; k.OW0 = pw;
+            k.NT = nt;
+            const int dh_min = dh[nh - 1], dw_min = dw[nw - 1];       // offsets descend with the kernel index
+            k.dh_min = dh_min; k.dw_min = dw_min;
+            rc = plan_tiles(pl, s->B, Hr, Wc, 1, nh, nw, s->Cin, false);
+            if (rc != DS_OK) return rc;
+            for (int i = 0; i < nh; ++i)
+                for (int j = 0; j < nw; ++j) k.tap_off[i * nw + j] = (dh[i] - dh_min) * k.cols_in + (dw[j] - dw_min);
+            k.x = gy; k.w = w_dgrad_packed + w_this; k.y = gx;
+            k.scale = k.shift = k.res = nullptr; k.stats = nullptr;
+            k.flags = 0;
+            rc = launch(pl, 0, stream);
+            if (rc != DS_OK) return rc;
+        }
+    return DS_OK;
+}
+
 extern "C" int ds_conv_plan_describe(const ds_conv_shape *s, int *out8) {
     DS_REQUIRE(out8, DS_ERR_NULL);
     ConvPlan pl;

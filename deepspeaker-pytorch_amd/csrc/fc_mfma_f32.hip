@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) fc_reduce_l2norm_kernel(const float *part
     for (int k = lane; k < N; k += 64) {
         float v = 0.f;
         for (int s = 0; s < S; ++s) v += partial[((size_t)s * B + r) * N + k];
-        v += bias[k];
+        if (bias) v += bias[k];
         if (row < B) f[(size_t)r * N + k] = v;
         ss += v * v;
     }
@@ -97,7 +97,7 @@ extern "C" long long ds_fc_workspace_floats(int B, int K, int N) {
 extern "C" int ds_fc_l2norm_fwd_f32(const float *pooled, const float *w_packed, const float *bias, float *workspace,
                                     float *f, float *e, int B, int K, int N, float alpha, float eps,
                                     void *stream) {
-    DS_REQUIRE(pooled && w_packed && bias && workspace && f, DS_ERR_NULL);
+    DS_REQUIRE(pooled && w_packed && workspace && f, DS_ERR_NULL);
     DS_REQUIRE(B > 0 && K > 0 && N > 0 && K % (4 * CK) == 0 && N % 128 == 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(pooled) && DS_ALIGNED16(w_packed), DS_ERR_ALIGNMENT);
     const int S = fc_splits(K), n_tiles = N / 128, m_tiles = ds_ceil_div(B, 32);

@@ -52,6 +52,7 @@ class PackedWeights:
     fc: torch.Tensor                # packed as a 1x1 convolution over k' = f*C + c
     fc_bias: torch.Tensor
     fc_ones: torch.Tensor
+    fc_dgrad: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -116,9 +117,9 @@ class Engine:
                 packs.append(pl)
             sw = StageWeights(pc, packs[0], packs[1])
             if with_dgrad:
-                if i > 1:
+                if i > 1:       # 5x5 stride 2: four parity-class banks (ds_conv_dgrad_f32)
                     sw.conv_dgrad = torch.empty_like(pc)
-                    lib.call("ds_pack_conv_weight_f32", self._p(w), self._p(sw.conv_dgrad), co, ci, 5, 1, st)
+                    lib.call("ds_pack_conv_dgrad_s2_f32", self._p(w), self._p(sw.conv_dgrad), co, ci, st)
                 for j, attr in ((1, "l_conv1_dgrad"), (2, "l_conv2_dgrad")):
                     wl = sd[f"model.layer{i}.0.conv{j}.weight"].detach()
                     pd = torch.empty(wl.numel(), dtype=torch.float32, device=wl.device)
@@ -134,7 +135,12 @@ class Engine:
         lib.call("ds_pack_fc_weight_f32", self._p(wfc), self._p(pfc), wfc.shape[0], c_last, f_bins,
                  self._stream(wfc))
         ones = torch.ones(wfc.shape[0], dtype=torch.float32, device=wfc.device)
-        return PackedWeights(stages, pfc, bfc.contiguous(), ones)
+        pw = PackedWeights(stages, pfc, bfc.contiguous(), ones)
+        if with_dgrad:
+            pw.fc_dgrad = torch.empty_like(pfc)
+            lib.call("ds_pack_fc_weight_dgrad_f32", self._p(wfc), self._p(pw.fc_dgrad), wfc.shape[0], c_last,
+                     f_bins, self._stream(wfc))
+        return pw
 
     def bn_fold(self, bn: BNParams) -> Tuple[torch.Tensor, torch.Tensor]:
         c = bn.weight.numel()

@@ -198,7 +198,8 @@ class _ResCNNTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ge):
         from .backward import backward_train
-        grads = backward_train(get_engine(), ctx.model, ctx.pw, ctx.saved_forward, ge.contiguous())
+        bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
+        grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float())
         ctx.saved_forward = None
         return (None, None) + tuple(grads.get(n) for n in ctx.param_names)
 

@@ -66,6 +66,8 @@ int ds_pack_conv1_weight_f32(const float *w_oihw, float *w_packed, int Cout, voi
 /* fc weight [N, C*F] indexed c*F+f (model.py:164,208) -> 1x1-conv packing over k' = f*C + c,
  * the order in which ds_avgpool_time_f32 emits the pooled features. */
 int ds_pack_fc_weight_f32(const float *w, float *w_packed, int N, int C, int F, void *stream);
+/* the transposed bank for the fc data gradient (gpooled = gf . W), same k' order */
+int ds_pack_fc_weight_dgrad_f32(const float *w, float *w_packed, int N, int C, int F, void *stream);
 
 /* ---- BatchNorm ---------------------------------------------------------------------------------- */
 /* eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
@@ -120,7 +122,8 @@ int ds_l2norm_scale_f32(const float *f, float *e, int B, int D, float alpha, flo
 
 /* fused projection + normalisation: f = pooled . W^T + b  (model.py:209), e = alpha f / |f|
  * (model.py:210-213).  Split-K MFMA GEMM + a deterministic reduce; `workspace` holds
- * ds_fc_workspace_floats(B,K,N) floats; `e` may be NULL (projection only). */
+ * ds_fc_workspace_floats(B,K,N) floats; `bias` and `e` may be NULL (plain GEMM, used by the backward
+ * pass for gpooled = gf . W). */
 long long ds_fc_workspace_floats(int B, int K, int N);
 int ds_fc_l2norm_fwd_f32(const float *pooled, const float *w_packed, const float *bias,
                          float *workspace, float *f, float *e, int B, int K, int N, float alpha,
@@ -138,6 +141,33 @@ int ds_triplet_margin_fwd_f32(const float *a, const float *p, const float *n, fl
 int ds_triplet_filter_f32(const float *d_p, const float *d_n, float margin, long long *idx,
                           int *count, float *mean_diff, int N, void *stream);
 
+
+/* ---- backward of the convolution stack (torch autograd of nn.Conv2d / nn.BatchNorm2d under
+ *      loss.backward(), train_triplet.py:223,290) -------------------------------- */
+/* filter bank of the 5x5 stride-2 data gradient: four parity classes, see ds_conv_dgrad_f32 */
+int ds_pack_conv_dgrad_s2_f32(const float *w_oihw, float *w_packed, int Cout, int Cin, void *stream);
+/* gx[B,H,W,Cin] = dL/dx given gy[B,Ho,Wo,Cout] = dL/dy of the convolution described by `s` (the
+ * FORWARD shape).  w_dgrad_packed: ds_pack_conv_weight_f32(..., dgrad=1) for stride 1,
+ * ds_pack_conv_dgrad_s2_f32 for the 5x5 stride-2 layers. */
+int ds_conv_dgrad_f32(const ds_conv_shape *s, const float *gy, const float *w_dgrad_packed,
+                      float *gx, void *stream);
+/* gw_oihw[Cout,Cin,KS,KS] = dL/dW given the layer input x[B,H,W,Cin] and gy[B,Ho,Wo,Cout].  Pixel-split
+ * MFMA GEMM + deterministic reduce; `workspace`: ds_conv_wgrad_workspace_floats(s) floats.  Cin = 1
+ * selects the conv1 kernel.  fc_F > 0: `s` is the fc layer as a 1x1 convolution over [1,B,1,K] and
+ * the result is written in the reference's [N, C*F] feature order (model.py:164,208). */
+long long ds_conv_wgrad_workspace_floats(const ds_conv_shape *s);
+int ds_conv_wgrad_f32(const ds_conv_shape *s, const float *x, const float *gy, float *workspace,
+                      float *gw_oihw, int fc_F, void *stream);
+/* BatchNorm (train mode) backward in one call: gy = (g1 [+ g2]) masked by the clipped-ReLU of `act`
+ * (NULL: unmasked); reductions sum gy, sum gy*xhat; ggamma, gbeta; gz = dL/d(conv output).
+ * partial: ds_bn_bwd_partial_rows(n_pix) * C * 2 floats; coef: 3*C floats; gy is written (it is the
+ * masked gradient the residual branch re-uses). */
+int ds_bn_bwd_partial_rows(long long n_pix);
+int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act, const float *z,
+                  const float *mean, const float *invstd, const float *gamma, float *gy,
+                  float *partial, float *coef, float *ggamma, float *gbeta, float *gz,
+                  long long n_pix, int C, void *stream);
+int ds_colsum_f32(const float *x, float *out, int R, int C, void *stream);
 
 /* ---- backward of the loss side and the tail (torch autograd of the lines cited above; the
  *      reference obtains them from loss.backward(), train_triplet.py:223,290) ------------------- */

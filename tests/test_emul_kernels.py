@@ -133,3 +133,129 @@ def test_conv1(shape):
     tot = stats.astype(np.float64).sum(axis=0)
     np.testing.assert_allclose(tot[:, 0], z.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(tot[:, 1], (z * z).sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# backward kernels
+# ------------------------------------------------------------------------------------------------
+DGRAD_CASES = [
+    (2, 64, 8, 9, 32, 3, 1), (3, 128, 16, 20, 8, 3, 1),
+    (2, 64, 8, 16, 32, 5, 2), (2, 64, 16, 13, 16, 5, 2), (3, 128, 8, 7, 8, 5, 2), (1, 64, 8, 1, 4, 5, 2),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv_dgrad(case):
+    """dL/dx of nn.Conv2d: flipped-filter convolution (stride 1) / four parity-class convolutions (stride 2)."""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(abs(hash(case)) % 2**31)
+    x = rs.randn(b, ci, h, w)
+    wt = rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    gy = rs.randn(b, co, ho, wo)
+    gx_ref, _ = O.conv2d_bwd(x, wt, gy, s, k // 2)
+    wsrc, wp = to_aligned(wt.astype(np.float32)), aligned(wt.size)
+    if s == 1:
+        lib.call("ds_pack_conv_weight_f32", ptr(wsrc), ptr(wp), co, ci, k, 1, None)
+    else:
+        lib.call("ds_pack_conv_dgrad_s2_f32", ptr(wsrc), ptr(wp), co, ci, None)
+    gyh = nhwc(gy.astype(np.float32))
+    gx = aligned((b, h, w, ci), fill=np.nan)
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    lib.call("ds_conv_dgrad_f32", ctypes.byref(shp), ptr(gyh), ptr(wp), ptr(gx), None)
+    assert rel_err(nchw(gx), gx_ref) < 2e-6
+
+
+@pytest.mark.parametrize("C,npix,with_g2,with_act", [(64, 700, True, True), (128, 300, False, True),
+                                                       (512, 50, False, False), (256, 1030, True, False)])
+def test_bn_bwd(C, npix, with_g2, with_act):
+    lib = emul_lib()
+    rs = np.random.RandomState(C + npix)
+    z = rs.randn(npix, C).astype(np.float32) * 2 + 1
+    g1 = rs.randn(npix, C).astype(np.float32)
+    g2 = rs.randn(npix, C).astype(np.float32) if with_g2 else None
+    act = (rs.rand(npix, C).astype(np.float32) * 30 - 5).clip(0, 20) if with_act else None
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32)
+    mean = z.astype(np.float64).mean(0)
+    invstd = 1 / np.sqrt(z.astype(np.float64).var(0) + 1e-5)
+    gy_ref = g1.astype(np.float64) + (g2 if with_g2 else 0)
+    if with_act:
+        gy_ref = gy_ref * ((act > 0) & (act < 20))
+    zz = z.astype(np.float64).T.reshape(1, C, npix, 1)
+    gz_ref, gg_ref, gb_ref = O.bn_train_bwd(zz, mean, invstd, gamma.astype(np.float64),
+                                            gy_ref.T.reshape(1, C, npix, 1))
+    rows = lib.raw("ds_bn_bwd_partial_rows")(npix)
+    bufs = dict(g1=to_aligned(g1), g2=to_aligned(g2) if with_g2 else None, act=to_aligned(act) if with_act else None,
+                z=to_aligned(z), mean=to_aligned(mean.astype(np.float32)), invstd=to_aligned(invstd.astype(np.float32)),
+                gamma=to_aligned(gamma), gy=aligned((npix, C), fill=np.nan), partial=aligned((rows, C, 2), fill=np.nan),
+                coef=aligned(3 * C), gg=aligned(C), gb=aligned(C), gz=aligned((npix, C), fill=np.nan))
+    lib.call("ds_bn_bwd_f32", ptr(bufs["g1"]), ptr(bufs["g2"]), ptr(bufs["act"]), ptr(bufs["z"]), ptr(bufs["mean"]),
+             ptr(bufs["invstd"]), ptr(bufs["gamma"]), ptr(bufs["gy"]), ptr(bufs["partial"]), ptr(bufs["coef"]),
+             ptr(bufs["gg"]), ptr(bufs["gb"]), ptr(bufs["gz"]), npix, C, None)
+    assert rel_err(bufs["gy"], gy_ref) < 1e-6
+    assert rel_err(bufs["gg"], gg_ref) < 1e-4 and rel_err(bufs["gb"], gb_ref) < 1e-4
+    assert rel_err(bufs["gz"], gz_ref[0, :, :, 0].T) < 1e-4
+
+
+WGRAD_CASES = [
+    (2, 64, 64, 9, 32, 3, 1),       # stage-1 geometry, ragged rows
+    (3, 128, 64, 20, 8, 3, 1),      # multi-row segments
+    (5, 64, 128, 10, 4, 3, 1),      # several images per tile
+    (2, 64, 128, 16, 32, 5, 2),     # 5x5 stride 2: kernel-row groups, wide-co tiles
+    (3, 64, 64, 13, 16, 5, 2),      # 5x5 stride 2, odd height, 64x64 tiles
+    (1, 128, 64, 70, 1, 1, 1),      # the fc layer as a 1x1 convolution over [1,B,1,K]
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(case):
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(abs(hash(case)) % 2**31)
+    x = rs.randn(b, ci, h, w)
+    wt = rs.randn(co, ci, k, k)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    gy = rs.randn(b, co, ho, wo)
+    _, gw_ref = O.conv2d_bwd(x, wt, gy, s, k // 2, need_gx=False)
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    n_ws = lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp))
+    assert n_ws > 0
+    ws = aligned(n_ws, fill=np.nan)
+    xh, gyh = nhwc(x.astype(np.float32)), nhwc(gy.astype(np.float32))
+    gw = aligned((co, ci, k, k), fill=np.nan)
+    lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), ptr(xh), ptr(gyh), ptr(ws), ptr(gw), 0, None)
+    assert rel_err(gw, gw_ref) < 3e-6
+
+
+def test_fc_wgrad_feature_permutation():
+    lib = emul_lib()
+    rs = np.random.RandomState(8)
+    B, C, F, N = 40, 32, 4, 64                  # K = C*F = 128
+    pooled = rs.randn(B, F * C).astype(np.float32)             # kernel order k' = f*C + c
+    gf = rs.randn(B, N).astype(np.float32)
+    ref_kp = gf.astype(np.float64).T @ pooled.astype(np.float64)            # [N, f*C+c]
+    ref = ref_kp.reshape(N, F, C).transpose(0, 2, 1).reshape(N, C * F)      # reference order c*F+f
+    shp = ConvShape(1, B, 1, F * C, N, 1, 1)
+    ws = aligned(lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp)), fill=np.nan)
+    gw = aligned((N, C * F), fill=np.nan)
+    pa, ga = to_aligned(pooled), to_aligned(gf)
+    lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), ptr(pa), ptr(ga), ptr(ws), ptr(gw), F, None)
+    assert rel_err(gw, ref) < 3e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 160, 64), (3, 13, 64), (1, 7, 20)])
+def test_conv1_wgrad(shape):
+    lib = emul_lib()
+    b, h, w = shape
+    rs = np.random.RandomState(h + 1)
+    x = rs.randn(b, 1, h, w)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    gy = rs.randn(b, 64, ho, wo)
+    _, gw_ref = O.conv2d_bwd(x, rs.randn(64, 1, 5, 5), gy, 2, 2, need_gx=False)
+    shp = ConvShape(b, h, w, 1, 64, 5, 2)
+    ws = aligned(lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp)), fill=np.nan)
+    gw = aligned((64, 1, 5, 5), fill=np.nan)
+    xa, ga = to_aligned(x.astype(np.float32)), nhwc(gy.astype(np.float32))
+    lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), ptr(xa), ptr(ga), ptr(ws), ptr(gw), 0, None)
+    assert rel_err(gw, gw_ref) < 3e-6

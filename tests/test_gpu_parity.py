@@ -206,3 +206,114 @@ def test_layout_roundtrip(dev):
     eng.lib.call("ds_nchw_to_nhwc_f32", eng._p(x), eng._p(y), 3, 5, 7, 4, eng._stream(x))
     eng.lib.call("ds_nhwc_to_nchw_f32", eng._p(y), eng._p(z), 3, 5, 7, 4, eng._stream(x))
     assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous()) and torch.equal(z, x)
+
+
+def grad_digest(a):
+    a = np.asarray(a, np.float64).ravel()
+    stride = max(1, a.size // 64)
+    return np.concatenate([[np.sqrt((a * a).sum()), a.sum()], a[:16], a[::stride][:64]])
+
+
+def test_backward_single_forward(dev, golden):
+    """Network backward from a fixed embedding gradient (B = 8, T = 160) vs (i) the numpy oracle in float64
+    on the same inputs and (ii) the digests recorded from the reference evaluated in float64 / float32.
+    A clipped-ReLU mask that flips between an fp32 and an fp64 forward moves early-layer gradients by up
+    to ~1e-2 (the reference's own fp32 run is that far from its fp64 run, tests/test_oracle_golden.py),
+    so the late layers are held tight and the early ones to that noise band."""
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    m = build_model(sd).train()
+    x = O.make_input(seed=32, batch=8)
+    ge = np.random.RandomState(77).randn(8, 512).astype(np.float32)
+    e = m(torch.from_numpy(x).cuda())
+    assert rel_err(e.detach().cpu().numpy(), golden["single_train_emb"]) < 5e-5
+    m.zero_grad()
+    e.backward(torch.from_numpy(ge).cuda())
+    cache = {}
+    O.forward(sd, x, train=True, dtype=np.float64, cache=cache)
+    ref = O.backward(sd, cache, x, ge)
+    worst = {}
+    for name, p in m.named_parameters():
+        if name.startswith("model.classifier"):
+            assert p.grad is None
+            continue
+        got = p.grad.cpu().numpy()
+        assert got.shape == ref[name].shape
+        worst[name] = np.linalg.norm(got - ref[name]) / np.linalg.norm(ref[name])
+        d64, d32 = golden["single_train64_grad/" + name], golden["single_train_grad/" + name]
+        dg = grad_digest(got)
+        assert np.abs(dg - d64).max() <= 8e-2 * np.abs(d64).max(), name
+        assert np.abs(dg - d32).max() <= 8e-2 * np.abs(d32).max(), name
+    print({k: f"{v:.1e}" for k, v in worst.items()})
+    for name in ("model.fc.weight", "model.fc.bias", "model.layer4.0.bn2.weight", "model.layer4.0.conv2.weight"):
+        assert worst[name] < 1e-4, (name, worst[name])
+    assert max(worst.values()) < 3e-2
+
+
+def test_training_step_like_the_reference_loop(dev, golden):
+    """train_triplet.py:215-224: three train-mode forwards, TripletMarginLoss, backward, Adagrad step."""
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    m = build_model(sd).train()
+    opt = torch.optim.Adagrad(m.parameters(), lr=0.1, lr_decay=1e-4)          # train_triplet.py:372-375
+    xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=8)).cuda() for i in range(3)]
+    out_a, out_p, out_n = m(xs[0]), m(xs[1]), m(xs[2])
+    loss = TripletMarginLoss(0.1).forward(out_a, out_p, out_n)
+    ref_loss = float(golden["full_train_loss"])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-3 * abs(ref_loss)
+    opt.zero_grad()
+    loss.backward()
+    n_checked = 0
+    for name, p in m.named_parameters():
+        if name.startswith("model.classifier"):
+            continue
+        ref = golden["full_train_grad/" + name]
+        dg = grad_digest(p.grad.cpu().numpy())
+        assert np.abs(dg - ref).max() <= 8e-2 * np.abs(ref).max(), name
+        n_checked += 1
+    assert n_checked == 38
+    before = m.model.conv4.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m.model.conv4.weight.detach())
+    assert int(m.model.bn1.num_batches_tracked) == 3
+    # the next forward sees the updated weights (packed-filter cache is keyed on parameter versions)
+    e2 = m(xs[0])
+    assert not torch.allclose(e2.detach(), out_a.detach())
+    # checkpoint round trip (train_triplet.py:325-327, 177-186)
+    ck = {"epoch": 1, "state_dict": m.state_dict(), "optimizer": opt.state_dict()}
+    m2 = build_model(sd)
+    m2.load_state_dict(ck["state_dict"])
+    m.eval(), m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m(xs[0]), m2(xs[0]))
+
+
+BWD_KERNEL_CASES = [(4, 64, 64, 80, 32, 3, 1), (4, 128, 256, 40, 16, 5, 2), (6, 512, 512, 10, 4, 3, 1),
+                    (3, 64, 128, 25, 16, 5, 2)]
+
+
+@pytest.mark.parametrize("case", BWD_KERNEL_CASES)
+def test_conv_backward_kernels_vs_oracle(dev, case):
+    from deepspeaker_pytorch_amd._native import ConvShape
+    from deepspeaker_pytorch_amd.backward import _dgrad, _wgrad
+    from deepspeaker_pytorch_amd.model import get_engine
+    eng = get_engine()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(abs(hash(case)) % 2**31)
+    x = rs.randn(b, ci, h, w)
+    wt = rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    gy = rs.randn(b, co, ho, wo)
+    gx_ref, gw_ref = O.conv2d_bwd(x, wt, gy, s, k // 2)
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    tw = torch.from_numpy(wt.astype(np.float32)).cuda()
+    wp = torch.empty(wt.size, device="cuda")
+    if s == 1:
+        eng.lib.call("ds_pack_conv_weight_f32", eng._p(tw), eng._p(wp), co, ci, k, 1, eng._stream(tw))
+    else:
+        eng.lib.call("ds_pack_conv_dgrad_s2_f32", eng._p(tw), eng._p(wp), co, ci, eng._stream(tw))
+    xh = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float32)).cuda()
+    gyh = torch.from_numpy(np.ascontiguousarray(gy.transpose(0, 2, 3, 1)).astype(np.float32)).cuda()
+    gx = _dgrad(eng, shp, gyh, wp)
+    gw = _wgrad(eng, shp, xh, gyh, (co, ci, k, k))
+    assert rel_err(gx.cpu().numpy().transpose(0, 3, 1, 2), gx_ref) < 1e-5
+    assert rel_err(gw.cpu().numpy(), gw_ref) < 1e-5
