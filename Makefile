@@ -6,7 +6,7 @@ CSRC  := $(PKG)/csrc
 SRCS  := $(wildcard $(CSRC)/*.hip)
 HDRS  := $(wildcard $(CSRC)/*.h) include/deepspeaker_hip.h
 LIB   := $(PKG)/libdeepspeaker_hip.so
-FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$(CSRC) -Iinclude -Wall -Wno-unused-function
+FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$(CSRC) -Iinclude -Wall -Wno-unused-function -Wno-pass-failed
 
 all: $(LIB)
 

@@ -60,6 +60,13 @@ _SIGNATURES = {
     "ds_bn_bwd_partial_rows": (c_int, [c_longlong]),
     "ds_bn_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
     "ds_colsum_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ds_partial_sum_f64": (c_int, [_P, c_int, _P, c_int, _P]),
+    "ds_bn_stats_from_sums_f32": (c_int, [_P, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "ds_bn_bwd_reduce_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
+    "ds_bn_bwd_apply_f32": (c_int, [_P, c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
+    "ds_gather_rows_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "ds_scatter_add_rows_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_mine_semihard_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_pairwise_distance_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_margin_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_l2norm_scale_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),

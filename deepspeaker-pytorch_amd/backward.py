@@ -16,8 +16,10 @@ from ._native import ConvShape
 from .engine import ALPHA, L2_EPS, STAGE_CHANNELS, Engine, PackedWeights, SavedForward
 
 
-def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma):
-    """(masked upstream gradient gy, gz = dL/d(conv output), dgamma, dbeta)."""
+def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
+    """(masked upstream gradient gy, gz = dL/d(conv output), dgamma, dbeta).  With a `reducer` the two
+    per-channel sums are all-reduced between the reduce and the apply kernel (global-batch BatchNorm);
+    dgamma / dbeta then already are the global gradients."""
     mean, invstd, _ = stats
     c = z.shape[-1]
     n_pix = z.numel() // c
@@ -29,6 +31,18 @@ def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma):
     coef = torch.empty(3 * c, dtype=torch.float32, device=dev)
     gg = torch.empty(c, dtype=torch.float32, device=dev)
     gb = torch.empty_like(gg)
+    if reducer is not None and reducer.world > 1:
+        st = eng._stream(z)
+        eng.lib.call("ds_bn_bwd_reduce_f32", eng._p(g1), eng._p(g2), eng._p(act), eng._p(z), eng._p(mean),
+                     eng._p(invstd), eng._p(gy), eng._p(partial), n_pix, c, st)
+        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+        eng.lib.call("ds_partial_sum_f64", eng._p(partial), rows, eng._p(sums), c, st)
+        sums[2 * c] = float(n_pix)
+        reducer.all_reduce_sum_(sums)
+        eng.lib.call("ds_bn_bwd_apply_f32", eng._p(sums), 0, eng._p(gy), eng._p(z),
+                     eng._p(mean), eng._p(invstd), eng._p(gamma.detach()), eng._p(coef), eng._p(gg), eng._p(gb),
+                     eng._p(gz), n_pix, c, st)
+        return gy, gz, gg, gb
     eng.lib.call("ds_bn_bwd_f32", eng._p(g1), eng._p(g2), eng._p(act), eng._p(z), eng._p(mean), eng._p(invstd),
                  eng._p(gamma.detach()), eng._p(gy), eng._p(partial), eng._p(coef), eng._p(gg), eng._p(gb),
                  eng._p(gz), n_pix, c, eng._stream(z))
@@ -53,7 +67,7 @@ def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad):
 
 
 def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
-                   ge: torch.Tensor) -> Dict[str, torch.Tensor]:
+                   ge: torch.Tensor, reducer=None) -> Dict[str, torch.Tensor]:
     """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512]."""
     lib = eng.lib
     grads: Dict[str, torch.Tensor] = {}
@@ -92,19 +106,19 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         # out = clip(bn2(conv2(y)) + r)            (model.py:73-80)
         name = f"model.layer{i}.0.bn2"
         g_out, gz, gg, gbeta = _bn_bwd(eng, g, None, None if g_is_masked else c_act, saved.raws[name],
-                                       saved.stats[name], bn_weights[name])
+                                       saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3))
         g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad)
         # y = clip(bn1(conv1(r)))                  (model.py:69-71)
         name = f"model.layer{i}.0.bn1"
-        _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name])
+        _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3))
         g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv-path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
-        _, gz, gg, gbeta = _bn_bwd(eng, g_r, g_out, a_act, saved.raws[name], saved.stats[name], bn_weights[name])
+        _, gz, gg, gbeta = _bn_bwd(eng, g_r, g_out, a_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
         shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)

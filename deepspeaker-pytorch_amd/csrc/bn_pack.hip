@@ -409,6 +409,124 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float *x, float *out,
 
 }  // namespace
 
+// ---- split forms for data-parallel training: local sums -> (all-reduce by the caller) -> finalize ----
+namespace {
+
+// sums[c][2] (double) = sum over the partial rows; one workgroup per 32 channels
+__global__ void __launch_bounds__(256) partial_sum_f64_kernel(const float *partial, int n_partial, double *sums, int C) {
+    double *red = (double *)ds_dynamic_lds();
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rl; r < n_partial; r += 8) {
+            s1 += (double)partial[((size_t)r * C + c) * 2 + 0];
+            s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
+        }
+    red[(rl * 32 + cl) * 2 + 0] = s1;
+    red[(rl * 32 + cl) * 2 + 1] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            t1 += red[(k * 32 + cl) * 2 + 0];
+            t2 += red[(k * 32 + cl) * 2 + 1];
+        }
+        sums[c * 2 + 0] = t1;
+        sums[c * 2 + 1] = t2;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_stats_from_sums_kernel(const double *sums, double count, const float *gamma,
+                                                                 const float *beta, float eps, float momentum,
+                                                                 float *running_mean, float *running_var,
+                                                                 float *batch_mean, float *batch_invstd, float *scale,
+                                                                 float *shift, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (count <= 0.0) count = sums[2 * C];               // pixel count travelled with the all-reduce
+    const double mean = sums[c * 2] / count;
+    double var = sums[c * 2 + 1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    if (running_mean) {
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+    if (batch_mean) batch_mean[c] = (float)mean;
+    if (batch_invstd) batch_invstd[c] = (float)invstd;
+    const double sc = (double)gamma[c] * invstd;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - mean * sc);
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_from_sums_kernel(const double *sums, double count, const float *gamma,
+                                                               const float *invstd, float *ggamma, float *gbeta,
+                                                               float *coef, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (count <= 0.0) count = sums[2 * C];
+    gbeta[c] = (float)sums[c * 2];
+    ggamma[c] = (float)sums[c * 2 + 1];
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(sums[c * 2] / count);
+    coef[2 * C + c] = (float)(sums[c * 2 + 1] / count);
+}
+
+}  // namespace
+
+extern "C" int ds_partial_sum_f64(const float *partial, int n_partial, double *sums, int C, void *stream) {
+    DS_REQUIRE(partial && sums, DS_ERR_NULL);
+    DS_REQUIRE(n_partial > 0 && C > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(partial_sum_f64_kernel, ds_ceil_div(C, 32), 256, 8 * 32 * 2 * sizeof(double), stream, partial, n_partial,
+              sums, C);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_bn_stats_from_sums_f32(const double *sums, long long count, const float *gamma, const float *beta,
+                                         float eps, float momentum, float *running_mean, float *running_var,
+                                         float *batch_mean, float *batch_invstd, float *scale, float *shift, int C,
+                                         void *stream) {
+    DS_REQUIRE(sums && gamma && beta && scale && shift, DS_ERR_NULL);
+    DS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DS_ERR_NULL);
+    DS_REQUIRE(C > 0 && count >= 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(bn_stats_from_sums_kernel, ds_ceil_div(C, 256), 256, 0, stream, sums, (double)count, gamma, beta, eps,
+              momentum, running_mean, running_var, batch_mean, batch_invstd, scale, shift, C);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_bn_bwd_reduce_f32(const float *g1, const float *g2, const float *act, const float *z,
+                                    const float *mean, const float *invstd, float *gy, float *partial,
+                                    long long n_pix, int C, void *stream) {
+    DS_REQUIRE(g1 && z && mean && invstd && gy && partial, DS_ERR_NULL);
+    DS_REQUIRE(n_pix > 0 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) && DS_ALIGNED16(mean) && DS_ALIGNED16(invstd),
+               DS_ERR_ALIGNMENT);
+    long long blocks = (n_pix + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const int ppb = (int)((n_pix + blocks - 1) / blocks);
+    const int slots = 256 / (C / 4);
+    DS_LAUNCH(bn_bwd_reduce_kernel, (int)blocks, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd,
+              gy, partial, n_pix, C, ppb);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_bn_bwd_apply_f32(const double *sums, long long count, const float *gy, const float *z,
+                                   const float *mean, const float *invstd, const float *gamma, float *coef,
+                                   float *ggamma, float *gbeta, float *gz, long long n_pix, int C, void *stream) {
+    DS_REQUIRE(sums && gy && z && mean && invstd && gamma && coef && ggamma && gbeta && gz, DS_ERR_NULL);
+    DS_REQUIRE(n_pix > 0 && count >= 0 && C >= 4 && (C % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(bn_bwd_from_sums_kernel, ds_ceil_div(C, 256), 256, 0, stream, sums, (double)count, gamma, invstd, ggamma,
+              gbeta, coef, C);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    const long long n_vec = n_pix * (C / 4);
+    DS_LAUNCH(bn_bwd_apply_kernel, grid_for(n_vec), 256, 0, stream, gy, z, mean, invstd, (const float *)coef, gz, n_vec,
+              C);
+    return ds_last_launch_error();
+}
+
 extern "C" int ds_bn_bwd_partial_rows(long long n_pix) {
     if (n_pix <= 0) return DS_ERR_BAD_SHAPE;
     long long blocks = (n_pix + 255) / 256;            // >= 256 pixels per workgroup

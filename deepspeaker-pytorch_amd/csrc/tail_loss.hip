@@ -217,7 +217,107 @@ __global__ void __launch_bounds__(256) avgpool_time_bwd_kernel(const float *gpoo
     }
 }
 
+// ---- cross-GPU semi-hard negative search (NEW capability named by BASELINE.json north_star; the
+//      reference only filters pre-sampled triplets).  For anchor i: among candidates j with
+//      cand_label[j] != anchor_label[i], the closest one that is farther than d_p[i]; if none is
+//      semi-hard, the closest overall; ties -> lowest j; -1 when every candidate shares the label.
+//      One workgroup per anchor: the anchor row sits in LDS, each wave scans candidates, lanes split
+//      the 512 dimensions, wave-shuffle reduction per candidate; fixed scan order => deterministic. ----
+__global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor, const float *d_p,
+                                                            const long long *anchor_label, const float *cand,
+                                                            const long long *cand_label, long long *out, float *out_d,
+                                                            int M, int D, float eps) {
+    float *arow = ds_dynamic_lds();                         // [D] + 4*{semi d, semi j, any d, any j}
+    float *res = arow + D;
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < D; k += 256) arow[k] = anchor[(size_t)i * D + k];
+    __syncthreads();
+    const long long la = anchor_label[i];
+    const float dp = d_p[i];
+    float best_semi = 3.0e38f, best_any = 3.0e38f;
+    int j_semi = -1, j_any = -1;
+    for (int j = wave; j < M; j += 4) {
+        const float *c = cand + (size_t)j * D;
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) {
+            const float d = fabsf(arow[k] - c[k]);
+            s += d * d;
+        }
+        s = wave_sum(s);
+        const float d = sqrtf(s + eps);
+        if (cand_label[j] != la) {
+            if (d < best_any) { best_any = d; j_any = j; }
+            if (d > dp && d < best_semi) { best_semi = d; j_semi = j; }
+        }
+    }
+    if (lane == 0) {
+        res[wave * 4 + 0] = best_semi; res[wave * 4 + 1] = __int_as_float(j_semi);
+        res[wave * 4 + 2] = best_any;  res[wave * 4 + 3] = __int_as_float(j_any);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bs = 3.0e38f, ba = 3.0e38f;
+        int js = -1, ja = -1;
+        for (int w = 0; w < 4; ++w) {
+            const float ds_ = res[w * 4 + 0], da = res[w * 4 + 2];
+            const int s_j = __float_as_int(res[w * 4 + 1]), a_j = __float_as_int(res[w * 4 + 3]);
+            if (s_j >= 0 && (ds_ < bs || (ds_ == bs && s_j < js))) { bs = ds_; js = s_j; }
+            if (a_j >= 0 && (da < ba || (da == ba && a_j < ja))) { ba = da; ja = a_j; }
+        }
+        const int j = js >= 0 ? js : ja;
+        out[i] = j;
+        if (out_d) out_d[i] = js >= 0 ? bs : (ja >= 0 ? ba : 0.0f);
+    }
+}
+
+// dst[i,:] = src[idx[i],:]  (idx < 0 -> zeros)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float *src, const long long *idx, float *dst, int N,
+                                                          int D) {
+    const int i = blockIdx.x;
+    const long long j = idx[i];
+    for (int k = threadIdx.x; k < D; k += 256) dst[(size_t)i * D + k] = j >= 0 ? src[(size_t)j * D + k] : 0.0f;
+}
+
+// dst[j,:] (+)= sum over {i : idx[i] == j} of g[i,:], i ascending (deterministic; one workgroup per dst row)
+__global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float *g, const long long *idx, float *dst, int N,
+                                                               int D, int accumulate) {
+    const int j = blockIdx.x;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        float s = accumulate ? dst[(size_t)j * D + k] : 0.0f;
+        for (int i = 0; i < N; ++i)
+            if (idx[i] == j) s += g[(size_t)i * D + k];
+        dst[(size_t)j * D + k] = s;
+    }
+}
+
 }  // namespace
+
+extern "C" int ds_gather_rows_f32(const float *src, const long long *idx, float *dst, int N, int D, void *stream) {
+    DS_REQUIRE(src && idx && dst, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(gather_rows_kernel, N, 256, 0, stream, src, idx, dst, N, D);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_scatter_add_rows_f32(const float *g, const long long *idx, float *dst, int N, int M, int D,
+                                       int accumulate, void *stream) {
+    DS_REQUIRE(g && idx && dst, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && M > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(scatter_add_rows_kernel, M, 256, 0, stream, g, idx, dst, N, D, accumulate);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_mine_semihard_f32(const float *anchor, const float *d_p, const long long *anchor_label,
+                                    const float *cand, const long long *cand_label, long long *out_index,
+                                    float *out_dist, int N, int M, int D, void *stream) {
+    DS_REQUIRE(anchor && d_p && anchor_label && cand && cand_label && out_index, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && M > 0 && D > 0 && D <= 8192, DS_ERR_BAD_SHAPE);
+    const float eps = (float)(1e-4 / (double)D);
+    DS_LAUNCH(mine_semihard_kernel, N, 256, (size_t)(D + 16) * 4, stream, anchor, d_p, anchor_label, cand, cand_label,
+              out_index, out_dist, M, D, eps);
+    return ds_last_launch_error();
+}
 
 extern "C" int ds_pairwise_distance_bwd_f32(const float *x1, const float *x2, const float *d, const float *gd,
                                             float *g1, float *g2, int N, int D, void *stream) {

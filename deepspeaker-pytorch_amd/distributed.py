@@ -1,0 +1,192 @@
+"""Data-parallel training of the triplet network: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no multi-GPU code at all; this is the new capability named in
+BASELINE.json's north_star.  Partitioning: rank r owns rows [r*B_loc, (r+1)*B_loc) of the
+anchor / positive / negative batches.  Exchange steps per iteration:
+
+1. BatchNorm batch statistics -- forward {sum x, sum x^2} and backward {sum dy, sum dy*xhat}: one tiny
+   float64 all-reduce per BatchNorm (engine.bn_finalize / backward._bn_bwd).  With them an N-rank step
+   reproduces the single-process step on the global batch.
+2. Embeddings (+ speaker labels): RCCL all-gather so every rank sees the global batch for cross-GPU
+   semi-hard negative mining; the gather is differentiable (its adjoint is a reduce-scatter), so the
+   gradient of a negative mined on another GPU returns to the rank that owns it.
+3. Filter / weight gradients: one flat bucket per stage, all-reduced (sum) asynchronously.  BatchNorm
+   affine gradients need no exchange: they are computed from the already-global sums.
+
+xGMI is point-to-point (7 links per GPU); the only bandwidth-relevant message is the 46 MB gradient
+all-reduce, issued as 5 bucket-sized collectives so RCCL can spread them over all links while the host
+keeps launching backward kernels of the next stage.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class Reducer:
+    """Thin handle on a process group (backend "nccl" = RCCL on ROCm; "gloo" in the CPU logic tests)."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised: launch one process per GPU with "
+                               "torch.distributed.run and call dist.init_process_group('nccl') first")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_sum_(self, t: torch.Tensor, async_op: bool = False):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """[n, ...] on every rank -> [world*n, ...], rank-major (equal n on all ranks)."""
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
+    def reduce_scatter_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """[world*n, ...] on every rank -> this rank's [n, ...] slice of the sum over ranks."""
+        n = t.shape[0] // self.world
+        if dist.get_backend(self.group) == "gloo":       # gloo (CPU logic tests) has no reduce-scatter
+            full = t.contiguous().clone()
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+            return full[self.rank * n:(self.rank + 1) * n].contiguous()
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.reduce_scatter_tensor(out, t.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+
+class AllGatherRows(torch.autograd.Function):
+    """Differentiable all-gather of embedding rows: backward = reduce-scatter of the gathered gradient."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, reducer: Reducer):
+        ctx.reducer = reducer
+        return reducer.all_gather_rows(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.reducer.reduce_scatter_rows(g), None
+
+
+# names of gradients that must be summed over ranks (everything except BatchNorm affine gradients,
+# which come out of the all-reduced statistics and are already global)
+def needs_allreduce(name: str) -> bool:
+    return not (".bn" in name)
+
+
+def allreduce_gradients(grads: Dict[str, torch.Tensor], reducer: Reducer, n_buckets: int = 5) -> None:
+    """Sum filter / fc gradients over the ranks in place: a few flat buckets (one per stage + fc),
+    launched asynchronously back to back, then copied back.  Deterministic bucket composition."""
+    if reducer.world == 1:
+        return
+    names = sorted(n for n in grads if needs_allreduce(n))
+    buckets: List[List[str]] = [[] for _ in range(n_buckets)]
+    for n in names:                                   # stage index from the name; fc -> last bucket
+        k = n_buckets - 1
+        for i in range(1, 5):
+            if f"conv{i}." in n and "layer" not in n or f"layer{i}." in n:
+                k = min(i - 1, n_buckets - 1)
+        buckets[k].append(n)
+    work = []
+    for b in buckets:
+        if not b:
+            continue
+        flat = torch.cat([grads[n].reshape(-1) for n in b])
+        work.append((b, flat, reducer.all_reduce_sum_(flat, async_op=True)))
+    for b, flat, h in work:
+        h.wait()
+        off = 0
+        for n in b:
+            k = grads[n].numel()
+            grads[n].copy_(flat[off:off + k].view_as(grads[n]))
+            off += k
+
+
+@dataclass
+class TripletStepResult:
+    loss: torch.Tensor                    # global-batch mean hinge (identical on every rank)
+    grads: Dict[str, torch.Tensor]        # global parameter gradients (identical on every rank)
+    embeddings: Tuple[torch.Tensor, torch.Tensor, torch.Tensor]
+    mined: Optional[torch.Tensor] = None  # index into the gathered candidate set per local anchor
+
+
+def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, reducer: Optional[Reducer] = None,
+                       labels: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                       mine: bool = False) -> TripletStepResult:
+    """One data-parallel training step on this rank's shard of the triplet batch (engine level).
+
+    reference semantics (train_triplet.py:215-224): three train-mode forwards (three BatchNorm statistic
+    sets), TripletMarginLoss over the batch, backward.  With `reducer` the statistics, the loss mean and
+    the gradients are those of the GLOBAL batch.  With `mine` (needs `labels` = (c1, c2) speaker ids of
+    positives / negatives) every anchor's negative is replaced by the semi-hard negative found among the
+    all-gathered embeddings of all ranks before the loss is taken.
+    """
+    from .backward import backward_train
+    lib = eng.lib
+    world = reducer.world if reducer is not None else 1
+    outs, saves = [], []
+    for x in (xa, xp, xn):
+        e, saved = eng.forward_train(x, pw, bns, save=True, reducer=reducer)
+        outs.append(e)
+        saves.append(saved)
+    ea, ep, en = outs
+    n_loc, d = ea.shape
+    n_glob = n_loc * world
+    st = eng._stream(ea)
+    mined = None
+    gathered = None
+    if mine:
+        if labels is None:
+            raise ValueError("mining needs the speaker labels (c1, c2) of the batch")
+        c1, c2 = labels
+        loc = torch.cat([ea, ep, en])
+        lab = torch.cat([c1, c1, c2]).to(torch.int64)
+        if reducer is not None and world > 1:
+            # [world][3*n_loc] rank-major candidate set and its labels
+            gathered = reducer.all_gather_rows(loc)
+            glab = reducer.all_gather_rows(lab)
+        else:
+            gathered, glab = loc, lab
+        d_p = eng.pairwise_distance(ea, ep)
+        mined = torch.empty(n_loc, dtype=torch.int64, device=ea.device)
+        lib.call("ds_mine_semihard_f32", eng._p(ea), eng._p(d_p), eng._p(c1.to(torch.int64).contiguous()),
+                 eng._p(gathered), eng._p(glab), eng._p(mined), None, n_loc, gathered.shape[0], d, st)
+        en_used = torch.empty_like(en)
+        lib.call("ds_gather_rows_f32", eng._p(gathered), eng._p(mined), eng._p(en_used), n_loc, d, st)
+    else:
+        en_used = en
+    loss_loc, d_p, d_n = eng.triplet_margin(ea, ep, en_used, margin)
+    # global mean: local mean * n_loc / n_glob, summed over ranks
+    loss = loss_loc * (float(n_loc) / float(n_glob))
+    if reducer is not None and world > 1:
+        reducer.all_reduce_sum_(loss)
+    gl = torch.full((1,), float(n_loc) / float(n_glob), dtype=torch.float32, device=ea.device)
+    ga, gp, gn_used = torch.empty_like(ea), torch.empty_like(ep), torch.empty_like(en)
+    lib.call("ds_triplet_margin_bwd_f32", eng._p(ea), eng._p(ep), eng._p(en_used), eng._p(d_p), eng._p(d_n),
+             float(margin), eng._p(gl), eng._p(ga), eng._p(gp), eng._p(gn_used), n_loc, d, st)
+    if mine:
+        # adjoint of the row gather, then of the all-gather: gradients of mined candidates go home
+        gcand = torch.empty_like(gathered)
+        lib.call("ds_scatter_add_rows_f32", eng._p(gn_used), eng._p(mined), eng._p(gcand), n_loc,
+                 gathered.shape[0], d, 0, st)
+        if reducer is not None and world > 1:
+            gcand = reducer.reduce_scatter_rows(gcand)
+        ga = ga + gcand[:n_loc]                         # elementwise accumulation of two gradient paths
+        gp = gp + gcand[n_loc:2 * n_loc]
+        gn = gcand[2 * n_loc:].contiguous()
+    else:
+        gn = gn_used
+    grads: Dict[str, torch.Tensor] = {}
+    for saved, g in zip(saves, (ga, gp, gn)):
+        gr = backward_train(eng, bn_weights, pw, saved, g.contiguous(), reducer=reducer)
+        for k, v in gr.items():
+            if k in grads:
+                grads[k].add_(v)
+            else:
+                grads[k] = v
+    if reducer is not None:
+        allreduce_gradients(grads, reducer)
+    return TripletStepResult(loss.reshape(()), grads, (ea, ep, en), mined)

@@ -190,13 +190,28 @@ class Engine:
                       self._p(y), self._p(stats), B, H, W, 64, flags, self._stream(x))
         return y, stats
 
-    def bn_finalize(self, stats: torch.Tensor, count: int, bn: BNParams, update_running: bool = True):
+    def bn_finalize(self, stats: torch.Tensor, count: int, bn: BNParams, update_running: bool = True,
+                    reducer=None):
+        """Per-tile partial sums -> batch mean / invstd / (scale, shift) + running-stat update.  With a
+        `reducer` (data-parallel training) the [C][2] float64 sums and the pixel count are summed over
+        the ranks first, so every rank normalises with the statistics of the global batch."""
         c = bn.weight.numel()
         dev = stats.device
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         invstd = torch.empty_like(mean)
         scale = torch.empty_like(mean)
         shift = torch.empty_like(mean)
+        if reducer is not None and reducer.world > 1:
+            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            self.lib.call("ds_partial_sum_f64", self._p(stats), stats.shape[0], self._p(sums), c, self._stream(stats))
+            sums[2 * c] = float(count)
+            reducer.all_reduce_sum_(sums)
+            self.lib.call("ds_bn_stats_from_sums_f32", self._p(sums), 0, self._p(bn.weight.detach()),
+                          self._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM,
+                          self._p(bn.running_mean) if update_running else None,
+                          self._p(bn.running_var) if update_running else None,
+                          self._p(mean), self._p(invstd), self._p(scale), self._p(shift), c, self._stream(stats))
+            return mean, invstd, scale, shift
         self.lib.call("ds_bn_stats_finalize_f32", self._p(stats), stats.shape[0], count,
                       self._p(bn.weight.detach()), self._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM,
                       self._p(bn.running_mean) if update_running else None,
@@ -264,7 +279,7 @@ class Engine:
         return self.tail(a, pw)
 
     def forward_train(self, x: torch.Tensor, pw: PackedWeights, bns: Dict[str, BNParams],
-                      save: bool = True) -> Tuple[torch.Tensor, Optional[SavedForward]]:
+                      save: bool = True, reducer=None) -> Tuple[torch.Tensor, Optional[SavedForward]]:
         """Train-mode forward: each convolution emits its raw output plus per-tile column sums, a
         finalize kernel turns them into batch statistics (and updates the running ones), and one
         elementwise pass normalises + adds the residual + clips (nn.BatchNorm2d.train() semantics)."""
@@ -284,19 +299,19 @@ class Engine:
             h, w, cin = conv_out(h, 5, 2), conv_out(w, 5, 2), c
             count = B * h * w
             name = f"model.bn{i}"
-            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name])
+            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             a = self.bn_apply(z, sc, sh, None, DS_EPI_CLIP)
             if save:
                 saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, (mean, invstd, sc), a
             name = f"model.layer{i}.0.bn1"
             z, st = self.conv(a, sw.l_conv1, B, h, w, c, c, 3, 1, want_stats=True)
-            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name])
+            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             y = self.bn_apply(z, sc, sh, None, DS_EPI_CLIP)
             if save:
                 saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, (mean, invstd, sc), y
             name = f"model.layer{i}.0.bn2"
             z, st = self.conv(y, sw.l_conv2, B, h, w, c, c, 3, 1, want_stats=True)
-            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name])
+            mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             a = self.bn_apply(z, sc, sh, a, DS_EPI_CLIP | DS_EPI_RESIDUAL)
             if save:
                 saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, (mean, invstd, sc), a

@@ -169,6 +169,33 @@ int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act, const floa
                   long long n_pix, int C, void *stream);
 int ds_colsum_f32(const float *x, float *out, int R, int C, void *stream);
 
+/* ---- split forms for data-parallel training (one process per GPU): the caller all-reduces the
+ *      [C][2] float64 sums over RCCL between the two halves, so that N ranks normalise with the
+ *      statistics of the GLOBAL batch exactly like one process would.  count == 0:
+ *      the (all-reduced) pixel count is read from sums[2*C] on the device -- no host sync. ------- */
+int ds_partial_sum_f64(const float *partial, int n_partial, double *sums, int C, void *stream);
+int ds_bn_stats_from_sums_f32(const double *sums, long long count, const float *gamma,
+                              const float *beta, float eps, float momentum, float *running_mean,
+                              float *running_var, float *batch_mean, float *batch_invstd,
+                              float *scale, float *shift, int C, void *stream);
+int ds_bn_bwd_reduce_f32(const float *g1, const float *g2, const float *act, const float *z,
+                         const float *mean, const float *invstd, float *gy, float *partial,
+                         long long n_pix, int C, void *stream);
+int ds_bn_bwd_apply_f32(const double *sums, long long count, const float *gy, const float *z,
+                        const float *mean, const float *invstd, const float *gamma, float *coef,
+                        float *ggamma, float *gbeta, float *gz, long long n_pix, int C, void *stream);
+
+/* row gather and its adjoint (selection of mined candidates and the gradient back to them) */
+int ds_gather_rows_f32(const float *src, const long long *idx, float *dst, int N, int D, void *stream);
+int ds_scatter_add_rows_f32(const float *g, const long long *idx, float *dst, int N, int M, int D,
+                            int accumulate, void *stream);
+
+/* ---- cross-GPU semi-hard negative search over an all-gathered candidate set (north_star; no
+ *      reference counterpart).  out_index[i] in [0,M) or -1; out_dist may be NULL. ---- */
+int ds_mine_semihard_f32(const float *anchor, const float *d_p, const long long *anchor_label,
+                         const float *cand, const long long *cand_label, long long *out_index,
+                         float *out_dist, int N, int M, int D, void *stream);
+
 /* ---- backward of the loss side and the tail (torch autograd of the lines cited above; the
  *      reference obtains them from loss.backward(), train_triplet.py:223,290) ------------------- */
 int ds_pairwise_distance_bwd_f32(const float *x1, const float *x2, const float *d, const float *gd,

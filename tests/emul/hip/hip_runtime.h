@@ -40,6 +40,8 @@ void wave_exchange(float mine, float *all64);          // all64[l] = lane l's `m
 
 static inline void __syncthreads() { emu::syncthreads(); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 typedef void *hipStream_t;
 // scheduling hints are no-ops on the host
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

@@ -1,0 +1,118 @@
+"""Data-parallel logic on CPU: world_size 2 over gloo, kernels on the host emulator.
+
+Asserts the property SURVEY 8(e) asks for: an N-rank step (sharded triplets, all-reduced BatchNorm
+statistics, all-gathered embeddings for cross-rank mining, all-reduced gradients) reproduces the
+single-process step on the global batch -- loss, every parameter gradient, the running statistics and
+the embeddings.  The RCCL path on real GPUs runs the same Python with backend "nccl"."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_STAGES, B_GLOBAL, T = 2, 4, 16
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _problem():
+    _setup_paths()
+    import deepspeaker_oracle as O
+    sd = O.make_state_dict(seed=51, num_classes=4, n_stages=N_STAGES)
+    xs = [O.make_input(seed=52 + i, batch=B_GLOBAL, frames=T) for i in range(3)]
+    c1 = np.array([0, 1, 2, 0], np.int64)
+    c2 = np.array([1, 2, 0, 3], np.int64)
+    return sd, xs, c1, c2
+
+
+def _run(rank, world, mine, reducer):
+    _setup_paths()
+    from emul_util import emul_lib
+    from deepspeaker_pytorch_amd.distributed import triplet_train_step
+    from deepspeaker_pytorch_amd.engine import BNParams, Engine
+    sd, xs, c1, c2 = _problem()
+    eng = Engine(emul_lib())
+    tsd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    pw = eng.pack_weights(tsd, N_STAGES, with_dgrad=True)
+    names = []
+    for i in range(1, N_STAGES + 1):
+        names += [f"model.bn{i}", f"model.layer{i}.0.bn1", f"model.layer{i}.0.bn2"]
+    bns = {n: BNParams(tsd[n + ".weight"], tsd[n + ".bias"], tsd[n + ".running_mean"], tsd[n + ".running_var"])
+           for n in names}
+    n_loc = B_GLOBAL // world
+    sl = slice(rank * n_loc, (rank + 1) * n_loc)
+    xa, xp, xn = (torch.from_numpy(x[sl].copy()) for x in xs)
+    labels = (torch.from_numpy(c1[sl].copy()), torch.from_numpy(c2[sl].copy()))
+    res = triplet_train_step(eng, pw, bns, {n: b.weight for n, b in bns.items()}, xa, xp, xn, 0.1, reducer,
+                             labels=labels, mine=mine)
+    out = {"loss": res.loss.numpy()}
+    for k, v in res.grads.items():
+        out["grad/" + k] = v.numpy()
+    for n, b in bns.items():
+        out["rm/" + n] = b.running_mean.numpy().copy()
+        out["rv/" + n] = b.running_var.numpy().copy()
+    for nm, e in zip("apn", res.embeddings):
+        out["emb_" + nm] = e.numpy()
+    return out
+
+
+def _worker(rank, world, port, mine, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _setup_paths()
+    from deepspeaker_pytorch_amd.distributed import Reducer
+    out = _run(rank, world, mine, Reducer())
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("mine", [False, True])
+def test_two_ranks_reproduce_single_process(tmp_path, mine):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), mine, str(tmp_path)), nprocs=world, join=True)
+    ref = _run(0, 1, mine, None)                      # the whole batch in one process, no collectives
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    n_loc = B_GLOBAL // world
+    for r, got in enumerate(ranks):
+        assert abs(float(got["loss"]) - float(ref["loss"])) <= 1e-5 * max(1.0, abs(float(ref["loss"])))
+        for k, v in ref.items():
+            if k.startswith("grad/"):
+                err = np.linalg.norm(got[k] - v) / max(np.linalg.norm(v), 1e-30)
+                assert err < 5e-5, (r, k, err)
+            elif k.startswith(("rm/", "rv/")):
+                np.testing.assert_allclose(got[k], v, rtol=1e-5, atol=1e-6, err_msg=k)
+            elif k.startswith("emb_"):
+                np.testing.assert_allclose(got[k], v[r * n_loc:(r + 1) * n_loc], rtol=2e-5, atol=2e-5)
+    # both ranks hold identical global gradients
+    for k in ranks[0].files:
+        if k.startswith("grad/"):
+            np.testing.assert_array_equal(ranks[0][k], ranks[1][k])
+    assert float(ref["loss"]) > 0
+
+
+def test_gradient_bucketing_names():
+    _setup_paths()
+    from deepspeaker_pytorch_amd.distributed import needs_allreduce
+    assert needs_allreduce("model.conv3.weight") and needs_allreduce("model.layer2.0.conv1.weight")
+    assert needs_allreduce("model.fc.weight") and needs_allreduce("model.fc.bias")
+    assert not needs_allreduce("model.bn1.weight") and not needs_allreduce("model.layer4.0.bn2.bias")

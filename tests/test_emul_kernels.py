@@ -259,3 +259,34 @@ def test_conv1_wgrad(shape):
     xa, ga = to_aligned(x.astype(np.float32)), nhwc(gy.astype(np.float32))
     lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), ptr(xa), ptr(ga), ptr(ws), ptr(gw), 0, None)
     assert rel_err(gw, gw_ref) < 3e-6
+
+
+@pytest.mark.parametrize("N,M", [(8, 40), (5, 300)])
+def test_mine_semihard(N, M):
+    lib = emul_lib()
+    rs = np.random.RandomState(N)
+    a = to_aligned(rs.randn(N, 512).astype(np.float32))
+    cand = to_aligned(rs.randn(M, 512).astype(np.float32))
+    la = rs.randint(0, 4, N).astype(np.int64)
+    lc = rs.randint(0, 4, M).astype(np.int64)
+    lc[:3] = la[0]
+    d_all = np.sqrt(((a[:, None, :] - cand[None]) ** 2).sum(-1))
+    d_p = np.median(d_all, axis=1).astype(np.float32)            # half the candidates are "semi-hard"
+    d_p[1] = 1e9                                                 # no semi-hard candidate: falls back to closest
+    out = aligned(N, np.int64)
+    outd = aligned(N, fill=np.nan)
+    la_a, lc_a, dp_a = to_aligned(la, np.int64), to_aligned(lc, np.int64), to_aligned(d_p)
+    lib.call("ds_mine_semihard_f32", ptr(a), ptr(dp_a), ptr(la_a), ptr(cand), ptr(lc_a), ptr(out), ptr(outd),
+             N, M, 512, None)
+    ref = O.mine_semihard(a, d_p, la, cand, lc)
+    np.testing.assert_array_equal(out, ref)
+    sel = aligned((N, 512), fill=np.nan)
+    lib.call("ds_gather_rows_f32", ptr(cand), ptr(out), ptr(sel), N, 512, None)
+    np.testing.assert_array_equal(sel, cand[ref])
+    g = to_aligned(rs.randn(N, 512).astype(np.float32))
+    idx = to_aligned(np.array([0, 0, 3, 7, 3][:N] + [1] * max(0, N - 5), np.int64), np.int64)
+    dst = aligned((M, 512), fill=np.nan)
+    lib.call("ds_scatter_add_rows_f32", ptr(g), ptr(idx), ptr(dst), N, M, 512, 0, None)
+    ref_s = np.zeros((M, 512), np.float32)
+    np.add.at(ref_s, idx, g)
+    np.testing.assert_allclose(dst, ref_s, rtol=1e-6, atol=1e-6)
