@@ -92,7 +92,7 @@ def main():
 
     import deepspeaker_oracle as O
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss, get_engine
-    from deepspeaker_pytorch_amd.mining import select_triplets
+    from deepspeaker_pytorch_amd.mining import mine_semihard_negatives, select_triplets
 
     sd_np = O.make_state_dict(seed=0, num_classes=1211)
     model = DeepSpeakerModel(512, 1211)
@@ -104,7 +104,13 @@ def main():
     data = list(data_all.split(BATCH_TRIPLETS))
     loss_fn = TripletMarginLoss(0.1)
     eng = get_engine()
-    gathered = [torch.empty(world * BATCH_TRIPLETS, 512, device=dev) for _ in range(3)] if world > 1 else None
+    # synthetic speaker ids (c1 = anchor/positive speaker, c2 = negative speaker), 64 speakers
+    c1 = torch.randint(0, 64, (BATCH_TRIPLETS,), generator=g)
+    c2 = (c1 + 1 + torch.randint(0, 63, (BATCH_TRIPLETS,), generator=g)) % 64
+    c1, c2 = c1.to(dev), c2.to(dev)
+    labels_loc = torch.cat([c1, c1, c2])
+    emb_glob = torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if world > 1 else None
+    lab_glob = torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if world > 1 else None
 
     def step():
         with torch.no_grad():
@@ -112,12 +118,17 @@ def main():
                 embs = [model(x) for x in data]
             else:                                   # eval mode: per-utterance results do not depend on batching
                 embs = list(model(data_all).split(BATCH_TRIPLETS))
-            if world > 1:
-                for buf, e in zip(gathered, embs):
-                    dist.all_gather_into_tensor(buf, e)
             loss = loss_fn.forward(*embs)
             sel = select_triplets(*embs, margin=0.1)
-        return loss, sel
+            # cross-GPU semi-hard negative search over the all-gathered global batch (BASELINE configs[2]);
+            # at N = 1 the candidate set is the local batch, so per-GPU work has the same shape
+            if world > 1:
+                dist.all_gather_into_tensor(emb_glob, torch.cat(embs))
+                dist.all_gather_into_tensor(lab_glob, labels_loc)
+                mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob)
+            else:
+                mined = mine_semihard_negatives(embs[0], embs[1], c1, torch.cat(embs), labels_loc)
+        return loss, sel, mined
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -161,7 +172,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: full DeepSpeaker ResCNN (64/128/256/512) eval forward + "
-                                   "triplet loss + filter, 256 triplets = 768 x [1,160,64] utterances per GPU per step",
+                                   "triplet loss + filter + semi-hard negative search over the (all-gathered) "
+                                   "batch, 256 triplets = 768 x [1,160,64] utterances per GPU per step",
                        "batch_triplets": BATCH_TRIPLETS, "utterances_per_step_per_gpu": 3 * BATCH_TRIPLETS,
                        "frames": FRAMES, "parallelism": f"dp{world}",
                        "forward_calls_per_step": 3 if args.split_apn else 1,

@@ -31,3 +31,24 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     idx, count, mean_diff = eng.triplet_filter(d_p, d_n, margin)
     k = int(count.item())                      # the one host sync: the reference branches on it (:263)
     return TripletSelection(idx[:k], d_p, d_n, a.shape[0] - k, mean_diff)
+
+
+def mine_semihard_negatives(anchors: torch.Tensor, positives: torch.Tensor, anchor_labels: torch.Tensor,
+                            candidates: torch.Tensor, candidate_labels: torch.Tensor):
+    """Cross-GPU hard-negative search (BASELINE.json north_star; no reference counterpart).
+
+    `candidates` / `candidate_labels` are normally the RCCL all-gather of every rank's embeddings and
+    speaker ids.  For anchor i returns the index j of the candidate with a different speaker that is
+    closest to the anchor among those farther than its positive (semi-hard), else the closest one;
+    ties -> lowest j; -1 if no candidate has another speaker.  Also returns the distances d(a_i, x_j)."""
+    _require_cuda(anchors, "mine_semihard_negatives")
+    eng = get_engine()
+    a, p, c = (t.detach().contiguous() for t in (anchors, positives, candidates))
+    d_p = eng.pairwise_distance(a, p)
+    n, d = a.shape
+    idx = torch.empty(n, dtype=torch.int64, device=a.device)
+    dist_out = torch.empty(n, dtype=torch.float32, device=a.device)
+    eng.lib.call("ds_mine_semihard_f32", eng._p(a), eng._p(d_p), eng._p(anchor_labels.to(torch.int64).contiguous()),
+                 eng._p(c), eng._p(candidate_labels.to(torch.int64).contiguous()), eng._p(idx), eng._p(dist_out),
+                 n, c.shape[0], d, eng._stream(a))
+    return idx, dist_out

@@ -186,7 +186,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
     def forward(ctx, x, model, *params):
         eng = get_engine()
         pw = model._packed(with_dgrad=True)
-        e, saved = eng.forward_train(x, pw, model._bn_params(), save=True)
+        e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer)
         for bn in model._bn_modules():
             bn.num_batches_tracked += 1                             # nn.BatchNorm2d.train() bookkeeping
         ctx.saved_forward = saved
@@ -199,7 +199,8 @@ class _ResCNNTrainFn(torch.autograd.Function):
     def backward(ctx, ge):
         from .backward import backward_train
         bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
-        grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float())
+        grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
+                               reducer=ctx.model._reducer)
         ctx.saved_forward = None
         return (None, None) + tuple(grads.get(n) for n in ctx.param_names)
 
@@ -224,6 +225,7 @@ class DeepSpeakerModel(nn.Module):
         f_bins = 64 >> n_stages
         self.model.fc = nn.Linear(c_last * f_bins, self.embedding_size)       # 512*4 (model.py:164)
         self.model.classifier = nn.Linear(self.embedding_size, num_classes)   # model.py:167
+        self._reducer = None          # set by enable_data_parallel()
         self._pack_cache = None
         self._pack_key = None
         self._fold_cache = None
@@ -277,6 +279,24 @@ class DeepSpeakerModel(nn.Module):
             self._fold_key = key
         return self._fold_cache
 
+    # ---- data-parallel training (new capability; the reference is single-GPU) ----
+    def enable_data_parallel(self, process_group=None):
+        """One process per GPU (torch.distributed backend "nccl" = RCCL).  From now on train-mode forwards
+        and their backward use global-batch BatchNorm statistics (all-reduced over the ranks); call
+        `allreduce_gradients()` after `loss.backward()` and scale the local loss by 1/world_size so that
+        the step equals the single-process step on the concatenated batch."""
+        from .distributed import Reducer
+        self._reducer = Reducer(process_group)
+        return self._reducer
+
+    def allreduce_gradients(self):
+        """Sum the filter / fc gradients over the ranks (BatchNorm affine gradients are already global)."""
+        from .distributed import allreduce_gradients, needs_allreduce
+        if self._reducer is None:
+            raise RuntimeError("call enable_data_parallel() first")
+        grads = {n: p.grad for n, p in self.named_parameters() if p.grad is not None and needs_allreduce(n)}
+        allreduce_gradients(grads, self._reducer)
+
     # ---- reference surface ----
     def l2_norm(self, input):
         """reference model.py:172-183: x / sqrt(sum x^2 + 1e-10) (no alpha)."""
@@ -298,7 +318,8 @@ class DeepSpeakerModel(nn.Module):
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 self.features = _ResCNNTrainFn.apply(x, self, *params)
             else:
-                e, _ = get_engine().forward_train(x, self._packed(), self._bn_params(), save=False)
+                e, _ = get_engine().forward_train(x, self._packed(), self._bn_params(), save=False,
+                                                  reducer=self._reducer)
                 for bn in self._bn_modules():
                     bn.num_batches_tracked += 1
                 self.features = e

@@ -320,3 +320,45 @@ def test_conv_backward_kernels_vs_oracle(dev, case):
     gw = _wgrad(eng, shp, xh, gyh, (co, ci, k, k))
     assert rel_err(gx.cpu().numpy().transpose(0, 3, 1, 2), gx_ref) < 1e-5
     assert rel_err(gw.cpu().numpy(), gw_ref) < 1e-5
+
+
+def test_mining_kernel_vs_oracle(dev):
+    from deepspeaker_pytorch_amd.mining import mine_semihard_negatives
+    rs = np.random.RandomState(9)
+    N, M = 64, 1536
+    a = rs.randn(N, 512).astype(np.float32)
+    p = a + rs.randn(N, 512).astype(np.float32) * 0.9
+    cand = rs.randn(M, 512).astype(np.float32)
+    la, lc = rs.randint(0, 8, N).astype(np.int64), rs.randint(0, 8, M).astype(np.int64)
+    idx, dd = mine_semihard_negatives(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(la).cuda(),
+                                      torch.from_numpy(cand).cuda(), torch.from_numpy(lc).cuda())
+    d_p = O.pairwise_distance(a, p)
+    ref = O.mine_semihard(a, d_p, la, cand, lc)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    ref_d = np.sqrt(((a - cand[ref]) ** 2).sum(1) + 1e-4 / 512)
+    assert rel_err(dd.cpu().numpy(), ref_d) < 1e-5
+
+
+def test_data_parallel_world1_nccl(dev):
+    """The RCCL code path with a single rank: enable_data_parallel must not change the step."""
+    import torch.distributed as dist
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=4)).cuda() for i in range(3)]
+    grads = []
+    for dp in (False, True):
+        m = build_model(sd).train()
+        if dp:
+            m.enable_data_parallel()
+        loss = TripletMarginLoss(0.1).forward(m(xs[0]), m(xs[1]), m(xs[2]))
+        loss.backward()
+        if dp:
+            m.allreduce_gradients()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        assert rel_err(grads[1][n].cpu().numpy(), grads[0][n].cpu().numpy()) < 1e-5, n
+    dist.destroy_process_group()
