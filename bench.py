@@ -31,6 +31,7 @@ BATCH_TRIPLETS = 256
 FRAMES = 160
 FWD_FLOPS_PER_EMB = 2 * 1153335296
 F32_MFMA_PEAK_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0              # MI355X_MICROARCH.md: bf16 MFMA dense peak
 
 
 def cpu_baseline(sd_np, budget_s=10.0):
@@ -72,6 +73,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the stage convolutions: exact-f32 MFMA (parity path, default), "
+                         "split-operand bf16 MFMA (f32-class accuracy) or plain bf16 (speed mode)")
     ap.add_argument("--split-apn", action="store_true",
                     help="three separate 256-utterance forwards (the reference's call pattern, "
                          "train_triplet.py:215) instead of one 768-utterance forward")
@@ -95,7 +99,7 @@ def main():
     from deepspeaker_pytorch_amd.mining import mine_semihard_negatives, select_triplets
 
     sd_np = O.make_state_dict(seed=0, num_classes=1211)
-    model = DeepSpeakerModel(512, 1211)
+    model = DeepSpeakerModel(512, 1211, precision=args.precision)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
     model = model.to(dev).eval()
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -165,11 +169,18 @@ def main():
             d[1] += e0.elapsed_time(e1)
             d[2] += 1
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else BF16_MFMA_PEAK_TFLOPS
+        kname = {"f32": "conv_mfma_f32_kernel (implicit-GEMM 3x3/5x5, all tile shapes)",
+                 "bf16x3": "conv_mfma_bf16_kernel<X3=true> (3 bf16 MFMAs per product: hi*hi + hi*lo + lo*hi)",
+                 "bf16": "conv_mfma_bf16_kernel<X3=false>"}[args.precision]
+        arith = {"f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations",
+                 "bf16x3": "split-operand bf16 MFMA (v_mfma_f32_32x32x16_bf16 x3, f32 accumulate), f32 activations",
+                 "bf16": "bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, f32 accumulate), f32 activations"}[args.precision]
         out = {
             "metric": "embeddings/sec (64-fbank x 160-frame utterances)",
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: full DeepSpeaker ResCNN (64/128/256/512) eval forward + "
                                    "triplet loss + filter + semi-hard negative search over the (all-gathered) "
@@ -177,10 +188,10 @@ def main():
                        "batch_triplets": BATCH_TRIPLETS, "utterances_per_step_per_gpu": 3 * BATCH_TRIPLETS,
                        "frames": FRAMES, "parallelism": f"dp{world}",
                        "forward_calls_per_step": 3 if args.split_apn else 1,
-                       "arith": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations"},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel (implicit-GEMM 3x3/5x5/1x1, both tile shapes)",
-                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                       "arith": arith},
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
                          "launches": len(prof), "avg_launch_ms": round(ms / max(len(prof), 1), 4),
                          "conv_ms_per_step": round(ms / args.steps, 3),
                          "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}},

@@ -46,6 +46,9 @@ _SIGNATURES = {
     "ds_conv5x5s2_c1_stats_rows": (c_int, [c_int, c_int]),
     "ds_conv5x5s2_c1_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv_fwd_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "ds_pack_conv_weight_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_conv_bf16_stats_rows": (c_int, [POINTER(ConvShape), c_int]),
+    "ds_conv_fwd_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_avgpool_time_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_l2norm_scale_f32": (c_int, [_P, _P, c_int, c_int, c_float, c_float, _P]),
     "ds_fc_workspace_floats": (c_longlong, [c_int, c_int, c_int]),

@@ -1,0 +1,396 @@
+// conv_mfma_bf16.hip -- implicit-GEMM convolution on the gfx950 bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16, f32 accumulate), the throughput variants of conv_mfma_f32.hip for the
+// forward convolutions of reference model.py:69,73,192,197,202 (+ the same fused BatchNorm-affine /
+// residual / clipped-ReLU epilogue, model.py:70-80,188-205).
+//
+//   X3 = false ("bf16"):   one MFMA per k-step, operands rounded to bf16.  ~8 bits of mantissa: the
+//                          embedding drifts ~6e-3 from the reference -- a speed mode.
+//   X3 = true  ("bf16x3"): every f32 operand is split x = hi + lo (two bf16) and the product is taken
+//                          as hi*hi + hi*lo + lo*hi on the matrix cores -- f32-class accuracy (~1e-5
+//                          relative per term) at up to 1/3 of the bf16 peak, i.e. > 5x the f32-MFMA rate.
+//
+// Activations stay f32 channels-last in HBM; they are converted (and split) while being staged into
+// LDS, so the kernel is a drop-in for ds_conv_fwd_f32.  Tiling / segment / halo logic is the same as the
+// f32 kernel's (see that file); differences: 16 input channels per chunk (= one MFMA k-step per tap),
+// LDS pixel records of 16 bf16 (+16 B pad, conflict-free ds_read_b128), no register prefetch of the
+// activation tile (two workgroups per CU overlap staging with the other's matrix work).
+#include <ds_device.h>
+#include "ds_common.h"
+
+namespace {
+
+constexpr int CKB = 16;             // input channels per chunk = K of one bf16 MFMA
+constexpr int PSB = 48;             // bytes per staged pixel record: 16 bf16 + 16 B pad
+
+struct ConvKB {
+    const float *x;
+    const __bf16 *w_hi, *w_lo;      // packed [Cin/16][tap][Cout][16]
+    float *y;
+    const float *scale, *shift, *res;
+    float *stats;
+    int H, W, Cin;
+    int Hr, Wc, Ho, Wo, Cout;
+    int IS;
+    int dh_min, dw_min;
+    int rows_in, cols_in, seg_pix;
+    int RT, NI, segs_per_img, n_segs;
+    int n_ntiles;
+    int flags;
+};
+
+template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3>
+__global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const ConvKB p) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MT = MSUB * WM * 32;
+    constexpr int NTILE = NSUB * WN * 32;
+    constexpr int NT = KS * KS;
+    constexpr int RING = (KS == 3) ? (MSUB <= 2 ? 9 : 3) : (KS == 5 ? 5 : 1);
+
+    char *lds = (char *)ds_dynamic_lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile_n = blockIdx.x % p.n_ntiles;
+    const int tile_m = blockIdx.x / p.n_ntiles;
+    const int seg0 = tile_m * p.NI;
+    const int pix_per_seg = p.RT * p.Wc;
+    const int tile_pix = p.NI * p.seg_pix;
+    char *lds_hi = lds;                                        // [tile_pix][PSB]
+    char *lds_lo = lds + (X3 ? tile_pix * PSB : 0);
+    int *out_off = (int *)(lds + (X3 ? 2 : 1) * tile_pix * PSB);   // [MT]
+    int *pix_goff = out_off + MT;                              // [tile_pix] global float offset or -1
+    float *red = (float *)(pix_goff + tile_pix);               // [WM][NTILE][2]
+
+    for (int m = tid; m < MT; m += NTHR) {
+        const int seg = m / pix_per_seg;
+        const int rem = m - seg * pix_per_seg;
+        const int r = rem / p.Wc, c = rem - r * p.Wc;
+        const int gseg = seg0 + seg;
+        int off = -1;
+        if (seg < p.NI && gseg < p.n_segs) {
+            const int b = gseg / p.segs_per_img;
+            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
+            if (rr < p.Hr) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+        }
+        out_off[m] = off;
+    }
+    for (int pix = tid; pix < tile_pix; pix += NTHR) {
+        const int seg = pix / p.seg_pix;
+        const int pr = pix - seg * p.seg_pix;
+        const int rr = pr / p.cols_in, cc = pr - rr * p.cols_in;
+        const int gseg = seg0 + seg;
+        int g = -1;
+        if (gseg < p.n_segs) {
+            const int b = gseg / p.segs_per_img;
+            const int r0 = (gseg - b * p.segs_per_img) * p.RT;
+            const int h = p.IS * r0 + p.dh_min + rr, w = p.dw_min + cc;
+            if (h >= 0 && h < p.H && w >= 0 && w < p.W) g = ((b * p.H + h) * p.W + w) * p.Cin;
+        }
+        pix_goff[pix] = g;
+    }
+
+    int a_off[MSUB];                                           // byte offset of this lane's fragment
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int m = (wm * MSUB + ms) * 32 + l31;
+        const int seg = m / pix_per_seg;
+        const int rem = m - seg * pix_per_seg;
+        const int r = rem / p.Wc, c = rem - r * p.Wc;
+        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.cols_in + p.IS * c : 0;
+        a_off[ms] = pix * PSB + 16 * lhi;
+    }
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+
+    const int n_chunks = p.Cin / CKB;
+    const int n_base = tile_n * NTILE + wn * NSUB * 32;
+    const size_t lane_w = ((size_t)(n_base + l31) * CKB + 8 * lhi);      // in bf16 elements
+    const size_t w_tap_stride = (size_t)p.Cout * CKB;
+    const int last_tap = n_chunks * NT - 1;
+
+    bf16x8 bq_hi[RING][NSUB], bq_lo[X3 ? RING : 1][NSUB];
+#pragma unroll
+    for (int d = 0; d < RING; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+            const int g = d < last_tap ? d : last_tap;
+            const size_t o = lane_w + (size_t)g * w_tap_stride + (size_t)ns * 32 * CKB;
+            bq_hi[d][ns] = *(const bf16x8 *)(p.w_hi + o);
+            if constexpr (X3) bq_lo[d][ns] = *(const bf16x8 *)(p.w_lo + o);
+        }
+
+    const int n_items = tile_pix * (CKB / 4);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        __syncthreads();                       // previous chunk's fragment reads (and the tables) are done
+        // ---- stage + convert: f32 pixels -> bf16 hi (+ lo) records ----
+        for (int idx = tid; idx < n_items; idx += NTHR) {
+            const int pix = idx >> 2, q = idx & 3;
+            const int g = pix_goff[pix];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (g >= 0) v = *(const f32x4 *)(p.x + g + chunk * CKB + q * 4);
+            bf16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
+            *(bf16x4 *)(lds_hi + pix * PSB + q * 8) = h;
+            if constexpr (X3) {
+                bf16x4 l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) l[j] = (__bf16)(v[j] - (float)h[j]);
+                *(bf16x4 *)(lds_lo + pix * PSB + q * 8) = l;
+            }
+        }
+        __syncthreads();
+        const int g0 = chunk * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int slot = t % RING;
+            if (t > 0) {                       // refill the slot the previous tap consumed
+                int gn = g0 + t - 1 + RING;
+                gn = gn < last_tap ? gn : last_tap;
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) {
+                    const size_t o = lane_w + (size_t)gn * w_tap_stride + (size_t)ns * 32 * CKB;
+                    bq_hi[(t - 1) % RING][ns] = *(const bf16x8 *)(p.w_hi + o);
+                    if constexpr (X3) bq_lo[(t - 1) % RING][ns] = *(const bf16x8 *)(p.w_lo + o);
+                }
+            }
+            const int toff = ((t / KS) * p.cols_in + (t % KS)) * PSB;
+            bf16x8 a_hi[MSUB], a_lo[X3 ? MSUB : 1];
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms) {
+                a_hi[ms] = *(const bf16x8 *)(lds_hi + a_off[ms] + toff);
+                if constexpr (X3) a_lo[ms] = *(const bf16x8 *)(lds_lo + a_off[ms] + toff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) {
+                    if constexpr (X3) {        // small cross terms first, the leading term last
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_lo[ms], bq_hi[slot][ns], acc[ms][ns]);
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[ms], bq_lo[slot][ns], acc[ms][ns]);
+                    }
+                    acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[ms], bq_hi[slot][ns], acc[ms][ns]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            int gn = g0 + NT - 1 + RING;
+            gn = gn < last_tap ? gn : last_tap;
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) {
+                const size_t o = lane_w + (size_t)gn * w_tap_stride + (size_t)ns * 32 * CKB;
+                bq_hi[(NT - 1) % RING][ns] = *(const bf16x8 *)(p.w_hi + o);
+                if constexpr (X3) bq_lo[(NT - 1) % RING][ns] = *(const bf16x8 *)(p.w_lo + o);
+            }
+        }
+    }
+
+    // ---- epilogue (identical to the f32 kernel's) ----
+    const int flags = p.flags;
+    float sc[NSUB], sh[NSUB], s1[NSUB], s2[NSUB];
+    int col[NSUB];
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+        col[ns] = n_base + ns * 32 + l31;
+        sc[ns] = (flags & DS_EPI_AFFINE) ? p.scale[col[ns]] : 1.0f;
+        sh[ns] = (flags & DS_EPI_AFFINE) ? p.shift[col[ns]] : 0.0f;
+        s1[ns] = 0.0f;
+        s2[ns] = 0.0f;
+    }
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int off = out_off[row];
+            if (off >= 0) {
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) {
+                    float v = acc[ms][ns][r];
+                    s1[ns] += v;
+                    s2[ns] += v * v;
+                    if (flags & DS_EPI_AFFINE) v = v * sc[ns] + sh[ns];
+                    if (flags & DS_EPI_RESIDUAL) v += p.res[(size_t)off + col[ns]];
+                    if (flags & DS_EPI_CLIP) v = fminf(fmaxf(v, 0.0f), 20.0f);
+                    p.y[(size_t)off + col[ns]] = v;
+                }
+            }
+        }
+    }
+    if (flags & DS_EPI_STATS) {
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+            s1[ns] += ds_shfl_xor(s1[ns], 32);
+            s2[ns] += ds_shfl_xor(s2[ns], 32);
+            if (lhi == 0) {
+                const int c = wn * NSUB * 32 + ns * 32 + l31;
+                red[(wm * NTILE + c) * 2 + 0] = s1[ns];
+                red[(wm * NTILE + c) * 2 + 1] = s2[ns];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < NTILE; c += NTHR) {
+            float a1 = 0.0f, a2 = 0.0f;
+            for (int k = 0; k < WM; ++k) {
+                a1 += red[(k * NTILE + c) * 2 + 0];
+                a2 += red[(k * NTILE + c) * 2 + 1];
+            }
+            float *dst = p.stats + ((size_t)tile_m * p.Cout + tile_n * NTILE + c) * 2;
+            dst[0] = a1;
+            dst[1] = a2;
+        }
+    }
+}
+
+// OIHW f32 -> [Cin/16][tap][Cout][16] bf16 hi (+ lo = bf16(w - hi))
+__global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float *w, __bf16 *hi, __bf16 *lo, int Cout,
+                                                                    int Cin, int KS) {
+    const int T = KS * KS;
+    const long long n = (long long)Cout * Cin * T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int kk = (int)(i & 15);
+        long long r = i >> 4;
+        const int nn = (int)(r % Cout);
+        r /= Cout;
+        const int t = (int)(r % T);
+        const int kc = (int)(r / T);
+        const int ci = kc * 16 + kk;
+        const int kh = t / KS, kw = t - kh * KS;
+        const float v = w[(((size_t)nn * Cin + ci) * KS + kh) * KS + kw];
+        const __bf16 h = (__bf16)v;
+        hi[i] = h;
+        if (lo) lo[i] = (__bf16)(v - (float)h);
+    }
+}
+
+// ---- host-side plan (same objective as the f32 planner; limits: 64 KiB LDS, 2 workgroups per CU) ----
+struct TileCfgB { int MT, NTILE, WM, wg_per_cu; };
+constexpr int kNumCfgB = 3;
+constexpr TileCfgB kCfgB[kNumCfgB] = {
+    {128, 64, 2, 3},      // <KS,2,1,2,2>
+    {160, 128, 1, 2},     // <KS,5,1,1,4>
+    {256, 64, 2, 2},      // <KS,4,1,2,2>
+};
+
+struct PlanB {
+    int cfg, grid, n_mtiles;
+    size_t lds_bytes;
+    ConvKB k;
+};
+
+static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
+    DS_REQUIRE(s != nullptr, DS_ERR_NULL);
+    DS_REQUIRE(s->B > 0 && s->H > 0 && s->W > 0 && s->Cin > 0 && s->Cout > 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(s->KS == 3 || s->KS == 5, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(s->stride == 1 || s->stride == 2, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(s->Cin % CKB == 0 && s->Cout % 64 == 0, DS_ERR_BAD_SHAPE);
+    const int pad = s->KS / 2;
+    const int Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
+    const int Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
+    DS_REQUIRE(Ho > 0 && Wo > 0 && Wo <= 128, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 31), DS_ERR_BAD_SHAPE);
+    const int IS = s->stride;
+    double best = -1.0;
+    int bc = -1, brt = 0, bni = 0;
+    for (int c = 0; c < kNumCfgB; ++c) {
+        const TileCfgB &cf = kCfgB[c];
+        if (s->Cout % cf.NTILE) continue;
+        for (int rt = 1; rt <= Ho; ++rt) {
+            if ((long long)rt * Wo > cf.MT) break;
+            const int segs_per_img = ds_ceil_div(Ho, rt);
+            const long long n_segs = (long long)s->B * segs_per_img;
+            int ni = cf.MT / (rt * Wo);
+            if (ni > n_segs) ni = (int)n_segs;
+            const int rows_in = IS * (rt - 1) + s->KS, cols_in = IS * (Wo - 1) + s->KS;
+            auto lds_of = [&](int n) {
+                const size_t tp = (size_t)n * rows_in * cols_in;
+                return tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
+            };
+            while (ni > 1 && lds_of(ni) > 64 * 1024) --ni;
+            if (lds_of(ni) > 64 * 1024) continue;
+            const long long n_mt = ds_ceil_div_ll(n_segs, ni);
+            double eff = (double)s->B * Ho * Wo / ((double)n_mt * cf.MT);
+            const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * cf.wg_per_cu;
+            if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
+            else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
+            eff += 1e-9 * rt + 1e-6 * (c == 1 ? 2 : (c == 2 ? 1 : 0));
+            if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; }
+        }
+    }
+    if (bc < 0) return DS_ERR_UNSUPPORTED;
+    const TileCfgB &cf = kCfgB[bc];
+    ConvKB &k = pl.k;
+    k.H = s->H; k.W = s->W; k.Cin = s->Cin;
+    k.Hr = Ho; k.Wc = Wo; k.Ho = Ho; k.Wo = Wo; k.Cout = s->Cout;
+    k.IS = IS; k.dh_min = -pad; k.dw_min = -pad;
+    k.RT = brt; k.NI = bni;
+    k.segs_per_img = ds_ceil_div(Ho, brt);
+    k.n_segs = s->B * k.segs_per_img;
+    k.rows_in = IS * (brt - 1) + s->KS;
+    k.cols_in = IS * (Wo - 1) + s->KS;
+    k.seg_pix = k.rows_in * k.cols_in;
+    k.n_ntiles = s->Cout / cf.NTILE;
+    pl.cfg = bc;
+    pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
+    pl.grid = pl.n_mtiles * k.n_ntiles;
+    const size_t tp = (size_t)k.NI * k.seg_pix;
+    pl.lds_bytes = tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
+    return DS_OK;
+}
+
+template <int KS, bool X3>
+static void launch_b(const PlanB &pl, void *stream) {
+    if (pl.cfg == 0)
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, 2, 1, 2, 2, X3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    else if (pl.cfg == 1)
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, 5, 1, 1, 4, X3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    else
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, 4, 1, 2, 2, X3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+}
+
+}  // namespace
+
+extern "C" int ds_pack_conv_weight_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin, int KS,
+                                        void *stream) {
+    DS_REQUIRE(w_oihw && w_hi, DS_ERR_NULL);
+    DS_REQUIRE(Cout > 0 && Cin > 0 && (KS == 3 || KS == 5) && (Cin % CKB) == 0, DS_ERR_BAD_SHAPE);
+    const long long n = (long long)Cout * Cin * KS * KS;
+    long long g = (n + 255) / 256;
+    DS_LAUNCH(pack_conv_weight_bf16_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w_oihw, (__bf16 *)w_hi,
+              (__bf16 *)w_lo, Cout, Cin, KS);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3) {
+    PlanB pl;
+    int rc = plan_bf16(pl, s, x3 != 0);
+    return rc == DS_OK ? pl.n_mtiles : rc;
+}
+
+extern "C" int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, const void *w_lo,
+                                const float *scale, const float *shift, const float *residual, float *y,
+                                float *stats_partial, int flags, void *stream) {
+    DS_REQUIRE(x && w_hi && y, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_AFFINE) || (scale && shift), DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_RESIDUAL) || residual, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_STATS) || stats_partial, DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(w_hi) && DS_ALIGNED16(y) && DS_ALIGNED16(w_lo), DS_ERR_ALIGNMENT);
+    const bool x3 = w_lo != nullptr;
+    PlanB pl;
+    int rc = plan_bf16(pl, s, x3);
+    if (rc != DS_OK) return rc;
+    pl.k.x = x; pl.k.w_hi = (const __bf16 *)w_hi; pl.k.w_lo = (const __bf16 *)w_lo; pl.k.y = y;
+    pl.k.scale = scale; pl.k.shift = shift; pl.k.res = residual; pl.k.stats = stats_partial;
+    pl.k.flags = flags;
+    if (s->KS == 3) { if (x3) launch_b<3, true>(pl, stream); else launch_b<3, false>(pl, stream); }
+    else            { if (x3) launch_b<5, true>(pl, stream); else launch_b<5, false>(pl, stream); }
+    return ds_last_launch_error();
+}

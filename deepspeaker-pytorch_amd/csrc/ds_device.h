@@ -15,6 +15,15 @@ __device__ __forceinline__ f32x16 ds_mfma_32x32x2_f32(float a, float b, f32x16 c
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_32x32x16_bf16: D = A(32x16) * B(16x32) + C, bf16 inputs, f32 accumulate.  Lane l supplies
+// 8 k-values of row (A) / column (B) l&31, in k-slot group l>>5; the kernels give slot (g, j) the same
+// channel 8g+j on both operands, which is all the contraction needs.  C/D layout as above.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 ds_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // cross-lane exchange inside one 64-lane wavefront
 __device__ __forceinline__ float ds_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float ds_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }

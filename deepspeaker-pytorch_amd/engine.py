@@ -44,6 +44,10 @@ class StageWeights:
     conv_dgrad: Optional[torch.Tensor] = None
     l_conv1_dgrad: Optional[torch.Tensor] = None
     l_conv2_dgrad: Optional[torch.Tensor] = None
+    # bf16 matrix-core banks: (hi, lo) pairs of [Cin/16][tap][Cout][16] bf16 (precision "bf16x3" / "bf16")
+    conv_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+    l_conv1_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+    l_conv2_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
 
 
 @dataclass
@@ -92,8 +96,15 @@ class Engine:
                              f"contiguous={t.is_contiguous()}")
 
     # ------------------------------------------------------------------ weights
+    def _pack_bf16(self, w: torch.Tensor, ks: int):
+        hi = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+        lo = torch.empty_like(hi)
+        self.lib.call("ds_pack_conv_weight_bf16", self._p(w), self._p(hi), self._p(lo), w.shape[0], w.shape[1], ks,
+                      self._stream(w))
+        return hi, lo
+
     def pack_weights(self, sd: Dict[str, torch.Tensor], n_stages: int = 4,
-                     with_dgrad: bool = False) -> PackedWeights:
+                     with_dgrad: bool = False, with_bf16: bool = False) -> PackedWeights:
         """OIHW / [out,in] parameters (reference shapes) -> kernel layouts."""
         lib = self.lib
         stages = []
@@ -116,6 +127,11 @@ class Engine:
                 lib.call("ds_pack_conv_weight_f32", self._p(wl), self._p(pl), co, co, 3, 0, st)
                 packs.append(pl)
             sw = StageWeights(pc, packs[0], packs[1])
+            if with_bf16:
+                if i > 1:
+                    sw.conv_bf16 = self._pack_bf16(w, 5)
+                sw.l_conv1_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3)
+                sw.l_conv2_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3)
             if with_dgrad:
                 if i > 1:       # 5x5 stride 2: four parity-class banks (ds_conv_dgrad_f32)
                     sw.conv_dgrad = torch.empty_like(pc)
@@ -176,6 +192,25 @@ class Engine:
             self.profile.append((f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}",
                                  2.0 * B * ho * wo * cout * cin * ks * ks, ev0, ev1))
         return y, stats
+
+    def conv_bf16(self, x: torch.Tensor, w_pair, x3: bool, B: int, H: int, W: int, cin: int, cout: int, ks: int,
+                  stride: int, scale=None, shift=None, residual=None, flags: int = 0):
+        """Forward convolution on the bf16 matrix cores; x3 = hi/lo split operands (f32-class accuracy)."""
+        shp = ConvShape(B, H, W, cin, cout, ks, stride)
+        ho, wo = conv_out(H, ks, stride), conv_out(W, ks, stride)
+        y = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=x.device)
+        prof = self.profile is not None and x.is_cuda
+        if prof:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        self.lib.call("ds_conv_fwd_bf16", ctypes.byref(shp), self._p(x), self._p(w_pair[0]),
+                      self._p(w_pair[1]) if x3 else None, self._p(scale), self._p(shift), self._p(residual),
+                      self._p(y), None, flags, self._stream(x))
+        if prof:
+            ev1.record()
+            self.profile.append((f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}",
+                                 2.0 * B * ho * wo * cout * cin * ks * ks, ev0, ev1))
+        return y
 
     def conv1(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, scale=None, shift=None,
               flags: int = 0, want_stats: bool = False):
@@ -248,9 +283,18 @@ class Engine:
 
     # ------------------------------------------------------------------ forward passes
     def forward_eval(self, x: torch.Tensor, pw: PackedWeights, folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]],
-                     taps: Optional[dict] = None) -> torch.Tensor:
+                     taps: Optional[dict] = None, precision: str = "f32") -> torch.Tensor:
         """Eval-mode forward: BatchNorm (running statistics), residual add and clipped ReLU all live in
-        the convolution epilogues -- 3 launches per stage, no intermediate normalisation pass."""
+        the convolution epilogues -- 3 launches per stage, no intermediate normalisation pass.
+
+        precision: "f32" exact-f32 MFMA (the parity path); "bf16x3" split-operand bf16 MFMA (f32-class
+        accuracy); "bf16" plain bf16 operands (speed mode).  conv1, fc and the tail are f32 in all modes."""
+        if precision not in ("f32", "bf16x3", "bf16"):
+            raise ValueError(f"unknown precision {precision!r}")
+        lowp = precision != "f32"
+        x3 = precision == "bf16x3"
+        if lowp and pw.stages[0].l_conv1_bf16 is None:
+            raise ValueError("pack_weights(..., with_bf16=True) is required for the bf16 precisions")
         self._check(x, "input")
         B, one, T, F = x.shape
         if one != 1:
@@ -263,17 +307,25 @@ class Engine:
             sc, sh = folded[f"model.bn{i}"]
             if i == 1:
                 a, _ = self.conv1(a, sw.conv, B, h, w, sc, sh, AC)
+            elif lowp:
+                a = self.conv_bf16(a, sw.conv_bf16, x3, B, h, w, cin, c, 5, 2, sc, sh, None, AC)
             else:
                 a, _ = self.conv(a, sw.conv, B, h, w, cin, c, 5, 2, sc, sh, None, AC)
             h, w, cin = conv_out(h, 5, 2), conv_out(w, 5, 2), c
             if taps is not None:
                 taps[f"stage{i}.a"] = a
             sc, sh = folded[f"model.layer{i}.0.bn1"]
-            y, _ = self.conv(a, sw.l_conv1, B, h, w, c, c, 3, 1, sc, sh, None, AC)
+            if lowp:
+                y = self.conv_bf16(a, sw.l_conv1_bf16, x3, B, h, w, c, c, 3, 1, sc, sh, None, AC)
+            else:
+                y, _ = self.conv(a, sw.l_conv1, B, h, w, c, c, 3, 1, sc, sh, None, AC)
             if taps is not None:
                 taps[f"stage{i}.b"] = y
             sc, sh = folded[f"model.layer{i}.0.bn2"]
-            a, _ = self.conv(y, sw.l_conv2, B, h, w, c, c, 3, 1, sc, sh, a, AC | DS_EPI_RESIDUAL)
+            if lowp:
+                a = self.conv_bf16(y, sw.l_conv2_bf16, x3, B, h, w, c, c, 3, 1, sc, sh, a, AC | DS_EPI_RESIDUAL)
+            else:
+                a, _ = self.conv(y, sw.l_conv2, B, h, w, c, c, 3, 1, sc, sh, a, AC | DS_EPI_RESIDUAL)
             if taps is not None:
                 taps[f"stage{i}.c"] = a
         return self.tail(a, pw)

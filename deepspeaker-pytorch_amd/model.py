@@ -213,8 +213,11 @@ class DeepSpeakerModel(nn.Module):
     `.forward_classifier(x)`; `.l2_norm(t)`.  `state_dict()` has the reference's 76 keys.
     """
 
-    def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4):
+    def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4, precision: str = "f32"):
         super().__init__()
+        # arithmetic of the eval-mode convolutions: "f32" (exact-f32 MFMA, the parity path), "bf16x3"
+        # (split-operand bf16 MFMA, f32-class accuracy) or "bf16" (speed mode); training is always f32
+        self.precision = precision
         if feature_dim != 64:
             # the reference's feature_dim == 40 branch is dead code that cannot run (SURVEY Appendix C)
             raise NotImplementedError("only feature_dim=64 is functional in the reference and implemented here")
@@ -261,11 +264,12 @@ class DeepSpeakerModel(nn.Module):
         sd["model.fc.bias"] = self.model.fc.bias
         return sd
 
-    def _packed(self, with_dgrad: bool = False):
+    def _packed(self, with_dgrad: bool = False, with_bf16: bool = False):
         sd = self._conv_fc_tensors()
-        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (with_dgrad,)
+        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (with_dgrad, with_bf16)
         if self._pack_key != key:
-            self._pack_cache = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad)
+            self._pack_cache = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad,
+                                                         with_bf16=with_bf16)
             self._pack_key = key
         return self._pack_cache
 
@@ -324,7 +328,9 @@ class DeepSpeakerModel(nn.Module):
                     bn.num_batches_tracked += 1
                 self.features = e
         else:
-            self.features = get_engine().forward_eval(x, self._packed(), self._folded())
+            lowp = self.precision != "f32"
+            self.features = get_engine().forward_eval(x, self._packed(with_bf16=lowp), self._folded(),
+                                                      precision=self.precision)
         return self.features
 
     def forward_classifier(self, x):

@@ -113,6 +113,18 @@ int ds_conv_fwd_f32(const ds_conv_shape *s, const float *x, const float *w_packe
                     const float *scale, const float *shift, const float *residual, float *y,
                     float *stats_partial, int flags, void *stream);
 
+/* ---- bf16 matrix-core variants of the forward convolutions (v_mfma_f32_32x32x16_bf16, f32 accumulate;
+ *      same epilogue flags, f32 channels-last activations in and out -> drop-in for ds_conv_fwd_f32).
+ *      w_lo == NULL: plain bf16 operands (speed mode, ~6e-3 embedding drift on this network);
+ *      w_lo != NULL: "bf16x3" -- both operands split hi+lo, product = hi*hi + hi*lo + lo*hi: f32-class
+ *      accuracy at up to 1/3 of the bf16 peak.  KS in {3, 5}; Cin % 16 == 0. ----------------------- */
+int ds_pack_conv_weight_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin, int KS,
+                             void *stream);             /* -> [Cin/16][KS*KS][Cout][16] bf16 (x2) */
+int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3);
+int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, const void *w_lo,
+                     const float *scale, const float *shift, const float *residual, float *y,
+                     float *stats_partial, int flags, void *stream);
+
 /* ---- tail: temporal average pool, L2 normalisation --------------------------------------------- */
 /* x [B,Hr,Wc,C] -> pooled [B, Wc*C] (index f*C + c), mean over Hr  (model.py:111,207-208) */
 int ds_avgpool_time_f32(const float *x, float *pooled, int B, int Hr, int Wc, int C, void *stream);

@@ -24,6 +24,30 @@ static inline f32x16 ds_mfma_32x32x2_f32(float a, float b, f32x16 c) {
     return c;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x16_bf16 model: lane l = i + 32 g holds k-slots (g, 0..7) of row/column i; products of
+// bf16 values are exact in f32, the 16-term sum is accumulated in double and rounded once into the f32
+// accumulator (the hardware's internal summation order is not architecturally specified).
+static inline f32x16 ds_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    float A[8][64], B[8][64];
+    for (int j = 0; j < 8; ++j) {
+        emu::wave_exchange((float)a[j], A[j]);
+        emu::wave_exchange((float)b[j], B[j]);
+    }
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        double s = 0.0;
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 8; ++j) s += (double)A[j][row + 32 * g] * (double)B[j][col + 32 * g];
+        c[r] = (float)((double)c[r] + s);
+    }
+    return c;
+}
+
 static inline float ds_shfl_xor(float v, int mask) {
     float all[64];
     emu::wave_exchange(v, all);

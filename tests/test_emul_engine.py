@@ -124,3 +124,19 @@ def test_backward_matches_oracle(n_stages, B, T, seed):
         assert got.shape == v.shape, k
         err = np.linalg.norm(got - v) / max(np.linalg.norm(v), 1e-30)
         assert err < 5e-5, (k, err)
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 3e-2)])
+def test_forward_eval_bf16_precisions(precision, tol):
+    eng = Engine(emul_lib())
+    n_stages, B, T = 4, 2, 32
+    sd = O.make_state_dict(seed=9, num_classes=4, n_stages=n_stages)
+    x = O.make_input(seed=6, batch=B, frames=T)
+    tsd = torch_sd(sd)
+    pw = eng.pack_weights(tsd, n_stages, with_bf16=True)
+    folded = {n: eng.bn_fold(b) for n, b in make_bns(tsd, n_stages).items()}
+    e = eng.forward_eval(torch.from_numpy(x), pw, folded, precision=precision)
+    ref = O.forward(sd, x, n_stages=n_stages, dtype=np.float64)
+    err = rel_err(e.numpy(), ref)
+    print(precision, err)
+    assert err < tol

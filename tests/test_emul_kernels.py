@@ -290,3 +290,44 @@ def test_mine_semihard(N, M):
     ref_s = np.zeros((M, 512), np.float32)
     np.add.at(ref_s, idx, g)
     np.testing.assert_allclose(dst, ref_s, rtol=1e-6, atol=1e-6)
+
+
+BF16_CASES = [
+    (2, 16, 64, 9, 32, 3, 1), (3, 32, 128, 20, 8, 3, 1), (5, 16, 128, 10, 4, 3, 1),
+    (2, 16, 64, 16, 32, 5, 2), (2, 32, 128, 13, 16, 5, 2), (3, 16, 128, 7, 8, 5, 2),
+]
+
+
+@pytest.mark.parametrize("x3", [True, False])
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv_fwd_bf16(case, x3):
+    """bf16 matrix-core variants: bf16x3 (hi/lo split, f32-class accuracy) and plain bf16."""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(abs(hash(case)) % 2**31)
+    x = rs.randn(b, ci, h, w).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, co).astype(np.float32)
+    shift = rs.randn(co).astype(np.float32)
+    whi = aligned(wt.size, np.uint16)
+    wlo = aligned(wt.size, np.uint16) if x3 else None
+    wsrc = to_aligned(wt)
+    lib.call("ds_pack_conv_weight_bf16", ptr(wsrc), ptr(whi), ptr(wlo), co, ci, k, None)
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    rows = lib.raw("ds_conv_bf16_stats_rows")(ctypes.byref(shp), int(x3))
+    assert rows > 0
+    y = aligned((b, ho, wo, co), fill=np.nan)
+    stats = aligned((rows, co, 2), fill=np.nan)
+    xh, sc, sh = nhwc(x), to_aligned(scale), to_aligned(shift)
+    lib.call("ds_conv_fwd_bf16", ctypes.byref(shp), ptr(xh), ptr(whi), ptr(wlo), ptr(sc), ptr(sh), None, ptr(y),
+             ptr(stats), DS_EPI_AFFINE | DS_EPI_STATS, None)
+    z = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    ref = z * scale[None, :, None, None] + shift[None, :, None, None]
+    err = rel_err(nchw(y), ref)
+    assert err < (2e-5 if x3 else 2e-2), err
+    if not x3:
+        assert err > 1e-4                      # really is the reduced-precision path
+    tot = stats.astype(np.float64).sum(axis=0)
+    np.testing.assert_allclose(tot[:, 0], z.sum(axis=(0, 2, 3)), rtol=2e-2 if not x3 else 1e-4,
+                               atol=0.5 if not x3 else 1e-3)

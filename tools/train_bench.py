@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (not the headline): one training step as the reference runs it
+(train_triplet.py:215-224): three train-mode forwards of 256 utterances, TripletMarginLoss, backward,
+Adagrad step.  Prints one JSON line: utterances/s through forward+backward+update on one MI355X."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256)
+    args = ap.parse_args()
+    import deepspeaker_oracle as O
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
+    dev = torch.device("cuda", 0)
+    sd = O.make_state_dict(seed=0, num_classes=1211, randomize_bn=False)
+    model = DeepSpeakerModel(512, 1211)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model = model.to(dev).train()
+    opt = torch.optim.Adagrad(model.parameters(), lr=0.1, lr_decay=1e-4)
+    g = torch.Generator().manual_seed(5)
+    data = [torch.randn(args.batch, 1, 160, 64, generator=g).to(dev) for _ in range(3)]
+    loss_fn = TripletMarginLoss(0.1)
+
+    def step():
+        out_a, out_p, out_n = model(data[0]), model(data[1]), model(data[2])
+        loss = loss_fn.forward(out_a, out_p, out_n)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    utt = 3 * args.batch * args.steps
+    print(json.dumps({"metric": "training utterances/sec (fwd + bwd + Adagrad), f32", "value": round(utt / dt, 1),
+                      "ms_per_step": round(dt / args.steps * 1e3, 2), "batch_triplets": args.batch,
+                      "tflops_algorithmic": round(utt / dt * 6.9e9 / 1e12, 1), "final_loss": float(loss)}))
+
+
+if __name__ == "__main__":
+    main()
