@@ -73,9 +73,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
-                    help="arithmetic of the stage convolutions: exact-f32 MFMA (parity path, default), "
-                         "split-operand bf16 MFMA (f32-class accuracy) or plain bf16 (speed mode)")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the stage convolutions: split-operand bf16 MFMA (default: f32-class "
+                         "accuracy, 6e-6 from the reference, inside the 1e-3 contract), exact-f32 MFMA, or "
+                         "plain bf16 (speed mode, ~3e-3 from the reference -- outside the contract)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed exact-f32 comparison run")
     ap.add_argument("--split-apn", action="store_true",
                     help="three separate 256-utterance forwards (the reference's call pattern, "
                          "train_triplet.py:215) instead of one 768-utterance forward")
@@ -99,9 +101,6 @@ def main():
     from deepspeaker_pytorch_amd.mining import mine_semihard_negatives, select_triplets
 
     sd_np = O.make_state_dict(seed=0, num_classes=1211)
-    model = DeepSpeakerModel(512, 1211, precision=args.precision)
-    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
-    model = model.to(dev).eval()
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     # anchors | positives | negatives, resident in HBM as one [768,1,160,64] buffer
     data_all = torch.randn(3 * BATCH_TRIPLETS, 1, FRAMES, 64, generator=g).to(dev)
@@ -116,50 +115,54 @@ def main():
     emb_glob = torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if world > 1 else None
     lab_glob = torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if world > 1 else None
 
-    def step():
-        with torch.no_grad():
-            if args.split_apn:
-                embs = [model(x) for x in data]
-            else:                                   # eval mode: per-utterance results do not depend on batching
-                embs = list(model(data_all).split(BATCH_TRIPLETS))
-            loss = loss_fn.forward(*embs)
-            sel = select_triplets(*embs, margin=0.1)
-            # cross-GPU semi-hard negative search over the all-gathered global batch (BASELINE configs[2]);
-            # at N = 1 the candidate set is the local batch, so per-GPU work has the same shape
-            if world > 1:
-                dist.all_gather_into_tensor(emb_glob, torch.cat(embs))
-                dist.all_gather_into_tensor(lab_glob, labels_loc)
-                mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob)
-            else:
-                mined = mine_semihard_negatives(embs[0], embs[1], c1, torch.cat(embs), labels_loc)
-        return loss, sel, mined
-
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.profile = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof, eng.profile = eng.profile, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(precision, steps, warmup):
+        model = DeepSpeakerModel(512, 1211, precision=precision)
+        model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
+        model = model.to(dev).eval()
 
-    if rank == 0:
-        emb_per_step = 3 * BATCH_TRIPLETS * world
-        value = emb_per_step * args.steps / elapsed
-        # live roofline of the dominant kernel family (the f32-MFMA implicit-GEMM convolution):
-        # algorithmic FLOPs of every launch / its event-measured duration on the launch stream
+        def step():
+            with torch.no_grad():
+                if args.split_apn:
+                    embs = [model(x) for x in data]
+                else:                                   # eval mode: per-utterance results do not depend on batching
+                    embs = list(model(data_all).split(BATCH_TRIPLETS))
+                loss = loss_fn.forward(*embs)
+                sel = select_triplets(*embs, margin=0.1)
+                # cross-GPU semi-hard negative search over the all-gathered global batch (BASELINE configs[2]);
+                # at N = 1 the candidate set is the local batch, so per-GPU work has the same shape
+                if world > 1:
+                    dist.all_gather_into_tensor(emb_glob, torch.cat(embs))
+                    dist.all_gather_into_tensor(lab_glob, labels_loc)
+                    mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob)
+                else:
+                    mined = mine_semihard_negatives(embs[0], embs[1], c1, torch.cat(embs), labels_loc)
+            return loss, sel, mined
+
+        for _ in range(warmup):
+            step()
+        fence()
+        eng.profile = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof, eng.profile = eng.profile, None
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof
+
+    def roofline_of(precision, prof, steps):
+        # live roofline of the dominant kernel family (the implicit-GEMM convolution): algorithmic FLOPs
+        # of every launch / its event-measured duration on the launch stream
         flops = sum(p[1] for p in prof)
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         by = {}
@@ -169,13 +172,37 @@ def main():
             d[1] += e0.elapsed_time(e1)
             d[2] += 1
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else BF16_MFMA_PEAK_TFLOPS
+        peak = F32_MFMA_PEAK_TFLOPS if precision == "f32" else BF16_MFMA_PEAK_TFLOPS
         kname = {"f32": "conv_mfma_f32_kernel (implicit-GEMM 3x3/5x5, all tile shapes)",
                  "bf16x3": "conv_mfma_bf16_kernel<X3=true> (3 bf16 MFMAs per product: hi*hi + hi*lo + lo*hi)",
-                 "bf16": "conv_mfma_bf16_kernel<X3=false>"}[args.precision]
+                 "bf16": "conv_mfma_bf16_kernel<X3=false>"}[precision]
+        r = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+             "frac": round(achieved / peak, 4), "traffic": None, "launches": len(prof),
+             "avg_launch_ms": round(ms / max(len(prof), 1), 4), "conv_ms_per_step": round(ms / steps, 3),
+             "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}}
+        if precision == "bf16x3":
+            # "achieved" counts each product once (algorithmic FLOPs); the matrix cores issue three MFMAs per
+            # product, so their issue rate is 3x that
+            r["mfma_issue_tflops"] = round(3 * achieved, 1)
+            r["mfma_issue_frac"] = round(3 * achieved / peak, 4)
+        return r
+
+    elapsed, prof = measure(args.precision, args.steps, args.warmup)
+
+    secondary = None
+    if world == 1 and not args.no_secondary and args.precision != "f32":
+        e2, p2 = measure("f32", max(3, args.steps // 2), 2)       # untimed comparison: the exact-f32 path
+        secondary = (e2, p2, max(3, args.steps // 2))
+
+    if rank == 0:
+        emb_per_step = 3 * BATCH_TRIPLETS * world
+        value = emb_per_step * args.steps / elapsed
         arith = {"f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations",
-                 "bf16x3": "split-operand bf16 MFMA (v_mfma_f32_32x32x16_bf16 x3, f32 accumulate), f32 activations",
-                 "bf16": "bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, f32 accumulate), f32 activations"}[args.precision]
+                 "bf16x3": "split-operand bf16 MFMA: x = hi + lo (two bf16), product = hi*hi + hi*lo + lo*hi on "
+                           "v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 activations; embeddings 6e-6 from the "
+                           "reference (contract: 1e-3), identical triplet selections",
+                 "bf16": "bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, f32 accumulate), f32 activations; "
+                         "embeddings ~3e-3 from the reference (OUTSIDE the 1e-3 contract)"}[args.precision]
         out = {
             "metric": "embeddings/sec (64-fbank x 160-frame utterances)",
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
@@ -189,14 +216,13 @@ def main():
                        "frames": FRAMES, "parallelism": f"dp{world}",
                        "forward_calls_per_step": 3 if args.split_apn else 1,
                        "arith": arith},
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
-                         "launches": len(prof), "avg_launch_ms": round(ms / max(len(prof), 1), 4),
-                         "conv_ms_per_step": round(ms / args.steps, 3),
-                         "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}},
+            "roofline": roofline_of(args.precision, prof, args.steps),
             "whole_forward_tflops": round(value * FWD_FLOPS_PER_EMB / 1e12, 2),
         }
+        if secondary is not None:
+            e2, p2, k2 = secondary
+            out["f32_path"] = {"value": round(emb_per_step * k2 / e2, 1), "unit": "embeddings/s", "steps": k2,
+                               "roofline": roofline_of("f32", p2, k2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out))

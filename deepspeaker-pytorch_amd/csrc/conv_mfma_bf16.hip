@@ -33,12 +33,17 @@ struct ConvKB {
     int IS;
     int dh_min, dw_min;
     int rows_in, cols_in, seg_pix;
+    int pitch, half;                // LDS records per tile row; first odd-column slot (stride-2 de-interleave)
     int RT, NI, segs_per_img, n_segs;
     int n_ntiles;
     int flags;
 };
 
-template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3>
+// NIT: float4 staging slots per thread (compile time, so all loads of a chunk are issued together);
+// PREF: the next chunk's pixels are loaded into registers BEFORE this chunk's matrix work and converted
+// / written to LDS after it (small tiles); otherwise they are loaded right after the barrier (big
+// tiles, where 16 slots would not fit next to the accumulators).
+template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3, int NIT, bool PREF>
 __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const ConvKB p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = MSUB * WM * 32;
@@ -77,10 +82,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     for (int pix = tid; pix < tile_pix; pix += NTHR) {
         const int seg = pix / p.seg_pix;
         const int pr = pix - seg * p.seg_pix;
-        const int rr = pr / p.cols_in, cc = pr - rr * p.cols_in;
+        const int rr = pr / p.pitch, pc = pr - rr * p.pitch;
+        // stride-2 layers keep even input columns in slots [0, half) and odd ones in [half, cols_in), so
+        // that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
+        const int cc = (p.IS == 2) ? (pc < p.half ? 2 * pc : 2 * (pc - p.half) + 1) : pc;
         const int gseg = seg0 + seg;
         int g = -1;
-        if (gseg < p.n_segs) {
+        if (gseg < p.n_segs && pc < p.cols_in) {
             const int b = gseg / p.segs_per_img;
             const int r0 = (gseg - b * p.segs_per_img) * p.RT;
             const int h = p.IS * r0 + p.dh_min + rr, w = p.dw_min + cc;
@@ -96,7 +104,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         const int seg = m / pix_per_seg;
         const int rem = m - seg * pix_per_seg;
         const int r = rem / p.Wc, c = rem - r * p.Wc;
-        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.cols_in + p.IS * c : 0;
+        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
         a_off[ms] = pix * PSB + 16 * lhi;
     }
 
@@ -125,27 +133,64 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
             if constexpr (X3) bq_lo[d][ns] = *(const bf16x8 *)(p.w_lo + o);
         }
 
+    // ---- staging descriptors (chunk-invariant): global float offset / validity / LDS byte offset ----
     const int n_items = tile_pix * (CKB / 4);
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        __syncthreads();                       // previous chunk's fragment reads (and the tables) are done
-        // ---- stage + convert: f32 pixels -> bf16 hi (+ lo) records ----
-        for (int idx = tid; idx < n_items; idx += NTHR) {
+    const int dump_off = (X3 ? 2 : 1) * tile_pix * PSB + (MT + tile_pix) * 4 + WM * NTILE * 8;   // 16-B slot
+    int g_off[NIT], l_off[NIT];
+    bool g_ok[NIT];
+    __syncthreads();                            // pix_goff is complete
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTHR;
+        g_off[it] = 0;
+        g_ok[it] = false;
+        l_off[it] = -1;
+        if (idx < n_items) {
             const int pix = idx >> 2, q = idx & 3;
             const int g = pix_goff[pix];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g >= 0) v = *(const f32x4 *)(p.x + g + chunk * CKB + q * 4);
-            bf16x4 h;
+            l_off[it] = pix * PSB + q * 8;
+            if (g >= 0) {
+                g_off[it] = g + q * 4;
+                g_ok[it] = true;
+            }
+        }
+    }
+    f32x4 st[NIT];
+    if constexpr (PREF) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
-            *(bf16x4 *)(lds_hi + pix * PSB + q * 8) = h;
-            if constexpr (X3) {
-                bf16x4 l;
+        for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
+    }
+    (void)dump_off;
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        __syncthreads();                       // previous chunk's fragment reads are done
+        if constexpr (!PREF) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) l[j] = (__bf16)(v[j] - (float)h[j]);
-                *(bf16x4 *)(lds_lo + pix * PSB + q * 8) = l;
+            for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + chunk * CKB);
+        }
+        // ---- convert: f32 pixels -> bf16 hi (+ lo) records ----
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (l_off[it] >= 0) {
+                const f32x4 v = g_ok[it] ? st[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
+                *(bf16x4 *)(lds_hi + l_off[it]) = h;
+                if constexpr (X3) {
+                    bf16x4 l;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) l[j] = (__bf16)(v[j] - (float)h[j]);
+                    *(bf16x4 *)(lds_lo + l_off[it]) = l;
+                }
             }
         }
         __syncthreads();
+        if constexpr (PREF) {                  // next chunk's pixels fly while this one computes
+            const int cn = chunk + 1 < n_chunks ? chunk + 1 : chunk;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + cn * CKB);
+        }
         const int g0 = chunk * NT;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -160,7 +205,8 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                     if constexpr (X3) bq_lo[(t - 1) % RING][ns] = *(const bf16x8 *)(p.w_lo + o);
                 }
             }
-            const int toff = ((t / KS) * p.cols_in + (t % KS)) * PSB;
+            const int kw = t % KS;
+            const int toff = ((t / KS) * p.pitch + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw)) * PSB;
             bf16x8 a_hi[MSUB], a_lo[X3 ? MSUB : 1];
 #pragma unroll
             for (int ms = 0; ms < MSUB; ++ms) {
@@ -168,16 +214,25 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                 if constexpr (X3) a_lo[ms] = *(const bf16x8 *)(lds_lo + a_off[ms] + toff);
             }
             __builtin_amdgcn_sched_barrier(0);
+            // term-major order: consecutive MFMAs always hit DIFFERENT accumulators (a dependent
+            // accumulate chain stalls the matrix pipe); small cross terms first, the leading term last
+            if constexpr (X3) {
+#pragma unroll
+                for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < NSUB; ++ns)
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_lo[ms], bq_hi[slot][ns], acc[ms][ns]);
+#pragma unroll
+                for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < NSUB; ++ns)
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[ms], bq_lo[slot][ns], acc[ms][ns]);
+            }
 #pragma unroll
             for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns) {
-                    if constexpr (X3) {        // small cross terms first, the leading term last
-                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_lo[ms], bq_hi[slot][ns], acc[ms][ns]);
-                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[ms], bq_lo[slot][ns], acc[ms][ns]);
-                    }
+                for (int ns = 0; ns < NSUB; ++ns)
                     acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[ms], bq_hi[slot][ns], acc[ms][ns]);
-                }
             __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -206,10 +261,22 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     }
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
+        // all 16 row offsets and (if any) the 16 residual rows of this sub-tile are fetched up front, branch
+        // free, so their latencies overlap instead of queueing behind one another
+        int offs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) offs[r] = out_off[(wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        float resv[16][NSUB];
+        if (flags & DS_EPI_RESIDUAL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                    resv[r][ns] = p.res[(size_t)(offs[r] >= 0 ? offs[r] : 0) + col[ns]];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const int off = out_off[row];
+            const int off = offs[r];
             if (off >= 0) {
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns) {
@@ -217,7 +284,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                     s1[ns] += v;
                     s2[ns] += v * v;
                     if (flags & DS_EPI_AFFINE) v = v * sc[ns] + sh[ns];
-                    if (flags & DS_EPI_RESIDUAL) v += p.res[(size_t)off + col[ns]];
+                    if (flags & DS_EPI_RESIDUAL) v += resv[r][ns];
                     if (flags & DS_EPI_CLIP) v = fminf(fmaxf(v, 0.0f), 20.0f);
                     p.y[(size_t)off + col[ns]] = v;
                 }
@@ -270,6 +337,34 @@ __global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float 
     }
 }
 
+// LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for a candidate row pitch: simulates
+// the two 16-lane service groups of lanes 0..31 (the upper half-wave behaves identically) over every
+// 32-row sub-tile of the M tile.  Bank slot of a record = (record * PSB / 16) mod 16.
+static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in, int pitch) {
+    static const int G0[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+    static const int G1[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+    const int pix_per_seg = RT * Wc, seg_pix = rows_in * pitch;
+    double total = 0.0;
+    int n = 0;
+    for (int m0 = 0; m0 + 32 <= MT; m0 += 32) {
+        for (int g = 0; g < 2; ++g) {
+            int cnt[16] = {0};
+            int worst = 0;
+            for (int j = 0; j < 16; ++j) {
+                const int m = m0 + (g ? G1[j] : G0[j]);
+                const int seg = m / pix_per_seg, rem = m % pix_per_seg;
+                const int r = rem / Wc, c = rem % Wc;
+                const int rec = (seg < NI) ? seg * seg_pix + (IS * r) * pitch + c : 0;
+                const int slot = (rec * (PSB / 16)) & 15;
+                if (++cnt[slot] > worst) worst = cnt[slot];
+            }
+            total += worst;
+            ++n;
+        }
+    }
+    return n ? total / n : 1.0;
+}
+
 // ---- host-side plan (same objective as the f32 planner; limits: 64 KiB LDS, 2 workgroups per CU) ----
 struct TileCfgB { int MT, NTILE, WM, wg_per_cu; };
 constexpr int kNumCfgB = 3;
@@ -280,7 +375,7 @@ constexpr TileCfgB kCfgB[kNumCfgB] = {
 };
 
 struct PlanB {
-    int cfg, grid, n_mtiles;
+    int cfg, grid, n_mtiles, nit;
     size_t lds_bytes;
     ConvKB k;
 };
@@ -310,12 +405,23 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
             int ni = cf.MT / (rt * Wo);
             if (ni > n_segs) ni = (int)n_segs;
             const int rows_in = IS * (rt - 1) + s->KS, cols_in = IS * (Wo - 1) + s->KS;
+            // conflict-avoiding row pitch for this geometry (at most 4 padding records per row)
+            auto pitch_of = [&](int n) {
+                int bp = cols_in;
+                double bc2 = 1e30;
+                for (int pt = cols_in; pt <= cols_in + 4; ++pt) {
+                    const double c2 = frag_read_cost(cf.MT, n, rt, Wo, IS, rows_in, pt);
+                    if (c2 < bc2 - 1e-9) { bc2 = c2; bp = pt; }
+                }
+                return bp;
+            };
             auto lds_of = [&](int n) {
-                const size_t tp = (size_t)n * rows_in * cols_in;
+                const size_t tp = (size_t)n * rows_in * pitch_of(n);
                 return tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
             };
-            while (ni > 1 && lds_of(ni) > 64 * 1024) --ni;
-            if (lds_of(ni) > 64 * 1024) continue;
+            auto items_of = [&](int n) { return (long long)n * rows_in * pitch_of(n) * (CKB / 4); };
+            while (ni > 1 && (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * 256)) --ni;
+            if (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * 256) continue;
             const long long n_mt = ds_ceil_div_ll(n_segs, ni);
             double eff = (double)s->B * Ho * Wo / ((double)n_mt * cf.MT);
             const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * cf.wg_per_cu;
@@ -336,24 +442,41 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     k.n_segs = s->B * k.segs_per_img;
     k.rows_in = IS * (brt - 1) + s->KS;
     k.cols_in = IS * (Wo - 1) + s->KS;
-    k.seg_pix = k.rows_in * k.cols_in;
+    k.half = (k.cols_in + 1) / 2;
+    // row pitch: the cheapest fragment read among cols_in .. cols_in+4 records per row
+    int best_pitch = k.cols_in;
+    double best_cost = 1e30;
+    for (int pt = k.cols_in; pt <= k.cols_in + 4; ++pt) {
+        const double c = frag_read_cost(cf.MT, bni, brt, Wo, IS, k.rows_in, pt);
+        if (c < best_cost - 1e-9) { best_cost = c; best_pitch = pt; }
+    }
+    k.pitch = best_pitch;
+    k.seg_pix = k.rows_in * k.pitch;
     k.n_ntiles = s->Cout / cf.NTILE;
     pl.cfg = bc;
     pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
     pl.grid = pl.n_mtiles * k.n_ntiles;
     const size_t tp = (size_t)k.NI * k.seg_pix;
-    pl.lds_bytes = tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
+    pl.lds_bytes = tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8 + 16;
+    pl.nit = ds_ceil_div((int)tp * (CKB / 4), 256);
     return DS_OK;
+}
+
+template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3>
+static void launch_nit_b(const PlanB &pl, void *stream) {
+    if (pl.nit <= 4)
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 4, true>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    else if (pl.nit <= 8)      // register-prefetch the next chunk where the accumulators leave room (MSUB <= 4)
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 8, (MSUB <= 4)>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    else
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 16, false>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
 }
 
 template <int KS, bool X3>
 static void launch_b(const PlanB &pl, void *stream) {
-    if (pl.cfg == 0)
-        DS_LAUNCH((conv_mfma_bf16_kernel<KS, 2, 1, 2, 2, X3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
-    else if (pl.cfg == 1)
-        DS_LAUNCH((conv_mfma_bf16_kernel<KS, 5, 1, 1, 4, X3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
-    else
-        DS_LAUNCH((conv_mfma_bf16_kernel<KS, 4, 1, 2, 2, X3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    if (pl.cfg == 0) launch_nit_b<KS, 2, 1, 2, 2, X3>(pl, stream);
+    else if (pl.cfg == 1) launch_nit_b<KS, 5, 1, 1, 4, X3>(pl, stream);
+    else launch_nit_b<KS, 4, 1, 2, 2, X3>(pl, stream);
 }
 
 }  // namespace

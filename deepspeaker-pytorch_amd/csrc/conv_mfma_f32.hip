@@ -271,10 +271,22 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK
     }
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
+        // all 16 row offsets and (if any) the 16 residual rows of this sub-tile are fetched up front, branch
+        // free, so their latencies overlap instead of queueing behind one another
+        int offs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) offs[r] = out_off[(wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        float resv[16][NSUB];
+        if (flags & DS_EPI_RESIDUAL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                    resv[r][ns] = p.res[(size_t)(offs[r] >= 0 ? offs[r] : 0) + col[ns]];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const int off = out_off[row];
+            const int off = offs[r];
             if (off >= 0) {
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns) {
@@ -282,7 +294,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK
                     s1[ns] += v;
                     s2[ns] += v * v;
                     if (flags & DS_EPI_AFFINE) v = v * sc[ns] + sh[ns];
-                    if (flags & DS_EPI_RESIDUAL) v += p.res[(size_t)off + col[ns]];
+                    if (flags & DS_EPI_RESIDUAL) v += resv[r][ns];
                     if (flags & DS_EPI_CLIP) v = fminf(fmaxf(v, 0.0f), 20.0f);
                     p.y[(size_t)off + col[ns]] = v;
                 }

@@ -7,20 +7,35 @@ the mask and the ordered compaction are kernels and only the selected-row count 
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-
 import torch
 
 from .model import _require_cuda, get_engine
 
 
-@dataclass
 class TripletSelection:
-    indices: torch.Tensor        # int64 [n_selected], ascending (train_triplet.py:262)
-    d_p: torch.Tensor            # [N]  (train_triplet.py:251)
-    d_n: torch.Tensor            # [N]  (train_triplet.py:252)
-    n_correct: int               # triplets already satisfying the margin (train_triplet.py:256-257)
-    mean_diff: torch.Tensor      # mean(d_n - d_p), 1-element device tensor (train_triplet.py:259-260)
+    """Result of `select_triplets`.  Everything stays on the device; reading `.indices` / `.n_selected` /
+    `.n_correct` is what synchronises (the reference branches on the count, train_triplet.py:263)."""
+
+    def __init__(self, idx_full, count, d_p, d_n, mean_diff):
+        self._idx_full = idx_full    # int64 [N]; the first `count` entries are valid, ascending
+        self.count = count           # int32 [1] on the device
+        self.d_p = d_p               # [N]  (train_triplet.py:251)
+        self.d_n = d_n               # [N]  (train_triplet.py:252)
+        self.mean_diff = mean_diff   # mean(d_n - d_p), 1-element device tensor (train_triplet.py:259-260)
+
+    @property
+    def n_selected(self) -> int:
+        return int(self.count.item())
+
+    @property
+    def indices(self) -> torch.Tensor:
+        """int64 [n_selected], ascending -- `np.where(all == 1)[0]` of train_triplet.py:262."""
+        return self._idx_full[:self.n_selected]
+
+    @property
+    def n_correct(self) -> int:
+        """triplets already satisfying the margin (train_triplet.py:256-257)"""
+        return self._idx_full.numel() - self.n_selected
 
 
 def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tensor, margin: float) -> TripletSelection:
@@ -29,8 +44,7 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     a, p, n = (t.detach().contiguous() for t in (out_a, out_p, out_n))
     _, d_p, d_n = eng.triplet_margin(a, p, n, margin)
     idx, count, mean_diff = eng.triplet_filter(d_p, d_n, margin)
-    k = int(count.item())                      # the one host sync: the reference branches on it (:263)
-    return TripletSelection(idx[:k], d_p, d_n, a.shape[0] - k, mean_diff)
+    return TripletSelection(idx, count, d_p, d_n, mean_diff)
 
 
 def mine_semihard_negatives(anchors: torch.Tensor, positives: torch.Tensor, anchor_labels: torch.Tensor,

@@ -1,15 +1,13 @@
 #!/bin/bash
 # Collect rocprofv3 PMC passes for bench.py on the GPU box (each --pmc set is its own run, with
-# --kernel-trace only -- see the gpurun rules).  Usage (inside gpurun): tools/pmc_run.sh <tag>
-TAG=${1:-pmc}
+# --kernel-trace only -- see the gpurun rules).  Usage (inside gpurun): tools/pmc_run.sh <tag> [bench args]
+TAG=${1:-pmc}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/sq1 --output-format csv -- $CMD > $OUT/sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -d $OUT/sq2 --output-format csv -- $CMD > $OUT/sq2.log 2>&1
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $@"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d $OUT/sq1 --output-format csv -- $CMD > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/sq2 --output-format csv -- $CMD > $OUT/sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/tcc --output-format csv -- $CMD > $OUT/tcc.log 2>&1
-rocprofv3 -L > $OUT/counters_list.txt 2>&1
-ls -R $OUT | head -50
