@@ -39,7 +39,7 @@ namespace {
 
 constexpr size_t kStack = 256 * 1024;
 constexpr int kMaxThreads = 1024;
-constexpr size_t kLdsBytes = 160 * 1024;
+constexpr size_t kLdsBytes = 64 * 1024;   // the default dynamic-LDS launch limit (no kernel here raises it)
 
 struct Fiber {
     void *sp = nullptr;
