@@ -70,6 +70,16 @@ _SIGNATURES = {
     "ds_gather_rows_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "ds_scatter_add_rows_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_mine_semihard_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_cross_entropy_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_cross_entropy_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_group_mean_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ds_roc_sweep_f32": (c_int, [_P, _P, c_int, c_float, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "ds_assemble_crops_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_optim_chunk_elems": (c_int, []),
+    "ds_adagrad_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P]),
+    "ds_sgd_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_int, _P]),
+    "ds_adam_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float,
+                                 c_float, c_float, _P]),
     "ds_pairwise_distance_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_margin_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_l2norm_scale_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),

@@ -454,3 +454,90 @@ extern "C" int ds_triplet_filter_f32(const float *d_p, const float *d_n, float m
     DS_LAUNCH(triplet_filter_kernel, 1, 256, 64, stream, d_p, d_n, margin, idx, count, mean_diff, N);
     return ds_last_launch_error();
 }
+
+// ---- softmax cross-entropy over the classifier logits (reference train_triplet.py:281-287:
+//      nn.CrossEntropyLoss() on cat[cls_a, cls_p, cls_n], mean reduction) -- one wave per row ----
+namespace {
+
+__device__ __forceinline__ float ce_wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, ds_shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float ce_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += ds_shfl_xor(v, m);
+    return v;
+}
+
+// row_loss[i] = logsumexp(logits[i,:]) - logits[i, label[i]];  lse[i] kept for the backward pass
+__global__ void __launch_bounds__(256) ce_rows_kernel(const float *logits, const long long *labels, float *row_loss,
+                                                      float *lse, int M, int n_cls, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = row < M ? row : M - 1;
+    const float *x = logits + (size_t)r * ld;
+    float mx = -3.0e38f;
+    for (int k = lane; k < n_cls; k += 64) mx = fmaxf(mx, x[k]);
+    mx = ce_wave_max(mx);
+    float s = 0.f;
+    for (int k = lane; k < n_cls; k += 64) s += expf(x[k] - mx);
+    s = ce_wave_sum(s);
+    const float l = mx + logf(s);
+    if (row < M && lane == 0) {
+        lse[row] = l;
+        row_loss[row] = l - x[labels[row]];
+    }
+}
+
+__global__ void __launch_bounds__(256) mean_kernel(const float *x, float *out, int N) {
+    float *scratch = ds_dynamic_lds();
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) acc += x[i];
+    acc = ce_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (float)N;
+}
+
+// dlogits[i,k] = gloss/M * (softmax(logits[i,:])[k] - [k == label[i]]);  columns >= n_cls (padding) = 0
+__global__ void __launch_bounds__(256) ce_bwd_kernel(const float *logits, const long long *labels, const float *lse,
+                                                     const float *gloss, float *dlogits, int M, int n_cls, int ld,
+                                                     int ld_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float g = gloss[0] / (float)M;
+    const float *x = logits + (size_t)row * ld;
+    const float l = lse[row];
+    const int lab = (int)labels[row];
+    float *d = dlogits + (size_t)row * ld_out;
+    for (int k = lane; k < ld_out; k += 64) {
+        float v = 0.f;
+        if (k < n_cls) v = g * (expf(x[k] - l) - (k == lab ? 1.0f : 0.0f));
+        d[k] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_cross_entropy_fwd_f32(const float *logits, const long long *labels, float *row_loss, float *lse,
+                                        float *loss, int M, int n_cls, int ld, void *stream) {
+    DS_REQUIRE(logits && labels && row_loss && lse && loss, DS_ERR_NULL);
+    DS_REQUIRE(M > 0 && n_cls > 0 && ld >= n_cls, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(ce_rows_kernel, ds_ceil_div(M, 4), 256, 0, stream, logits, labels, row_loss, lse, M, n_cls, ld);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(mean_kernel, 1, 256, 64, stream, (const float *)row_loss, loss, M);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_cross_entropy_bwd_f32(const float *logits, const long long *labels, const float *lse,
+                                        const float *grad_loss, float *dlogits, int M, int n_cls, int ld, int ld_out,
+                                        void *stream) {
+    DS_REQUIRE(logits && labels && lse && grad_loss && dlogits, DS_ERR_NULL);
+    DS_REQUIRE(M > 0 && n_cls > 0 && ld >= n_cls && ld_out >= n_cls, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(ce_bwd_kernel, ds_ceil_div(M, 4), 256, 0, stream, logits, labels, lse, grad_loss, dlogits, M, n_cls, ld,
+              ld_out);
+    return ds_last_launch_error();
+}

@@ -116,6 +116,106 @@ class TripletMarginLoss:
 
 
 # ---------------------------------------------------------------------------------------------
+# softmax pre-training head: classifier GEMM + cross-entropy (model.py:167,220-223; train_triplet.py:277-287)
+# ---------------------------------------------------------------------------------------------
+def _pad128(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+class _LinearHeadFn(torch.autograd.Function):
+    """y = x W^T + b on the f32 matrix cores (split-K GEMM of fc_mfma_f32.hip); W is zero-padded to a
+    multiple of 128 rows, the returned logits are the [M, n_cls] view of the padded [M, Np] buffer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eng):
+        import ctypes
+        x = x.contiguous()
+        m, k = x.shape
+        n = weight.shape[0]
+        npad = _pad128(n)
+        wpad = torch.zeros((npad, k), dtype=torch.float32, device=x.device)
+        wpad[:n].copy_(weight.detach())
+        bpad = torch.zeros(npad, dtype=torch.float32, device=x.device)
+        bpad[:n].copy_(bias.detach())
+        wp = torch.empty(npad * k, dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_pack_fc_weight_f32", eng._p(wpad), eng._p(wp), npad, k, 1, eng._stream(x))
+        ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(m, k, npad), dtype=torch.float32, device=x.device)
+        out = torch.empty((m, npad), dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_fc_l2norm_fwd_f32", eng._p(x), eng._p(wp), eng._p(bpad), eng._p(ws), eng._p(out), None, m, k,
+                     npad, 1.0, 0.0, eng._stream(x))
+        ctx.save_for_backward(x, wpad)
+        ctx.eng, ctx.n = eng, n
+        return out[:, :n]
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._native import ConvShape
+        import ctypes
+        x, wpad = ctx.saved_tensors
+        eng, n = ctx.eng, ctx.n
+        m, k = x.shape
+        npad = wpad.shape[0]
+        gp = torch.zeros((m, npad), dtype=torch.float32, device=x.device)
+        gp[:, :n].copy_(g)
+        st = eng._stream(x)
+        # dx = g Wpad
+        wd = torch.empty(npad * k, dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_pack_fc_weight_dgrad_f32", eng._p(wpad), eng._p(wd), npad, k, 1, st)
+        ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(m, npad, k), dtype=torch.float32, device=x.device)
+        gx = torch.empty((m, k), dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_fc_l2norm_fwd_f32", eng._p(gp), eng._p(wd), None, eng._p(ws), eng._p(gx), None, m, npad, k,
+                     1.0, 0.0, st)
+        # dW = g^T x (1x1 "convolution" over the M rows), db = column sums
+        shp = ConvShape(1, m, 1, k, npad, 1, 1)
+        ws2 = torch.empty(eng.lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp)), dtype=torch.float32,
+                          device=x.device)
+        gw = torch.empty((npad, k), dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), eng._p(x), eng._p(gp), eng._p(ws2), eng._p(gw), 0, st)
+        gb = torch.empty(npad, dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_colsum_f32", eng._p(gp), eng._p(gb), m, npad, st)
+        return gx, gw[:n], gb[:n], None
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, eng):
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        m, n = logits.shape
+        ld = logits.stride(0)
+        labels = labels.to(torch.int64).contiguous()
+        row_loss = torch.empty(m, dtype=torch.float32, device=logits.device)
+        lse = torch.empty_like(row_loss)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        eng.lib.call("ds_cross_entropy_fwd_f32", eng._p(logits), eng._p(labels), eng._p(row_loss), eng._p(lse),
+                     eng._p(loss), m, n, ld, eng._stream(logits))
+        ctx.save_for_backward(logits, labels, lse)
+        ctx.eng = eng
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        logits, labels, lse = ctx.saved_tensors
+        eng = ctx.eng
+        m, n = logits.shape
+        d = torch.empty((m, n), dtype=torch.float32, device=logits.device)
+        gl = gl.reshape(1).contiguous().float()
+        eng.lib.call("ds_cross_entropy_bwd_f32", eng._p(logits), eng._p(labels), eng._p(lse), eng._p(gl), eng._p(d), m,
+                     n, logits.stride(0), n, eng._stream(logits))
+        return d, None, None
+
+
+class CrossEntropyLoss:
+    """Drop-in for the `nn.CrossEntropyLoss()` of train_triplet.py:281 (mean reduction) on HIP kernels."""
+
+    def forward(self, logits, labels):
+        _require_cuda(logits, "CrossEntropyLoss")
+        return _CrossEntropyFn.apply(logits, labels, get_engine())
+
+    __call__ = forward
+
+
+# ---------------------------------------------------------------------------------------------
 # parameter containers mirroring the reference's module tree (model.py:36-130)
 # ---------------------------------------------------------------------------------------------
 class ReLU(nn.Hardtanh):
@@ -334,7 +434,6 @@ class DeepSpeakerModel(nn.Module):
         return self.features
 
     def forward_classifier(self, x):
-        """reference model.py:220-223.  The 512 -> num_classes head stays a library GEMM for now
-        ("next")."""
+        """reference model.py:220-223: logits = classifier(embedding x10), on the f32 matrix cores."""
         features = self.forward(x)
-        return torch.nn.functional.linear(features, self.model.classifier.weight, self.model.classifier.bias)
+        return _LinearHeadFn.apply(features, self.model.classifier.weight, self.model.classifier.bias, get_engine())

@@ -1,0 +1,160 @@
+"""Fused multi-tensor optimizers.
+
+Drop-in for the three optimizers `create_optimizer` builds in the reference (train_triplet.py:369-383):
+`optim.Adagrad(lr, lr_decay, weight_decay)`, `optim.SGD(lr, momentum=0.9, dampening=0.9, weight_decay)`,
+`optim.Adam(lr, weight_decay)`.  Same constructor arguments, same per-parameter state keys (`step`, `sum`,
+`momentum_buffer`, `exp_avg`, `exp_avg_sq`), so `optimizer.state_dict()` checkpoints
+(train_triplet.py:325-327) interchange with torch's.  One HIP launch per `step()` for all tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List
+
+import torch
+
+from .model import _require_cuda, get_engine
+
+
+class _FusedBase(torch.optim.Optimizer):
+    _engine = None          # tests may inject an Engine bound to the host emulator
+
+    def _eng(self):
+        return self._engine if self._engine is not None else get_engine()
+
+    def _tables(self, group, state_keys: List[str], need_state2: bool, with_step: bool = True):
+        """Device pointer tables + chunk table for the parameters of `group` that have gradients (cached
+        until the set of tensors / their storage changes)."""
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
+            return None
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise ValueError("fused optimizers need contiguous float32 parameters and gradients")
+        states = []
+        for p in params:
+            st = self.state[p]
+            if with_step and "step" not in st:
+                st["step"] = torch.tensor(0.0)
+            for k in state_keys:
+                if k not in st:
+                    st[k] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            states.append(st)
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) + tuple(st[k].data_ptr() for k in state_keys)
+                    for p, st in zip(params, states))
+        cache = group.get("_ds_cache")
+        if cache is None or cache["key"] != key:
+            dev = params[0].device
+            chunk = self._eng().lib.raw("ds_optim_chunk_elems")()
+
+            def ptr_table(ts):
+                return torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(dev)
+
+            ct, ci = [], []
+            for i, p in enumerate(params):
+                for c in range((p.numel() + chunk - 1) // chunk):
+                    ct.append(i)
+                    ci.append(c)
+            cache = {
+                "key": key,
+                "params": ptr_table(params), "grads": ptr_table([p.grad for p in params]),
+                "s1": ptr_table([st[state_keys[0]] for st in states]) if state_keys else None,
+                "s2": ptr_table([st[state_keys[1]] for st in states]) if need_state2 else None,
+                "numel": torch.tensor([p.numel() for p in params], dtype=torch.int64).to(dev),
+                "ct": torch.tensor(ct, dtype=torch.int32).to(dev), "ci": torch.tensor(ci, dtype=torch.int32).to(dev),
+                "n_chunks": len(ct),
+            }
+            group["_ds_cache"] = cache
+        return params, states, cache
+
+    @staticmethod
+    def _args(eng, c):
+        return (eng._p(c["params"]), eng._p(c["grads"]), eng._p(c["s1"]), eng._p(c["s2"]), eng._p(c["numel"]),
+                eng._p(c["ct"]), eng._p(c["ci"]), c["n_chunks"])
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for g in sd["param_groups"]:
+            g.pop("_ds_cache", None)
+        return sd
+
+
+class FusedAdagrad(_FusedBase):
+    """torch.optim.Adagrad(params, lr, lr_decay, weight_decay, initial_accumulator_value=0, eps=1e-10)."""
+
+    def __init__(self, params, lr=1e-2, lr_decay=0.0, weight_decay=0.0, eps=1e-10):
+        super().__init__(params, dict(lr=lr, lr_decay=lr_decay, weight_decay=weight_decay, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        eng = self._eng()
+        for group in self.param_groups:
+            t = self._tables(group, ["sum"], False)
+            if t is None:
+                continue
+            params, states, c = t
+            for st in states:
+                st["step"] += 1
+            step = float(states[0]["step"])
+            clr = group["lr"] / (1 + (step - 1) * group["lr_decay"])
+            eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
+                         eng._stream(params[0]))
+        return loss
+
+
+class FusedSGD(_FusedBase):
+    """torch.optim.SGD(params, lr, momentum, dampening, weight_decay) (no nesterov)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        eng = self._eng()
+        for group in self.param_groups:
+            fresh = any("momentum_buffer" not in self.state[p] for p in group["params"] if p.grad is not None)
+            t = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False, with_step=False)
+            if t is None:
+                continue
+            params, states, c = t
+            eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
+                         group["weight_decay"], int(fresh), eng._stream(params[0]))
+        return loss
+
+
+class FusedAdam(_FusedBase):
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) (no amsgrad)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        eng = self._eng()
+        for group in self.param_groups:
+            t = self._tables(group, ["exp_avg", "exp_avg_sq"], True)
+            if t is None:
+                continue
+            params, states, c = t
+            for st in states:
+                st["step"] += 1
+            step = float(states[0]["step"])
+            b1, b2 = group["betas"]
+            eng.lib.call("ds_adam_step_f32", *self._args(eng, c), group["lr"], b1, b2, group["eps"],
+                         group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), eng._stream(params[0]))
+        return loss
+
+
+def create_optimizer(model, new_lr, optimizer="adagrad", lr_decay=1e-4, wd=0.0):
+    """train_triplet.py:369-383 with the fused implementations (same hyper-parameters)."""
+    if optimizer == "sgd":
+        return FusedSGD(model.parameters(), lr=new_lr, momentum=0.9, dampening=0.9, weight_decay=wd)
+    if optimizer == "adam":
+        return FusedAdam(model.parameters(), lr=new_lr, weight_decay=wd)
+    if optimizer == "adagrad":
+        return FusedAdagrad(model.parameters(), lr=new_lr, lr_decay=lr_decay, weight_decay=wd)
+    raise ValueError(optimizer)

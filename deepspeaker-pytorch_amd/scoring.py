@@ -1,0 +1,63 @@
+"""Verification scoring on the device.
+
+`trial_scores` = the reference's test-time score (train_triplet.py:337-350): both utterances of a trial
+are embedded as `crops` fixed-length crops, the distance is taken crop-by-crop and averaged.
+`evaluate` = the threshold sweep of eval_metrics.py:5-50 (tpr / fpr / accuracy at the best-accuracy
+threshold) plus the equal error rate the reference never computes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .model import _require_cuda, get_engine
+
+_engine_override = None        # tests may bind the host emulator
+
+
+def _eng():
+    return _engine_override if _engine_override is not None else get_engine()
+
+
+def trial_scores(emb_a: torch.Tensor, emb_p: torch.Tensor, crops: int) -> torch.Tensor:
+    """[n_trials*crops, D] x 2 (rows ordered trial-major, crop-minor as train_triplet.py:339-340 builds them)
+    -> [n_trials] mean crop-pair distance."""
+    eng = _eng()
+    d = eng.pairwise_distance(emb_a.contiguous(), emb_p.contiguous())
+    n = d.numel() // crops
+    out = torch.empty(n, dtype=torch.float32, device=d.device)
+    eng.lib.call("ds_group_mean_f32", eng._p(d), eng._p(out), n, crops, eng._stream(d))
+    return out
+
+
+@dataclass
+class Verification:
+    tpr: float
+    fpr: float
+    accuracy: float
+    threshold: float
+    eer: float
+    eer_threshold: float
+    tp: torch.Tensor        # per-threshold counts, on the device
+    fp: torch.Tensor
+
+
+def evaluate(distances: torch.Tensor, labels: torch.Tensor, thr_start: float = 0.0, thr_stop: float = 30.0,
+             thr_step: float = 0.01) -> Verification:
+    """eval_metrics.evaluate (thresholds np.arange(0, 30, 0.01), eval_metrics.py:7) on the device + EER."""
+    eng = _eng()
+    d = distances.contiguous().float()
+    lab = (labels != 0).to(torch.int32).contiguous()
+    n = d.numel()
+    n_thr = len(np.arange(thr_start, thr_stop, thr_step))
+    n_same = int(lab.sum().item())
+    tp = torch.empty(n_thr, dtype=torch.int32, device=d.device)
+    fp = torch.empty_like(tp)
+    summary = torch.empty(6, dtype=torch.float32, device=d.device)
+    eng.lib.call("ds_roc_sweep_f32", eng._p(d), eng._p(lab), n, float(thr_start), float(thr_step), n_thr, n_same,
+                 n - n_same, eng._p(tp), eng._p(fp), eng._p(summary), eng._stream(d))
+    s = summary.cpu().numpy()
+    return Verification(float(s[1]), float(s[2]), float(s[3]), thr_start + thr_step * float(s[0]), float(s[4]),
+                        float(s[5]), tp, fp)

@@ -222,6 +222,50 @@ int ds_l2norm_scale_bwd_f32(const float *f, const float *ge, float *gf, int B, i
 int ds_avgpool_time_bwd_f32(const float *gpooled, const float *out, float *gx, int B, int Hr, int Wc,
                             int C, void *stream);
 
+
+/* ---- softmax cross-entropy of the classifier logits (nn.CrossEntropyLoss, mean reduction;
+ *      train_triplet.py:281-287).  logits [M, ld] with n_cls valid columns; lse[M] and row_loss[M] are
+ *      outputs of the forward that the backward re-uses; dlogits [M, ld_out], columns >= n_cls zeroed. -- */
+int ds_cross_entropy_fwd_f32(const float *logits, const long long *labels, float *row_loss, float *lse,
+                             float *loss, int M, int n_cls, int ld, void *stream);
+int ds_cross_entropy_bwd_f32(const float *logits, const long long *labels, const float *lse,
+                             const float *grad_loss, float *dlogits, int M, int n_cls, int ld, int ld_out,
+                             void *stream);
+
+/* ---- verification scoring on the device --------------------------------------
+ * ds_group_mean_f32: score of a trial = mean over G crop-pair distances (train_triplet.py:347-350).
+ * ds_roc_sweep_f32: the threshold sweep of eval_metrics.py:5-50 (predict = dist < thr; tp/fp per
+ * threshold thr0 + i*dthr) plus a summary {best-accuracy threshold index (first argmax), tpr, fpr,
+ * accuracy there, EER, EER threshold}; the reference computes no EER. -------------------- */
+int ds_group_mean_f32(const float *x, float *out, int n_groups, int G, void *stream);
+int ds_roc_sweep_f32(const float *dist, const int *issame, int N, float thr0, float dthr, int n_thr,
+                     int n_same, int n_diff, int *tp, int *fp, float *summary6, void *stream);
+
+/* ---- batch assembly on the device: out[b, t, :] = features[row_start[b] + t, :]
+ *      for t < T, zero past row_end[b]; features = the corpus' [frames, F] fbank matrices concatenated
+ *      and resident in HBM.  Replaces the host-side np.load + crop + transpose + H2D of
+ *      audio_processing.py:38-74,185 / DeepSpeakerDataset_dynamic.py:82-103 per batch. ---------------- */
+int ds_assemble_crops_f32(const float *features, const long long *row_start, const long long *row_end,
+                          float *out, int B, int T, int F, void *stream);
+
+/* ---- fused multi-tensor optimizer steps: one launch updates every parameter
+ *      tensor; replaces torch.optim.{Adagrad,SGD,Adam}.step() of train_triplet.py:369-383,224,291 with
+ *      the same arithmetic.  `params`, `grads`, `state1`, `state2` are DEVICE arrays of device pointers
+ *      (one per tensor), `numel` a device int64 array; workgroup b updates elements
+ *      [chunk_index[b]*ds_optim_chunk_elems(), +ds_optim_chunk_elems()) of tensor chunk_tensor[b]. ---- */
+int ds_optim_chunk_elems(void);
+int ds_adagrad_step_f32(const void *params, const void *grads, const void *state1, const void *state2,
+                        const long long *numel, const int *chunk_tensor, const int *chunk_index,
+                        int n_chunks, float clr, float weight_decay, float eps, void *stream);
+int ds_sgd_step_f32(const void *params, const void *grads, const void *state1, const void *state2,
+                    const long long *numel, const int *chunk_tensor, const int *chunk_index, int n_chunks,
+                    float lr, float momentum, float dampening, float weight_decay, int first_step,
+                    void *stream);
+int ds_adam_step_f32(const void *params, const void *grads, const void *state1, const void *state2,
+                     const long long *numel, const int *chunk_tensor, const int *chunk_index, int n_chunks,
+                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                     float bias_correction1, float bias_correction2_sqrt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -285,6 +285,34 @@ def test_scores(emb_a: np.ndarray, emb_p: np.ndarray, crops: int) -> np.ndarray:
     return d.reshape(-1, crops).mean(axis=1)
 
 
+def roc_sweep(distances: np.ndarray, labels: np.ndarray, thresholds: np.ndarray):
+    """eval_metrics.py:16-50: per threshold tp/fp with predict_issame = dist < threshold; best threshold =
+    first argmax of accuracy.  Returns (tp[], fp[], best_index, tpr, fpr, acc)."""
+    issame = labels.astype(bool)
+    d32 = distances.astype(np.float32)
+    tp = np.array([np.sum(np.logical_and(np.less(d32, np.float32(t)), issame)) for t in thresholds])
+    fp = np.array([np.sum(np.logical_and(np.less(d32, np.float32(t)), ~issame)) for t in thresholds])
+    n_same, n_diff = issame.sum(), (~issame).sum()
+    acc = (tp + (n_diff - fp)) / float(d32.size)                       # eval_metrics.py:49
+    best = int(np.argmax(acc))                                          # eval_metrics.py:33
+    tpr = 0 if n_same == 0 else tp[best] / float(n_same)               # eval_metrics.py:47
+    fpr = 0 if n_diff == 0 else fp[best] / float(n_diff)               # eval_metrics.py:48
+    return tp, fp, best, float(tpr), float(fpr), float(acc[best])
+
+
+def equal_error_rate(tp: np.ndarray, fp: np.ndarray, n_same: int, n_diff: int) -> float:
+    """EER from a threshold sweep (NEW: the reference computes none): first threshold where
+    FPR >= FNR, linearly interpolated with the previous one."""
+    fpr = fp / max(n_diff, 1)
+    fnr = 1.0 - tp / max(n_same, 1)
+    i = int(np.argmax(fpr >= fnr))
+    if i == 0:
+        return float(0.5 * (fpr[0] + fnr[0]))
+    d0, d1 = fnr[i - 1] - fpr[i - 1], fpr[i] - fnr[i]
+    w = d0 / (d0 + d1) if (d0 + d1) > 0 else 0.0
+    return float(fpr[i - 1] + w * (fpr[i] - fpr[i - 1]))
+
+
 def mine_semihard(anchor: np.ndarray, d_p: np.ndarray, anchor_label: np.ndarray,
                   cand: np.ndarray, cand_label: np.ndarray) -> np.ndarray:
     """Cross-GPU semi-hard negative search (NEW capability, no reference

@@ -172,6 +172,17 @@ def main():
     out["ce_logits"], out["ce_labels"] = logits.numpy(), labels.numpy()
     out["ce_value"] = torch.nn.CrossEntropyLoss()(logits, labels).numpy()
 
+    # ---------------- eval_metrics.calculate_roc (the importable half of evaluate(); calculate_val raises on
+    # scipy >= 1.15) on synthetic verification scores --------------------------------
+    import eval_metrics as ref_eval
+    rs2 = np.random.RandomState(61)
+    n_pairs = 600
+    roc_labels = (rs2.rand(n_pairs) < 0.5).astype(np.int64)
+    roc_dist = np.where(roc_labels == 1, rs2.normal(6.0, 1.5, n_pairs), rs2.normal(9.0, 1.5, n_pairs)).astype(np.float32)
+    tpr, fpr, acc = ref_eval.calculate_roc(np.arange(0, 30, 0.01), roc_dist, roc_labels)
+    out["roc_dist"], out["roc_labels"] = roc_dist, roc_labels
+    out["roc_tpr_fpr_acc"] = np.array([tpr, fpr, acc], np.float64)
+
     path = os.path.join(HERE, "reference_outputs.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -140,3 +140,110 @@ def test_forward_eval_bf16_precisions(precision, tol):
     err = rel_err(e.numpy(), ref)
     print(precision, err)
     assert err < tol
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "sgd", "adam"])
+def test_fused_optimizers_match_torch(kind):
+    """One-launch multi-tensor steps vs torch.optim with the reference's hyper-parameters
+    (train_triplet.py:369-383); the checker here is torch's own CPU optimizer."""
+    from deepspeaker_pytorch_amd import optim as fo
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(3)
+    shapes = [(64, 1, 5, 5), (17,), (33000,), (128, 64, 3, 3)]
+    ref_p = [torch.nn.Parameter(torch.from_numpy(rs.randn(*s).astype(np.float32))) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    if kind == "adagrad":
+        ref = torch.optim.Adagrad(ref_p, lr=0.1, lr_decay=1e-4, weight_decay=1e-3)
+        ours = fo.FusedAdagrad(our_p, lr=0.1, lr_decay=1e-4, weight_decay=1e-3)
+    elif kind == "sgd":
+        ref = torch.optim.SGD(ref_p, lr=0.1, momentum=0.9, dampening=0.9, weight_decay=1e-3)
+        ours = fo.FusedSGD(our_p, lr=0.1, momentum=0.9, dampening=0.9, weight_decay=1e-3)
+    else:
+        ref = torch.optim.Adam(ref_p, lr=0.01, weight_decay=1e-3)
+        ours = fo.FusedAdam(our_p, lr=0.01, weight_decay=1e-3)
+    ours._engine = eng
+    for it in range(3):
+        for a, b in zip(ref_p, our_p):
+            g = torch.from_numpy(rs.randn(*a.shape).astype(np.float32))
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step()
+        ours.step()
+        for a, b in zip(ref_p, our_p):
+            assert rel_err(b.detach().numpy(), a.detach().numpy()) < 2e-6, (kind, it)
+    # state interchange: our state_dict loads into torch's optimizer and vice versa
+    sd = ours.state_dict()
+    assert set(sd["state"][0].keys()) == set(ref.state_dict()["state"][0].keys())
+    ref.load_state_dict(sd)
+
+
+def test_scoring_and_roc(golden):
+    from deepspeaker_pytorch_amd import scoring
+    scoring._engine_override = Engine(emul_lib())
+    try:
+        d = torch.from_numpy(golden["roc_dist"])
+        lab = torch.from_numpy(golden["roc_labels"])
+        v = scoring.evaluate(d, lab)
+        np.testing.assert_allclose([v.tpr, v.fpr, v.accuracy], golden["roc_tpr_fpr_acc"], atol=1e-6)
+        thr = np.arange(0, 30, 0.01)
+        tp, fp, best, *_ = O.roc_sweep(golden["roc_dist"], golden["roc_labels"], thr)
+        np.testing.assert_array_equal(v.tp.numpy(), tp)
+        np.testing.assert_array_equal(v.fp.numpy(), fp)
+        assert abs(v.threshold - thr[best]) < 1e-5
+        issame = golden["roc_labels"].astype(bool)
+        assert abs(v.eer - O.equal_error_rate(tp, fp, issame.sum(), (~issame).sum())) < 1e-5
+        # test-time score: mean of 8 crop-pair distances (train_triplet.py:348-350)
+        rs = np.random.RandomState(2)
+        a, p = rs.randn(40, 512).astype(np.float32), rs.randn(40, 512).astype(np.float32)
+        s = scoring.trial_scores(torch.from_numpy(a), torch.from_numpy(p), 8)
+        assert rel_err(s.numpy(), O.test_scores(a, p, 8)) < 1e-6
+    finally:
+        scoring._engine_override = None
+
+
+def test_feature_store_crops():
+    from deepspeaker_pytorch_amd import data
+    data._engine_override = Engine(emul_lib())
+    try:
+        rs = np.random.RandomState(4)
+        utts = [rs.randn(t, 64).astype(np.float32) for t in (50, 33, 120)]
+        fs = data.FeatureStore(utts, device="cpu")
+        idx, st = [2, 0, 1, 2], [10, 0, 20, 100]
+        x = fs.crops(idx, st, 32).numpy()
+        assert x.shape == (4, 1, 32, 64)
+        for b, (u, s) in enumerate(zip(idx, st)):
+            ref = np.zeros((32, 64), np.float32)
+            seg = utts[u][s:s + 32]
+            ref[:len(seg)] = seg                               # zero padded past the utterance end
+            np.testing.assert_array_equal(x[b, 0], ref)
+        a, p, n = fs.triplets([0, 1], [0, 1], [2, 2], [[1, 2], [3, 0], [5, 60]], 16)
+        np.testing.assert_array_equal(n[1, 0].numpy(), utts[2][60:76])
+        with pytest.raises(IndexError):
+            fs.crops([3], [0], 8)
+    finally:
+        data._engine_override = None
+
+
+def test_classifier_head_and_cross_entropy(golden):
+    """forward_classifier's GEMM + the CE of train_triplet.py:277-287, forward and backward, vs torch on CPU."""
+    from deepspeaker_pytorch_amd.model import _CrossEntropyFn, _LinearHeadFn
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(12)
+    M, K, N = 12, 512, 21
+    x = torch.from_numpy(rs.randn(M, K).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rs.randn(N, K) * 0.05).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rs.randn(N).astype(np.float32)).requires_grad_(True)
+    labels = torch.from_numpy(rs.randint(0, N, M).astype(np.int64))
+    logits = _LinearHeadFn.apply(x, w, b, eng)
+    loss = _CrossEntropyFn.apply(logits, labels, eng)
+    loss.backward()
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    lr = torch.nn.functional.linear(xr, wr, br)
+    ref = torch.nn.CrossEntropyLoss()(lr, labels)
+    ref.backward()
+    assert rel_err(logits.detach().numpy(), lr.detach().numpy()) < 1e-5
+    assert abs(float(loss) - float(ref)) < 1e-5
+    for a, r in ((x, xr), (w, wr), (b, br)):
+        assert rel_err(a.grad.numpy(), r.grad.numpy()) < 1e-5
+    # the reference-recorded CE value
+    l2 = _CrossEntropyFn.apply(torch.from_numpy(golden["ce_logits"]), torch.from_numpy(golden["ce_labels"]), eng)
+    assert abs(float(l2) - float(golden["ce_value"])) < 1e-6

@@ -202,3 +202,12 @@ def test_torch_restatement(golden):
     with torch.no_grad():
         es = TR.forward_eval(tsds, torch.from_numpy(O.make_input(seed=22, batch=32)), n_stages=2)
     assert rel_err(es.numpy(), golden["small_eval_emb"]) < 1e-6
+
+
+def test_roc_sweep_vs_reference_eval_metrics(golden):
+    thr = np.arange(0, 30, 0.01)
+    tp, fp, best, tpr, fpr, acc = O.roc_sweep(golden["roc_dist"], golden["roc_labels"], thr)
+    np.testing.assert_allclose([tpr, fpr, acc], golden["roc_tpr_fpr_acc"], rtol=0, atol=1e-12)
+    lab = golden["roc_labels"].astype(bool)
+    eer = O.equal_error_rate(tp, fp, lab.sum(), (~lab).sum())
+    assert 0.05 < eer < 0.3
