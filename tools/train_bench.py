@@ -28,7 +28,8 @@ def main():
     model = DeepSpeakerModel(512, 1211)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to(dev).train()
-    opt = torch.optim.Adagrad(model.parameters(), lr=0.1, lr_decay=1e-4)
+    from deepspeaker_pytorch_amd.optim import create_optimizer
+    opt = create_optimizer(model, 0.1)              # fused multi-tensor Adagrad (train_triplet.py:379-382)
     g = torch.Generator().manual_seed(5)
     data = [torch.randn(args.batch, 1, 160, 64, generator=g).to(dev) for _ in range(3)]
     loss_fn = TripletMarginLoss(0.1)
