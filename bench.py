@@ -176,8 +176,16 @@ def main():
         kname = {"f32": "conv_mfma_f32_kernel (implicit-GEMM 3x3/5x5, all tile shapes)",
                  "bf16x3": "conv_mfma_bf16_kernel<X3=true> (3 bf16 MFMAs per product: hi*hi + hi*lo + lo*hi)",
                  "bf16": "conv_mfma_bf16_kernel<X3=false>"}[precision]
+        traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get(precision)
+            if t and (not args.split_apn) == (t["launch_batch"] == 3 * BATCH_TRIPLETS):
+                traffic = t["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         r = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-             "frac": round(achieved / peak, 4), "traffic": None, "launches": len(prof),
+             "frac": round(achieved / peak, 4), "traffic": traffic, "launches": len(prof),
              "avg_launch_ms": round(ms / max(len(prof), 1), 4), "conv_ms_per_step": round(ms / steps, 3),
              "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}}
         if precision == "bf16x3":
