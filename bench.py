@@ -144,7 +144,8 @@ def main():
                     mined = mine_semihard_negatives(embs[0], embs[1], c1, torch.cat(embs), labels_loc)
             return loss, sel, mined
 
-        for _ in range(warmup):
+        eng.profile = []                        # warm-up with the event instrumentation on: the first
+        for _ in range(warmup):                 # timing events of a process cost ~40 ms to create
             step()
         fence()
         eng.profile = []

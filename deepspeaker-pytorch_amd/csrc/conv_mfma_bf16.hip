@@ -50,6 +50,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     constexpr int NTILE = NSUB * WN * 32;
     constexpr int NT = KS * KS;
     constexpr int RING = (KS == 3) ? (MSUB <= 2 ? 9 : 3) : (KS == 5 ? 5 : 1);
+    // 2-wave workgroups run one wave per SIMD with a 160x64 register tile each: nothing else hides LDS
+    // latency there, so the next tap's pixel fragments are fetched before this tap's matrix work
+    constexpr bool APREF = (WM * WN == 2);
 
     char *lds = (char *)ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -192,6 +195,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
             for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + cn * CKB);
         }
         const int g0 = chunk * NT;
+        bf16x8 a_hi[APREF ? 2 : 1][MSUB], a_lo[APREF ? 2 : 1][X3 ? MSUB : 1];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int slot = t % RING;
@@ -205,13 +209,28 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                     if constexpr (X3) bq_lo[(t - 1) % RING][ns] = *(const bf16x8 *)(p.w_lo + o);
                 }
             }
-            const int kw = t % KS;
-            const int toff = ((t / KS) * p.pitch + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw)) * PSB;
-            bf16x8 a_hi[MSUB], a_lo[X3 ? MSUB : 1];
+            auto tap_off = [&](int tt) {
+                const int kw = tt % KS;
+                return ((tt / KS) * p.pitch + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw)) * PSB;
+            };
+            const int cur = APREF ? (t & 1) : 0;
+            if (!APREF || t == 0) {
+                const int toff = tap_off(t);
 #pragma unroll
-            for (int ms = 0; ms < MSUB; ++ms) {
-                a_hi[ms] = *(const bf16x8 *)(lds_hi + a_off[ms] + toff);
-                if constexpr (X3) a_lo[ms] = *(const bf16x8 *)(lds_lo + a_off[ms] + toff);
+                for (int ms = 0; ms < MSUB; ++ms) {
+                    a_hi[cur][ms] = *(const bf16x8 *)(lds_hi + a_off[ms] + toff);
+                    if constexpr (X3) a_lo[cur][ms] = *(const bf16x8 *)(lds_lo + a_off[ms] + toff);
+                }
+            }
+            if constexpr (APREF) {
+                if (t + 1 < NT) {
+                    const int toff = tap_off(t + 1);
+#pragma unroll
+                    for (int ms = 0; ms < MSUB; ++ms) {
+                        a_hi[cur ^ 1][ms] = *(const bf16x8 *)(lds_hi + a_off[ms] + toff);
+                        if constexpr (X3) a_lo[cur ^ 1][ms] = *(const bf16x8 *)(lds_lo + a_off[ms] + toff);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // term-major order: consecutive MFMAs always hit DIFFERENT accumulators (a dependent
@@ -221,18 +240,18 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                 for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
                     for (int ns = 0; ns < NSUB; ++ns)
-                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_lo[ms], bq_hi[slot][ns], acc[ms][ns]);
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_lo[cur][ms], bq_hi[slot][ns], acc[ms][ns]);
 #pragma unroll
                 for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
                     for (int ns = 0; ns < NSUB; ++ns)
-                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[ms], bq_lo[slot][ns], acc[ms][ns]);
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[cur][ms], bq_lo[slot][ns], acc[ms][ns]);
             }
 #pragma unroll
             for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns)
-                    acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[ms], bq_hi[slot][ns], acc[ms][ns]);
+                    acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[cur][ms], bq_hi[slot][ns], acc[ms][ns]);
             __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -366,12 +385,13 @@ static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in
 }
 
 // ---- host-side plan (same objective as the f32 planner; limits: 64 KiB LDS, 2 workgroups per CU) ----
-struct TileCfgB { int MT, NTILE, WM, wg_per_cu; };
-constexpr int kNumCfgB = 3;
+struct TileCfgB { int MT, NTILE, WM, wg_per_cu, NTHR; };
+constexpr int kNumCfgB = 4;
 constexpr TileCfgB kCfgB[kNumCfgB] = {
-    {128, 64, 2, 3},      // <KS,2,1,2,2>
-    {160, 128, 1, 2},     // <KS,5,1,1,4>
-    {256, 64, 2, 2},      // <KS,4,1,2,2>
+    {128, 64, 2, 3, 256},      // <KS,2,1,2,2>
+    {160, 128, 1, 2, 256},     // <KS,5,1,1,4>
+    {256, 64, 2, 2, 256},      // <KS,4,1,2,2>
+    {160, 128, 1, 2, 128},     // <3,5,2,1,2>: two waves, 160x64 register tile each, one wave per SIMD (3x3 only)
 };
 
 struct PlanB {
@@ -393,11 +413,13 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
     DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 31), DS_ERR_BAD_SHAPE);
     const int IS = s->stride;
+    const bool big_tile_ok = x3;                 // the 2-wave shape is tuned for (and only built for) bf16x3
     double best = -1.0;
     int bc = -1, brt = 0, bni = 0;
     for (int c = 0; c < kNumCfgB; ++c) {
         const TileCfgB &cf = kCfgB[c];
         if (s->Cout % cf.NTILE) continue;
+        if (c == 3 && (s->KS != 3 || !big_tile_ok)) continue;
         for (int rt = 1; rt <= Ho; ++rt) {
             if ((long long)rt * Wo > cf.MT) break;
             const int segs_per_img = ds_ceil_div(Ho, rt);
@@ -405,29 +427,21 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
             int ni = cf.MT / (rt * Wo);
             if (ni > n_segs) ni = (int)n_segs;
             const int rows_in = IS * (rt - 1) + s->KS, cols_in = IS * (Wo - 1) + s->KS;
-            // conflict-avoiding row pitch for this geometry (at most 4 padding records per row)
-            auto pitch_of = [&](int n) {
-                int bp = cols_in;
-                double bc2 = 1e30;
-                for (int pt = cols_in; pt <= cols_in + 4; ++pt) {
-                    const double c2 = frag_read_cost(cf.MT, n, rt, Wo, IS, rows_in, pt);
-                    if (c2 < bc2 - 1e-9) { bc2 = c2; bp = pt; }
-                }
-                return bp;
-            };
+            // feasibility with the widest row pitch the conflict search may pick (cols_in + 4); the pitch
+            // itself is chosen once, for the winning geometry (this function runs on every launch)
             auto lds_of = [&](int n) {
-                const size_t tp = (size_t)n * rows_in * pitch_of(n);
+                const size_t tp = (size_t)n * rows_in * (cols_in + 4);
                 return tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
             };
-            auto items_of = [&](int n) { return (long long)n * rows_in * pitch_of(n) * (CKB / 4); };
-            while (ni > 1 && (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * 256)) --ni;
-            if (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * 256) continue;
+            auto items_of = [&](int n) { return (long long)n * rows_in * (cols_in + 4) * (CKB / 4); };
+            while (ni > 1 && (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * cf.NTHR)) --ni;
+            if (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * cf.NTHR) continue;
             const long long n_mt = ds_ceil_div_ll(n_segs, ni);
             double eff = (double)s->B * Ho * Wo / ((double)n_mt * cf.MT);
             const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * cf.wg_per_cu;
             if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
             else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
-            eff += 1e-9 * rt + 1e-6 * (c == 1 ? 2 : (c == 2 ? 1 : 0));
+            eff += 1e-9 * rt + 1e-6 * (c == 3 ? 3 : (c == 1 ? 2 : (c == 2 ? 1 : 0)));
             if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; }
         }
     }
@@ -458,7 +472,7 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     pl.grid = pl.n_mtiles * k.n_ntiles;
     const size_t tp = (size_t)k.NI * k.seg_pix;
     pl.lds_bytes = tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8 + 16;
-    pl.nit = ds_ceil_div((int)tp * (CKB / 4), 256);
+    pl.nit = ds_ceil_div((int)tp * (CKB / 4), cf.NTHR);
     return DS_OK;
 }
 
@@ -476,7 +490,13 @@ template <int KS, bool X3>
 static void launch_b(const PlanB &pl, void *stream) {
     if (pl.cfg == 0) launch_nit_b<KS, 2, 1, 2, 2, X3>(pl, stream);
     else if (pl.cfg == 1) launch_nit_b<KS, 5, 1, 1, 4, X3>(pl, stream);
-    else launch_nit_b<KS, 4, 1, 2, 2, X3>(pl, stream);
+    else if (pl.cfg == 2) launch_nit_b<KS, 4, 1, 2, 2, X3>(pl, stream);
+    else if constexpr (KS == 3 && X3) {         // 2-wave shape: 128 threads, prefetch always fits
+        if (pl.nit <= 8)
+            DS_LAUNCH((conv_mfma_bf16_kernel<3, 5, 2, 1, 2, true, 8, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
+        else
+            DS_LAUNCH((conv_mfma_bf16_kernel<3, 5, 2, 1, 2, true, 16, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
+    }
 }
 
 }  // namespace

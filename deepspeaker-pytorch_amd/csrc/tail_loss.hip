@@ -221,103 +221,101 @@ __global__ void __launch_bounds__(256) avgpool_time_bwd_kernel(const float *gpoo
 //      reference only filters pre-sampled triplets).  For anchor i: among candidates j with
 //      cand_label[j] != anchor_label[i], the closest one that is farther than d_p[i]; if none is
 //      semi-hard, the closest overall; ties -> lowest j; -1 when every candidate shares the label.
-//      A workgroup owns 8 anchors (rows in LDS) and walks the candidates 256 at a time, one candidate
-//      per thread: 32-dimension slabs of the candidate tile are staged through LDS (coalesced 128-byte
-//      rows in, conflict-free padded columns out), so every candidate element is read from L2 once per
-//      8 anchors and the anchor values are LDS broadcasts.  Fixed scan / reduction order => deterministic.
+//      A workgroup owns 8 anchors (rows in LDS) x one tile of 256 candidates, one candidate per thread:
+//      32-dimension slabs of the candidate tile are staged through LDS (coalesced 128-byte rows in,
+//      conflict-free padded columns out), so every candidate element is read from L2 once per 8 anchors
+//      and the anchor values are LDS broadcasts.  Per-tile winners go to a workspace; a second kernel
+//      folds the tiles in ascending order.  Fixed scan / reduction order => deterministic.
 constexpr int MINE_A = 8;          // anchors per workgroup
 constexpr int MINE_K = 32;         // dimensions per staged slab
+constexpr int MINE_C = 256;        // candidates per workgroup
 
 __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor, const float *d_p,
                                                             const long long *anchor_label, const float *cand,
-                                                            const long long *cand_label, long long *out, float *out_d,
-                                                            int N, int M, int D, float eps) {
+                                                            const long long *cand_label, float *partial,
+                                                            int N, int M, int D, float eps, int n_agroups) {
     float *lds = ds_dynamic_lds();
     float *arow = lds;                                     // [MINE_A][D]
     float *ctile = arow + MINE_A * D;                      // [256][MINE_K + 1]
-    // the final reduction scratch aliases the candidate tile (dead by then): 2 x [2][MINE_A][256] words
+    // the reduction scratch aliases the candidate tile (dead by then): 2 x [2][MINE_A][256] words
     float *red_d = ctile;
     int *red_j = (int *)(ctile + 2 * MINE_A * 256);
     const int tid = threadIdx.x;
-    const int a0 = blockIdx.x * MINE_A;
+    const int ag = blockIdx.x % n_agroups, ct = blockIdx.x / n_agroups;
+    const int a0 = ag * MINE_A, j0 = ct * MINE_C;
     for (int i = tid; i < MINE_A * D; i += 256) {
         const int a = i / D;
         arow[i] = (a0 + a < N) ? anchor[(size_t)(a0 + a) * D + (i - a * D)] : 0.0f;
     }
-    float dpv[MINE_A];
-    long long lab[MINE_A];
+    float accd[MINE_A];
+#pragma unroll
+    for (int a = 0; a < MINE_A; ++a) accd[a] = 0.0f;
+    for (int k0 = 0; k0 < D; k0 += MINE_K) {
+        __syncthreads();
+        // stage candidates j0..j0+255, dims k0..k0+31: 8 threads cover one 128-byte row segment
+        for (int i = tid; i < MINE_C * (MINE_K / 4); i += 256) {
+            const int row = i / (MINE_K / 4), q = i - row * (MINE_K / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < M && k0 + q * 4 < D) v = *(const f32x4 *)(cand + (size_t)(j0 + row) * D + k0 + q * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ctile[row * (MINE_K + 1) + q * 4 + u] = v[u];
+        }
+        __syncthreads();
+        const int kmax = (D - k0) < MINE_K ? (D - k0) : MINE_K;
+        for (int k = 0; k < kmax; ++k) {
+            const float c = ctile[tid * (MINE_K + 1) + k];
+#pragma unroll
+            for (int a = 0; a < MINE_A; ++a) {
+                const float df = fabsf(arow[a * D + k0 + k] - c);
+                accd[a] += df * df;
+            }
+        }
+    }
+    __syncthreads();
+    const int j = j0 + tid;
+    const long long lc = j < M ? cand_label[j] : 0;
 #pragma unroll
     for (int a = 0; a < MINE_A; ++a) {
         const int ai = a0 + a < N ? a0 + a : N - 1;
-        dpv[a] = d_p[ai];
-        lab[a] = anchor_label[ai];
-    }
-    float best_semi[MINE_A], best_any[MINE_A];
-    int j_semi[MINE_A], j_any[MINE_A];
-#pragma unroll
-    for (int a = 0; a < MINE_A; ++a) {
-        best_semi[a] = 3.0e38f; best_any[a] = 3.0e38f;
-        j_semi[a] = -1; j_any[a] = -1;
-    }
-    for (int j0 = 0; j0 < M; j0 += 256) {
-        float accd[MINE_A];
-#pragma unroll
-        for (int a = 0; a < MINE_A; ++a) accd[a] = 0.0f;
-        for (int k0 = 0; k0 < D; k0 += MINE_K) {
-            __syncthreads();
-            // stage candidates j0..j0+255, dims k0..k0+31: 8 threads cover one 128-byte row segment
-            for (int i = tid; i < 256 * (MINE_K / 4); i += 256) {
-                const int row = i / (MINE_K / 4), q = i - row * (MINE_K / 4);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (j0 + row < M && k0 + q * 4 < D) v = *(const f32x4 *)(cand + (size_t)(j0 + row) * D + k0 + q * 4);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) ctile[row * (MINE_K + 1) + q * 4 + u] = v[u];
-            }
-            __syncthreads();
-            const int kmax = (D - k0) < MINE_K ? (D - k0) : MINE_K;
-            for (int k = 0; k < kmax; ++k) {
-                const float c = ctile[tid * (MINE_K + 1) + k];
-#pragma unroll
-                for (int a = 0; a < MINE_A; ++a) {
-                    const float df = fabsf(arow[a * D + k0 + k] - c);
-                    accd[a] += df * df;
-                }
-            }
-        }
-        const int j = j0 + tid;
-        if (j < M) {
-            const long long lc = cand_label[j];
-#pragma unroll
-            for (int a = 0; a < MINE_A; ++a) {
-                const float d = sqrtf(accd[a] + eps);
-                if (lc != lab[a]) {
-                    if (d < best_any[a]) { best_any[a] = d; j_any[a] = j; }
-                    if (d > dpv[a] && d < best_semi[a]) { best_semi[a] = d; j_semi[a] = j; }
-                }
-            }
-        }
+        const float d = sqrtf(accd[a] + eps);
+        const bool other = j < M && lc != anchor_label[ai];
+        const bool semi = other && d > d_p[ai];
+        red_d[(0 * MINE_A + a) * 256 + tid] = semi ? d : 3.0e38f;  red_j[(0 * MINE_A + a) * 256 + tid] = semi ? j : -1;
+        red_d[(1 * MINE_A + a) * 256 + tid] = other ? d : 3.0e38f; red_j[(1 * MINE_A + a) * 256 + tid] = other ? j : -1;
     }
     __syncthreads();
-#pragma unroll
-    for (int a = 0; a < MINE_A; ++a) {
-        red_d[(0 * MINE_A + a) * 256 + tid] = best_semi[a]; red_j[(0 * MINE_A + a) * 256 + tid] = j_semi[a];
-        red_d[(1 * MINE_A + a) * 256 + tid] = best_any[a];  red_j[(1 * MINE_A + a) * 256 + tid] = j_any[a];
-    }
-    __syncthreads();
-    if (tid < MINE_A && a0 + tid < N) {                    // one thread per anchor folds the 256 candidates-lanes
-        const int a = tid;
-        float bs = 3.0e38f, ba = 3.0e38f;
-        int js = -1, ja = -1;
-        for (int t = 0; t < 256; ++t) {
-            const float ds_ = red_d[(0 * MINE_A + a) * 256 + t], da = red_d[(1 * MINE_A + a) * 256 + t];
-            const int s_j = red_j[(0 * MINE_A + a) * 256 + t], a_j = red_j[(1 * MINE_A + a) * 256 + t];
-            if (s_j >= 0 && (ds_ < bs || (ds_ == bs && s_j < js))) { bs = ds_; js = s_j; }
-            if (a_j >= 0 && (da < ba || (da == ba && a_j < ja))) { ba = da; ja = a_j; }
+    if (tid < 2 * MINE_A) {                                // one thread per (criterion, anchor) folds the tile
+        const int a = tid % MINE_A, crit = tid / MINE_A;
+        if (a0 + a < N) {
+            float bd = 3.0e38f;
+            int bj = -1;
+            for (int t = 0; t < 256; ++t) {                // ascending j: strict < keeps the lowest index on ties
+                const float dd = red_d[(crit * MINE_A + a) * 256 + t];
+                const int jj = red_j[(crit * MINE_A + a) * 256 + t];
+                if (jj >= 0 && dd < bd) { bd = dd; bj = jj; }
+            }
+            float *dst = partial + (((size_t)ct * N) + a0 + a) * 4 + crit * 2;
+            dst[0] = bd;
+            dst[1] = __int_as_float(bj);
         }
-        const int jj = js >= 0 ? js : ja;
-        out[a0 + a] = jj;
-        if (out_d) out_d[a0 + a] = js >= 0 ? bs : (ja >= 0 ? ba : 0.0f);
     }
+}
+
+// fold the candidate tiles in ascending order; semi-hard winner if any, else the closest other-speaker one
+__global__ void __launch_bounds__(256) mine_merge_kernel(const float *partial, long long *out, float *out_d, int N,
+                                                         int n_ctiles) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float bs = 3.0e38f, ba = 3.0e38f;
+    int js = -1, ja = -1;
+    for (int ct = 0; ct < n_ctiles; ++ct) {
+        const float *src = partial + ((size_t)ct * N + i) * 4;
+        const int s_j = __float_as_int(src[1]), a_j = __float_as_int(src[3]);
+        if (s_j >= 0 && src[0] < bs) { bs = src[0]; js = s_j; }
+        if (a_j >= 0 && src[2] < ba) { ba = src[2]; ja = a_j; }
+    }
+    out[i] = js >= 0 ? js : ja;
+    if (out_d) out_d[i] = js >= 0 ? bs : (ja >= 0 ? ba : 0.0f);
 }
 
 // dst[i,:] = src[idx[i],:]  (idx < 0 -> zeros)
@@ -357,18 +355,28 @@ extern "C" int ds_scatter_add_rows_f32(const float *g, const long long *idx, flo
     return ds_last_launch_error();
 }
 
+extern "C" long long ds_mine_workspace_floats(int N, int M) {
+    if (N <= 0 || M <= 0) return DS_ERR_BAD_SHAPE;
+    return (long long)ds_ceil_div(M, MINE_C) * N * 4;
+}
+
 extern "C" int ds_mine_semihard_f32(const float *anchor, const float *d_p, const long long *anchor_label,
-                                    const float *cand, const long long *cand_label, long long *out_index,
-                                    float *out_dist, int N, int M, int D, void *stream) {
-    DS_REQUIRE(anchor && d_p && anchor_label && cand && cand_label && out_index, DS_ERR_NULL);
+                                    const float *cand, const long long *cand_label, float *workspace,
+                                    long long *out_index, float *out_dist, int N, int M, int D, void *stream) {
+    DS_REQUIRE(anchor && d_p && anchor_label && cand && cand_label && workspace && out_index, DS_ERR_NULL);
     DS_REQUIRE(N > 0 && M > 0 && D > 0 && D <= 8192, DS_ERR_BAD_SHAPE);
-    const float eps = (float)(1e-4 / (double)D);
     DS_REQUIRE(D % 4 == 0 && DS_ALIGNED16(cand), DS_ERR_ALIGNMENT);
+    const float eps = (float)(1e-4 / (double)D);
     const size_t tile_words = 256 * (MINE_K + 1) > 4 * MINE_A * 256 ? 256 * (MINE_K + 1) : 4 * MINE_A * 256;
     const size_t lds = ((size_t)MINE_A * D + tile_words) * 4;
     DS_REQUIRE(lds <= 64 * 1024, DS_ERR_BAD_SHAPE);
-    DS_LAUNCH(mine_semihard_kernel, ds_ceil_div(N, MINE_A), 256, lds, stream, anchor, d_p, anchor_label, cand,
-              cand_label, out_index, out_dist, N, M, D, eps);
+    const int n_agroups = ds_ceil_div(N, MINE_A), n_ctiles = ds_ceil_div(M, MINE_C);
+    DS_LAUNCH(mine_semihard_kernel, n_agroups * n_ctiles, 256, lds, stream, anchor, d_p, anchor_label, cand,
+              cand_label, workspace, N, M, D, eps, n_agroups);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(mine_merge_kernel, ds_ceil_div(N, 256), 256, 0, stream, (const float *)workspace, out_index, out_dist, N,
+              n_ctiles);
     return ds_last_launch_error();
 }
 

@@ -152,8 +152,10 @@ def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, redu
             gathered, glab = loc, lab
         d_p = eng.pairwise_distance(ea, ep)
         mined = torch.empty(n_loc, dtype=torch.int64, device=ea.device)
+        mws = torch.empty(lib.raw("ds_mine_workspace_floats")(n_loc, gathered.shape[0]), dtype=torch.float32,
+                          device=ea.device)
         lib.call("ds_mine_semihard_f32", eng._p(ea), eng._p(d_p), eng._p(c1.to(torch.int64).contiguous()),
-                 eng._p(gathered), eng._p(glab), eng._p(mined), None, n_loc, gathered.shape[0], d, st)
+                 eng._p(gathered), eng._p(glab), eng._p(mws), eng._p(mined), None, n_loc, gathered.shape[0], d, st)
         en_used = torch.empty_like(en)
         lib.call("ds_gather_rows_f32", eng._p(gathered), eng._p(mined), eng._p(en_used), n_loc, d, st)
     else:

@@ -281,6 +281,109 @@ class Engine:
             saved.pooled, saved.fc_out = pooled, f
         return e
 
+    # ------------------------------------------------------------------ cached launch plan (eval)
+    def _build_eval_plan(self, x, pw: PackedWeights, folded, precision: str):
+        """Everything that does not change between two eval forwards of the same shape -- tile plans are
+        recomputed inside the library anyway, but the Python side of a launch (shape structs, pointer
+        objects, activation buffers, the stream handle lookup) costs more than the launch itself at
+        ~100k embeddings/s.  The plan owns the intermediate activations (re-used by the next call on the
+        same stream); input, output and stream are patched into three mutable ctypes slots per call."""
+        B, _, T, F = x.shape
+        dev = x.device
+        lowp = precision != "f32"
+        x3 = precision == "bf16x3"
+        x_slot, e_slot, st_slot = ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_void_p(0)
+        calls = []            # (raw function, argument tuple, profile label or None, flops)
+        keep = []             # tensors / structs the argument tuples point into
+        AC = DS_EPI_AFFINE | DS_EPI_CLIP
+
+        def buf(*shape):
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+            keep.append(t)
+            return t
+
+        def conv_call(src_p, w_f32, w_bf16, Bc, h, w, cin, cout, ks, stride, sc, sh, res):
+            shp = ConvShape(Bc, h, w, cin, cout, ks, stride)
+            keep.append(shp)
+            ho, wo = conv_out(h, ks, stride), conv_out(w, ks, stride)
+            y = buf(Bc, ho, wo, cout)
+            flags = AC | (DS_EPI_RESIDUAL if res is not None else 0)
+            label = f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}"
+            flops = 2.0 * Bc * ho * wo * cout * cin * ks * ks
+            if lowp:
+                args = (ctypes.byref(shp), src_p, self._p(w_bf16[0]), self._p(w_bf16[1]) if x3 else None,
+                        self._p(sc), self._p(sh), self._p(res), self._p(y), None, flags, st_slot)
+                calls.append((self.lib.raw("ds_conv_fwd_bf16"), args, label, flops))
+            else:
+                args = (ctypes.byref(shp), src_p, self._p(w_f32), self._p(sc), self._p(sh), self._p(res), self._p(y),
+                        None, flags, st_slot)
+                calls.append((self.lib.raw("ds_conv_fwd_f32"), args, label, flops))
+            return y, ho, wo
+
+        h, w, cin = T, F, 1
+        a = None
+        for s, sw in enumerate(pw.stages):
+            i, c = s + 1, STAGE_CHANNELS[s]
+            sc, sh = folded[f"model.bn{i}"]
+            if i == 1:
+                ho, wo = conv_out(h, 5, 2), conv_out(w, 5, 2)
+                a = buf(B, ho, wo, 64)
+                calls.append((self.lib.raw("ds_conv5x5s2_c1_fwd_f32"),
+                              (x_slot, self._p(sw.conv), self._p(sc), self._p(sh), self._p(a), None, B, h, w, 64, AC,
+                               st_slot), None, 0.0))
+                h, w = ho, wo
+            else:
+                a, h, w = conv_call(self._p(a), sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2, sc, sh, None)
+            cin = c
+            sc, sh = folded[f"model.layer{i}.0.bn1"]
+            y, _, _ = conv_call(self._p(a), sw.l_conv1, sw.l_conv1_bf16, B, h, w, c, c, 3, 1, sc, sh, None)
+            sc, sh = folded[f"model.layer{i}.0.bn2"]
+            a, _, _ = conv_call(self._p(y), sw.l_conv2, sw.l_conv2_bf16, B, h, w, c, c, 3, 1, sc, sh, a)
+        k = w * cin
+        n_out = pw.fc_bias.numel()
+        pooled = buf(B, k)
+        calls.append((self.lib.raw("ds_avgpool_time_f32"), (self._p(a), self._p(pooled), B, h, w, cin, st_slot), None, 0.0))
+        ws_floats = self.lib.raw("ds_fc_workspace_floats")(B, k, n_out)
+        if ws_floats <= 0:
+            raise RuntimeError(f"ds_fc_workspace_floats({B},{k},{n_out}) failed: {ws_floats}")
+        ws, f = buf(ws_floats), buf(B, n_out)
+        calls.append((self.lib.raw("ds_fc_l2norm_fwd_f32"),
+                      (self._p(pooled), self._p(pw.fc), self._p(pw.fc_bias.detach()), self._p(ws), self._p(f), e_slot, B,
+                       k, n_out, ALPHA, L2_EPS, st_slot), None, 0.0))
+        keep += [pw, folded]
+        return {"calls": calls, "keep": keep, "x": x_slot, "e": e_slot, "st": st_slot, "n_out": n_out}
+
+    def forward_eval_planned(self, x: torch.Tensor, pw: PackedWeights, folded, precision: str = "f32") -> torch.Tensor:
+        """forward_eval through a launch plan cached per (shape, weights version, precision, device)."""
+        self._check(x, "input")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError("input must be [B,1,T,F] (reference model.py:185, SURVEY F1)")
+        if precision != "f32" and pw.stages[0].l_conv1_bf16 is None:
+            raise ValueError("pack_weights(..., with_bf16=True) is required for the bf16 precisions")
+        key = (tuple(x.shape), precision, id(pw), id(folded), x.device)
+        plans = self.__dict__.setdefault("_eval_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            if len(plans) > 16:
+                plans.clear()
+            plan = plans[key] = self._build_eval_plan(x, pw, folded, precision)
+        e = torch.empty((x.shape[0], plan["n_out"]), dtype=torch.float32, device=x.device)
+        plan["x"].value, plan["e"].value = x.data_ptr(), e.data_ptr()
+        plan["st"].value = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else None
+        prof = self.profile if (self.profile is not None and x.is_cuda) else None
+        for fn, args, label, flops in plan["calls"]:
+            if prof is not None and label is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                rc = fn(*args)
+                ev1.record()
+                prof.append((label, flops, ev0, ev1))
+            else:
+                rc = fn(*args)
+            if rc != 0:
+                raise RuntimeError(f"{fn.__name__} failed: {rc} ({self.lib.error_string(rc)})")
+        return e
+
     # ------------------------------------------------------------------ forward passes
     def forward_eval(self, x: torch.Tensor, pw: PackedWeights, folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]],
                      taps: Optional[dict] = None, precision: str = "f32") -> torch.Tensor:

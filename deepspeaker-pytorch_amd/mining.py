@@ -62,7 +62,8 @@ def mine_semihard_negatives(anchors: torch.Tensor, positives: torch.Tensor, anch
     n, d = a.shape
     idx = torch.empty(n, dtype=torch.int64, device=a.device)
     dist_out = torch.empty(n, dtype=torch.float32, device=a.device)
+    ws = torch.empty(eng.lib.raw("ds_mine_workspace_floats")(n, c.shape[0]), dtype=torch.float32, device=a.device)
     eng.lib.call("ds_mine_semihard_f32", eng._p(a), eng._p(d_p), eng._p(anchor_labels.to(torch.int64).contiguous()),
-                 eng._p(c), eng._p(candidate_labels.to(torch.int64).contiguous()), eng._p(idx), eng._p(dist_out),
-                 n, c.shape[0], d, eng._stream(a))
+                 eng._p(c), eng._p(candidate_labels.to(torch.int64).contiguous()), eng._p(ws), eng._p(idx),
+                 eng._p(dist_out), n, c.shape[0], d, eng._stream(a))
     return idx, dist_out

@@ -429,8 +429,8 @@ class DeepSpeakerModel(nn.Module):
                 self.features = e
         else:
             lowp = self.precision != "f32"
-            self.features = get_engine().forward_eval(x, self._packed(with_bf16=lowp), self._folded(),
-                                                      precision=self.precision)
+            self.features = get_engine().forward_eval_planned(x, self._packed(with_bf16=lowp), self._folded(),
+                                                              precision=self.precision)
         return self.features
 
     def forward_classifier(self, x):

@@ -204,9 +204,10 @@ int ds_scatter_add_rows_f32(const float *g, const long long *idx, float *dst, in
 
 /* ---- cross-GPU semi-hard negative search over an all-gathered candidate set (north_star; no
  *      reference counterpart).  out_index[i] in [0,M) or -1; out_dist may be NULL. ---- */
+long long ds_mine_workspace_floats(int N, int M);
 int ds_mine_semihard_f32(const float *anchor, const float *d_p, const long long *anchor_label,
-                         const float *cand, const long long *cand_label, long long *out_index,
-                         float *out_dist, int N, int M, int D, void *stream);
+                         const float *cand, const long long *cand_label, float *workspace,
+                         long long *out_index, float *out_dist, int N, int M, int D, void *stream);
 
 /* ---- backward of the loss side and the tail (torch autograd of the lines cited above; the
  *      reference obtains them from loss.backward(), train_triplet.py:223,290) ------------------- */

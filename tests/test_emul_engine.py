@@ -247,3 +247,21 @@ def test_classifier_head_and_cross_entropy(golden):
     # the reference-recorded CE value
     l2 = _CrossEntropyFn.apply(torch.from_numpy(golden["ce_logits"]), torch.from_numpy(golden["ce_labels"]), eng)
     assert abs(float(l2) - float(golden["ce_value"])) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_planned_eval_forward_equals_unplanned(precision):
+    """The cached launch plan must be the same computation as the step-by-step forward, call after call
+    (buffers are re-used) and across shapes."""
+    eng = Engine(emul_lib())
+    n_stages = 2
+    sd = O.make_state_dict(seed=19, num_classes=4, n_stages=n_stages)
+    tsd = torch_sd(sd)
+    pw = eng.pack_weights(tsd, n_stages, with_bf16=True)
+    folded = {n: eng.bn_fold(b) for n, b in make_bns(tsd, n_stages).items()}
+    for seed, (B, T) in enumerate([(2, 24), (3, 17), (2, 24)]):
+        x = torch.from_numpy(O.make_input(seed=seed, batch=B, frames=T))
+        e1 = eng.forward_eval(x, pw, folded, precision=precision)
+        e2 = eng.forward_eval_planned(x, pw, folded, precision=precision)
+        e3 = eng.forward_eval_planned(x, pw, folded, precision=precision)
+        assert torch.equal(e1, e2) and torch.equal(e2, e3)

@@ -276,7 +276,8 @@ def test_mine_semihard(N, M):
     out = aligned(N, np.int64)
     outd = aligned(N, fill=np.nan)
     la_a, lc_a, dp_a = to_aligned(la, np.int64), to_aligned(lc, np.int64), to_aligned(d_p)
-    lib.call("ds_mine_semihard_f32", ptr(a), ptr(dp_a), ptr(la_a), ptr(cand), ptr(lc_a), ptr(out), ptr(outd),
+    ws = aligned(lib.raw("ds_mine_workspace_floats")(N, M), fill=np.nan)
+    lib.call("ds_mine_semihard_f32", ptr(a), ptr(dp_a), ptr(la_a), ptr(cand), ptr(lc_a), ptr(ws), ptr(out), ptr(outd),
              N, M, 512, None)
     ref = O.mine_semihard(a, d_p, la, cand, lc)
     np.testing.assert_array_equal(out, ref)
