@@ -391,7 +391,7 @@ constexpr TileCfgB kCfgB[kNumCfgB] = {
     {128, 64, 2, 3, 256},      // <KS,2,1,2,2>
     {160, 128, 1, 2, 256},     // <KS,5,1,1,4>
     {256, 64, 2, 2, 256},      // <KS,4,1,2,2>
-    {160, 128, 1, 2, 128},     // <3,5,2,1,2>: two waves, 160x64 register tile each, one wave per SIMD (3x3 only)
+    {160, 128, 1, 2, 128},     // <KS,5,2,1,2>: two waves, 160x64 register tile each, one wave per SIMD; up to 80 KiB LDS
 };
 
 struct PlanB {
@@ -419,7 +419,9 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     for (int c = 0; c < kNumCfgB; ++c) {
         const TileCfgB &cf = kCfgB[c];
         if (s->Cout % cf.NTILE) continue;
-        if (c == 3 && (s->KS != 3 || !big_tile_ok)) continue;
+        if (c == 3 && !big_tile_ok) continue;
+        const size_t lds_cap = c == 3 ? 80 * 1024 : 64 * 1024;       // two workgroups of the 2-wave shape per CU
+        const long long item_cap = c == 3 ? 32 * cf.NTHR : 16 * cf.NTHR;
         for (int rt = 1; rt <= Ho; ++rt) {
             if ((long long)rt * Wo > cf.MT) break;
             const int segs_per_img = ds_ceil_div(Ho, rt);
@@ -434,8 +436,8 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
                 return tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
             };
             auto items_of = [&](int n) { return (long long)n * rows_in * (cols_in + 4) * (CKB / 4); };
-            while (ni > 1 && (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * cf.NTHR)) --ni;
-            if (lds_of(ni) > 64 * 1024 || items_of(ni) > 16 * cf.NTHR) continue;
+            while (ni > 1 && (lds_of(ni) > lds_cap || items_of(ni) > item_cap)) --ni;
+            if (lds_of(ni) > lds_cap || items_of(ni) > item_cap) continue;
             const long long n_mt = ds_ceil_div_ll(n_segs, ni);
             double eff = (double)s->B * Ho * Wo / ((double)n_mt * cf.MT);
             const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * cf.wg_per_cu;
@@ -491,11 +493,13 @@ static void launch_b(const PlanB &pl, void *stream) {
     if (pl.cfg == 0) launch_nit_b<KS, 2, 1, 2, 2, X3>(pl, stream);
     else if (pl.cfg == 1) launch_nit_b<KS, 5, 1, 1, 4, X3>(pl, stream);
     else if (pl.cfg == 2) launch_nit_b<KS, 4, 1, 2, 2, X3>(pl, stream);
-    else if constexpr (KS == 3 && X3) {         // 2-wave shape: 128 threads, prefetch always fits
+    else if constexpr (X3) {                    // 2-wave shape: 128 threads, up to 80 KiB of LDS per workgroup
         if (pl.nit <= 8)
-            DS_LAUNCH((conv_mfma_bf16_kernel<3, 5, 2, 1, 2, true, 8, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
+            DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, 5, 2, 1, 2, true, 8, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
+        else if (pl.nit <= 16)
+            DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, 5, 2, 1, 2, true, 16, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
         else
-            DS_LAUNCH((conv_mfma_bf16_kernel<3, 5, 2, 1, 2, true, 16, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
+            DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, 5, 2, 1, 2, true, 32, false>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
     }
 }
 

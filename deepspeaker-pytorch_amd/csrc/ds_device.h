@@ -40,6 +40,16 @@ __device__ __forceinline__ float *ds_dynamic_lds() {
 #define DS_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__)
 
+// Launch with more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU): the per-kernel
+// opt-in is set once per process (immutable function attribute, not launch state).
+#define DS_LAUNCH_BIG_LDS(kernel, grid, block, lds_bytes, stream, ...)                                          \
+    do {                                                                                                         \
+        static const hipError_t ds_attr_rc_ = hipFuncSetAttribute(                                               \
+            (const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
+        (void)ds_attr_rc_;                                                                                       \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__);    \
+    } while (0)
+
 static inline int ds_last_launch_error() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -81,4 +81,7 @@ static inline float *ds_dynamic_lds() { return emu::dynamic_lds(); }
 #define DS_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
     emu::launch((int)(grid), (int)(block), (size_t)(lds_bytes), [=]() { kernel(__VA_ARGS__); })
 
+#define DS_LAUNCH_BIG_LDS(kernel, grid, block, lds_bytes, stream, ...) \
+    emu::launch((int)(grid), (int)(block), (size_t)(lds_bytes), [=]() { kernel(__VA_ARGS__); }, true)
+
 static inline int ds_last_launch_error() { return 0; }

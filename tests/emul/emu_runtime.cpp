@@ -39,7 +39,8 @@ namespace {
 
 constexpr size_t kStack = 256 * 1024;
 constexpr int kMaxThreads = 1024;
-constexpr size_t kLdsBytes = 64 * 1024;   // the default dynamic-LDS launch limit (no kernel here raises it)
+constexpr size_t kLdsBytes = 64 * 1024;        // the default dynamic-LDS launch limit
+constexpr size_t kLdsBytesBig = 160 * 1024;    // with the per-kernel opt-in (DS_LAUNCH_BIG_LDS)
 
 struct Fiber {
     void *sp = nullptr;
@@ -157,8 +158,8 @@ void wave_exchange(float mine, float *all64) {
     memcpy(all64, wv.buf[gen & 1], sizeof(float) * 64);
 }
 
-void launch(int grid, int block, size_t lds_bytes, const std::function<void()> &body) {
-    if (block <= 0 || block > kMaxThreads || (block & 63) || lds_bytes > kLdsBytes || grid <= 0) {
+void launch(int grid, int block, size_t lds_bytes, const std::function<void()> &body, bool big_lds) {
+    if (block <= 0 || block > kMaxThreads || (block & 63) || lds_bytes > (big_lds ? kLdsBytesBig : kLdsBytes) || grid <= 0) {
         fprintf(stderr, "emu: bad launch grid=%d block=%d lds=%zu\n", grid, block, lds_bytes);
         abort();
     }
@@ -168,7 +169,7 @@ void launch(int grid, int block, size_t lds_bytes, const std::function<void()> &
     std::atomic<int> next{0};
     auto work = [&]() {
         Worker *w = new Worker();
-        w->lds = (char *)aligned_alloc(64, kLdsBytes);
+        w->lds = (char *)aligned_alloc(64, kLdsBytesBig);
         w->body = &body;
         g_w = w;
         for (;;) {

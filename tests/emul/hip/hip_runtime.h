@@ -28,7 +28,7 @@ struct Idx {
 };
 void syncthreads();
 float *dynamic_lds();
-void launch(int grid, int block, size_t lds_bytes, const std::function<void()> &body);
+void launch(int grid, int block, size_t lds_bytes, const std::function<void()> &body, bool big_lds = false);
 // wavefront collectives (64 lanes)
 void wave_exchange(float mine, float *all64);          // all64[l] = lane l's `mine`
 }  // namespace emu
