@@ -60,15 +60,22 @@ def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0):
     return gw
 
 
-def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad):
+def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad, w_dgrad_bf16=None):
     gx = torch.empty((shp.B, shp.H, shp.W, shp.Cin), dtype=torch.float32, device=gz.device)
+    if w_dgrad_bf16 is not None:       # bf16x3 data gradient (3x3 stride 1)
+        eng.lib.call("ds_conv_dgrad_bf16", ctypes.byref(shp), eng._p(gz), eng._p(w_dgrad_bf16[0]),
+                     eng._p(w_dgrad_bf16[1]), eng._p(gx), eng._stream(gz))
+        return gx
     eng.lib.call("ds_conv_dgrad_f32", ctypes.byref(shp), eng._p(gz), eng._p(w_dgrad), eng._p(gx), eng._stream(gz))
     return gx
 
 
 def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
-                   ge: torch.Tensor, reducer=None) -> Dict[str, torch.Tensor]:
-    """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512]."""
+                   ge: torch.Tensor, reducer=None, precision: str = "f32") -> Dict[str, torch.Tensor]:
+    """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512].
+    precision "bf16x3": the 3x3 data gradients run on the bf16 matrix cores with split operands; filter
+    gradients and the 5x5 stride-2 data gradients stay on the f32 matrix cores."""
+    x3 = precision == "bf16x3"
     lib = eng.lib
     grads: Dict[str, torch.Tensor] = {}
     n_stages = len(pw.stages)
@@ -109,13 +116,13 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
                                        saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3))
-        g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad)
+        g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad, pw.stages[s].l_conv2_dgrad_bf16 if x3 else None)
         # y = clip(bn1(conv1(r)))                  (model.py:69-71)
         name = f"model.layer{i}.0.bn1"
         _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3))
-        g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad)
+        g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad, pw.stages[s].l_conv1_dgrad_bf16 if x3 else None)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv-path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
         _, gz, gg, gbeta = _bn_bwd(eng, g_r, g_out, a_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)

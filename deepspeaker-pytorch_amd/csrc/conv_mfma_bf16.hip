@@ -336,20 +336,24 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
 }
 
 // OIHW f32 -> [Cin/16][tap][Cout][16] bf16 hi (+ lo = bf16(w - hi))
+// dgrad != 0: the transposed, spatially flipped bank of the stride-1 data gradient (N = Cin, K = Cout)
 __global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float *w, __bf16 *hi, __bf16 *lo, int Cout,
-                                                                    int Cin, int KS) {
+                                                                    int Cin, int KS, int dgrad) {
     const int T = KS * KS;
     const long long n = (long long)Cout * Cin * T;
+    const int N = dgrad ? Cin : Cout;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int kk = (int)(i & 15);
         long long r = i >> 4;
-        const int nn = (int)(r % Cout);
-        r /= Cout;
+        const int nn = (int)(r % N);
+        r /= N;
         const int t = (int)(r % T);
         const int kc = (int)(r / T);
-        const int ci = kc * 16 + kk;
-        const int kh = t / KS, kw = t - kh * KS;
-        const float v = w[(((size_t)nn * Cin + ci) * KS + kh) * KS + kw];
+        const int k = kc * 16 + kk;
+        const int tt = dgrad ? (T - 1 - t) : t;
+        const int kh = tt / KS, kw = tt - kh * KS;
+        const int co = dgrad ? k : nn, ci = dgrad ? nn : k;
+        const float v = w[(((size_t)co * Cin + ci) * KS + kh) * KS + kw];
         const __bf16 h = (__bf16)v;
         hi[i] = h;
         if (lo) lo[i] = (__bf16)(v - (float)h);
@@ -505,15 +509,24 @@ static void launch_b(const PlanB &pl, void *stream) {
 
 }  // namespace
 
-extern "C" int ds_pack_conv_weight_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin, int KS,
-                                        void *stream) {
+static int pack_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin, int KS, int dgrad, void *stream) {
     DS_REQUIRE(w_oihw && w_hi, DS_ERR_NULL);
-    DS_REQUIRE(Cout > 0 && Cin > 0 && (KS == 3 || KS == 5) && (Cin % CKB) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(Cout > 0 && Cin > 0 && (KS == 3 || KS == 5) && ((dgrad ? Cout : Cin) % CKB) == 0, DS_ERR_BAD_SHAPE);
     const long long n = (long long)Cout * Cin * KS * KS;
     long long g = (n + 255) / 256;
     DS_LAUNCH(pack_conv_weight_bf16_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w_oihw, (__bf16 *)w_hi,
-              (__bf16 *)w_lo, Cout, Cin, KS);
+              (__bf16 *)w_lo, Cout, Cin, KS, dgrad);
     return ds_last_launch_error();
+}
+
+extern "C" int ds_pack_conv_weight_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin, int KS,
+                                        void *stream) {
+    return pack_bf16(w_oihw, w_hi, w_lo, Cout, Cin, KS, 0, stream);
+}
+
+extern "C" int ds_pack_conv_weight_dgrad_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin, int KS,
+                                              void *stream) {
+    return pack_bf16(w_oihw, w_hi, w_lo, Cout, Cin, KS, 1, stream);
 }
 
 extern "C" int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3) {
@@ -541,3 +554,15 @@ extern "C" int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const vo
     else            { if (x3) launch_b<5, true>(pl, stream); else launch_b<5, false>(pl, stream); }
     return ds_last_launch_error();
 }
+
+// stride-1 data gradient on the bf16 matrix cores: the forward kernel on dY with the flipped/transposed bank
+extern "C" int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const void *w_hi, const void *w_lo,
+                                  float *gx, void *stream) {
+    DS_REQUIRE(s, DS_ERR_NULL);
+    DS_REQUIRE(s->stride == 1 && s->KS == 3, DS_ERR_UNSUPPORTED);
+    ds_conv_shape t = *s;
+    t.Cin = s->Cout;
+    t.Cout = s->Cin;
+    return ds_conv_fwd_bf16(&t, gy, w_hi, w_lo, nullptr, nullptr, nullptr, gx, nullptr, 0, stream);
+}
+

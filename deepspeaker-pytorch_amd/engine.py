@@ -48,6 +48,8 @@ class StageWeights:
     conv_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
     l_conv1_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
     l_conv2_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+    l_conv1_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+    l_conv2_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
 
 
 @dataclass
@@ -96,11 +98,11 @@ class Engine:
                              f"contiguous={t.is_contiguous()}")
 
     # ------------------------------------------------------------------ weights
-    def _pack_bf16(self, w: torch.Tensor, ks: int):
+    def _pack_bf16(self, w: torch.Tensor, ks: int, dgrad: bool = False):
         hi = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
         lo = torch.empty_like(hi)
-        self.lib.call("ds_pack_conv_weight_bf16", self._p(w), self._p(hi), self._p(lo), w.shape[0], w.shape[1], ks,
-                      self._stream(w))
+        self.lib.call("ds_pack_conv_weight_dgrad_bf16" if dgrad else "ds_pack_conv_weight_bf16", self._p(w),
+                      self._p(hi), self._p(lo), w.shape[0], w.shape[1], ks, self._stream(w))
         return hi, lo
 
     def pack_weights(self, sd: Dict[str, torch.Tensor], n_stages: int = 4,
@@ -132,6 +134,9 @@ class Engine:
                     sw.conv_bf16 = self._pack_bf16(w, 5)
                 sw.l_conv1_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3)
                 sw.l_conv2_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3)
+                if with_dgrad:
+                    sw.l_conv1_dgrad_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3, True)
+                    sw.l_conv2_dgrad_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3, True)
             if with_dgrad:
                 if i > 1:       # 5x5 stride 2: four parity-class banks (ds_conv_dgrad_f32)
                     sw.conv_dgrad = torch.empty_like(pc)
@@ -194,23 +199,30 @@ class Engine:
         return y, stats
 
     def conv_bf16(self, x: torch.Tensor, w_pair, x3: bool, B: int, H: int, W: int, cin: int, cout: int, ks: int,
-                  stride: int, scale=None, shift=None, residual=None, flags: int = 0):
+                  stride: int, scale=None, shift=None, residual=None, flags: int = 0, want_stats: bool = False):
         """Forward convolution on the bf16 matrix cores; x3 = hi/lo split operands (f32-class accuracy)."""
         shp = ConvShape(B, H, W, cin, cout, ks, stride)
         ho, wo = conv_out(H, ks, stride), conv_out(W, ks, stride)
         y = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=x.device)
+        stats = None
+        if want_stats:
+            rows = self.lib.raw("ds_conv_bf16_stats_rows")(ctypes.byref(shp), int(x3))
+            if rows <= 0:
+                raise RuntimeError(f"ds_conv_bf16_stats_rows failed: {rows}")
+            stats = torch.empty((rows, cout, 2), dtype=torch.float32, device=x.device)
+            flags |= DS_EPI_STATS
         prof = self.profile is not None and x.is_cuda
         if prof:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         self.lib.call("ds_conv_fwd_bf16", ctypes.byref(shp), self._p(x), self._p(w_pair[0]),
                       self._p(w_pair[1]) if x3 else None, self._p(scale), self._p(shift), self._p(residual),
-                      self._p(y), None, flags, self._stream(x))
+                      self._p(y), self._p(stats), flags, self._stream(x))
         if prof:
             ev1.record()
             self.profile.append((f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}",
                                  2.0 * B * ho * wo * cout * cin * ks * ks, ev0, ev1))
-        return y
+        return (y, stats) if want_stats else y
 
     def conv1(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, scale=None, shift=None,
               flags: int = 0, want_stats: bool = False):
@@ -434,7 +446,7 @@ class Engine:
         return self.tail(a, pw)
 
     def forward_train(self, x: torch.Tensor, pw: PackedWeights, bns: Dict[str, BNParams],
-                      save: bool = True, reducer=None) -> Tuple[torch.Tensor, Optional[SavedForward]]:
+                      save: bool = True, reducer=None, precision: str = "f32") -> Tuple[torch.Tensor, Optional[SavedForward]]:
         """Train-mode forward: each convolution emits its raw output plus per-tile column sums, a
         finalize kernel turns them into batch statistics (and updates the running ones), and one
         elementwise pass normalises + adds the residual + clips (nn.BatchNorm2d.train() semantics)."""
@@ -443,6 +455,17 @@ class Engine:
         if one != 1:
             raise ValueError("input must be [B,1,T,F]")
         saved = SavedForward(x=x) if save else None
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("training runs in f32 or bf16x3 (the plain-bf16 speed mode is eval-only)")
+        x3 = precision == "bf16x3"
+        if x3 and pw.stages[0].l_conv1_bf16 is None:
+            raise ValueError("pack_weights(..., with_bf16=True) is required for bf16x3")
+
+        def conv_s(src, w_f32, w_b, Bc, hh, ww, ci, co, ks, stride):
+            if x3:
+                return self.conv_bf16(src, w_b, True, Bc, hh, ww, ci, co, ks, stride, want_stats=True)
+            return self.conv(src, w_f32, Bc, hh, ww, ci, co, ks, stride, want_stats=True)
+
         h, w, cin = T, F, 1
         a = x
         for s, sw in enumerate(pw.stages):
@@ -450,7 +473,7 @@ class Engine:
             if i == 1:
                 z, st = self.conv1(a, sw.conv, B, h, w, want_stats=True)
             else:
-                z, st = self.conv(a, sw.conv, B, h, w, cin, c, 5, 2, want_stats=True)
+                z, st = conv_s(a, sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2)
             h, w, cin = conv_out(h, 5, 2), conv_out(w, 5, 2), c
             count = B * h * w
             name = f"model.bn{i}"
@@ -459,13 +482,13 @@ class Engine:
             if save:
                 saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, (mean, invstd, sc), a
             name = f"model.layer{i}.0.bn1"
-            z, st = self.conv(a, sw.l_conv1, B, h, w, c, c, 3, 1, want_stats=True)
+            z, st = conv_s(a, sw.l_conv1, sw.l_conv1_bf16, B, h, w, c, c, 3, 1)
             mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             y = self.bn_apply(z, sc, sh, None, DS_EPI_CLIP)
             if save:
                 saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, (mean, invstd, sc), y
             name = f"model.layer{i}.0.bn2"
-            z, st = self.conv(y, sw.l_conv2, B, h, w, c, c, 3, 1, want_stats=True)
+            z, st = conv_s(y, sw.l_conv2, sw.l_conv2_bf16, B, h, w, c, c, 3, 1)
             mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             a = self.bn_apply(z, sc, sh, a, DS_EPI_CLIP | DS_EPI_RESIDUAL)
             if save:

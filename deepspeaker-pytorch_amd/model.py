@@ -285,8 +285,10 @@ class _ResCNNTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
         eng = get_engine()
-        pw = model._packed(with_dgrad=True)
-        e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer)
+        prec = "bf16x3" if model.precision == "bf16x3" else "f32"
+        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"))
+        e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer, precision=prec)
+        ctx.precision = prec
         for bn in model._bn_modules():
             bn.num_batches_tracked += 1                             # nn.BatchNorm2d.train() bookkeeping
         ctx.saved_forward = saved
@@ -300,7 +302,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
         from .backward import backward_train
         bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
         grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
-                               reducer=ctx.model._reducer)
+                               reducer=ctx.model._reducer, precision=ctx.precision)
         ctx.saved_forward = None
         return (None, None) + tuple(grads.get(n) for n in ctx.param_names)
 
@@ -315,8 +317,9 @@ class DeepSpeakerModel(nn.Module):
 
     def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4, precision: str = "f32"):
         super().__init__()
-        # arithmetic of the eval-mode convolutions: "f32" (exact-f32 MFMA, the parity path), "bf16x3"
-        # (split-operand bf16 MFMA, f32-class accuracy) or "bf16" (speed mode); training is always f32
+        # arithmetic of the stage convolutions: "f32" (exact-f32 MFMA), "bf16x3" (split-operand bf16 MFMA,
+        # f32-class accuracy; in training: forward and 3x3 data gradients, the rest stays f32) or "bf16"
+        # (eval-only speed mode; training then runs in f32)
         self.precision = precision
         if feature_dim != 64:
             # the reference's feature_dim == 40 branch is dead code that cannot run

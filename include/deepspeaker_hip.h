@@ -120,6 +120,10 @@ int ds_conv_fwd_f32(const ds_conv_shape *s, const float *x, const float *w_packe
  *      accuracy at up to 1/3 of the bf16 peak.  KS in {3, 5}; Cin % 16 == 0. ----------------------- */
 int ds_pack_conv_weight_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin, int KS,
                              void *stream);             /* -> [Cin/16][KS*KS][Cout][16] bf16 (x2) */
+int ds_pack_conv_weight_dgrad_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin,
+                                   int KS, void *stream);   /* flipped / transposed bank, stride 1 */
+int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const void *w_hi, const void *w_lo,
+                       float *gx, void *stream);            /* 3x3 stride-1 data gradient */
 int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3);
 int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, const void *w_lo,
                      const float *scale, const float *shift, const float *residual, float *y,

@@ -265,3 +265,26 @@ def test_planned_eval_forward_equals_unplanned(precision):
         e2 = eng.forward_eval_planned(x, pw, folded, precision=precision)
         e3 = eng.forward_eval_planned(x, pw, folded, precision=precision)
         assert torch.equal(e1, e2) and torch.equal(e2, e3)
+
+
+def test_training_step_bf16x3_matches_oracle():
+    """Train-mode forward + backward with the bf16x3 convolutions (forward and 3x3 data gradients)."""
+    from deepspeaker_pytorch_amd.backward import backward_train
+    eng = Engine(emul_lib())
+    n_stages, B, T, seed = 2, 2, 23, 13
+    sd = O.make_state_dict(seed=seed, num_classes=4, n_stages=n_stages)
+    x = O.make_input(seed=seed + 1, batch=B, frames=T)
+    tsd = torch_sd(sd)
+    pw = eng.pack_weights(tsd, n_stages, with_dgrad=True, with_bf16=True)
+    bns = make_bns(tsd, n_stages)
+    e, saved = eng.forward_train(torch.from_numpy(x), pw, bns, precision="bf16x3")
+    ge = np.random.RandomState(3).randn(B, 512).astype(np.float32)
+    grads = backward_train(eng, {n: b.weight for n, b in bns.items()}, pw, saved, torch.from_numpy(ge),
+                           precision="bf16x3")
+    cache = {}
+    ref_e = O.forward(sd, x, train=True, n_stages=n_stages, dtype=np.float64, cache=cache)
+    assert rel_err(e.numpy(), ref_e) < 5e-5
+    ref = O.backward(sd, cache, x, ge, n_stages=n_stages)
+    for k, v in ref.items():
+        err = np.linalg.norm(grads[k].numpy() - v) / max(np.linalg.norm(v), 1e-30)
+        assert err < 3e-4, (k, err)

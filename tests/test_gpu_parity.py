@@ -398,3 +398,27 @@ def test_bf16_precisions_vs_reference(dev, golden, precision, tol):
         ref_idx, _, _ = O.triplet_filter(d_p, d_n, 0.1)
         sel = select_triplets(*embs, margin=0.1)
         np.testing.assert_array_equal(sel.indices.cpu().numpy(), ref_idx)
+
+
+def test_training_step_bf16x3(dev, golden):
+    """bf16x3 training (forward + 3x3 data gradients on the bf16 matrix cores): loss and gradients stay within
+    the fp32 noise band of the reference (same bounds as the f32 training test)."""
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    m = DeepSpeakerModel(512, 16, precision="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.cuda().train()
+    xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=8)).cuda() for i in range(3)]
+    outs = [m(x) for x in xs]
+    for e, k in zip(outs, "apn"):
+        assert rel_err(e.detach().cpu().numpy(), golden[f"full_train_emb_{k}"]) < 1e-4
+    loss = TripletMarginLoss(0.1).forward(*outs)
+    ref_loss = float(golden["full_train_loss"])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-3 * abs(ref_loss)
+    loss.backward()
+    for name, p in m.named_parameters():
+        if name.startswith("model.classifier"):
+            continue
+        ref = golden["full_train_grad/" + name]
+        dg = grad_digest(p.grad.cpu().numpy())
+        assert np.abs(dg - ref).max() <= 8e-2 * np.abs(ref).max(), name

@@ -20,12 +20,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
     args = ap.parse_args()
     import deepspeaker_oracle as O
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
     dev = torch.device("cuda", 0)
     sd = O.make_state_dict(seed=0, num_classes=1211, randomize_bn=False)
-    model = DeepSpeakerModel(512, 1211)
+    model = DeepSpeakerModel(512, 1211, precision=args.precision)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to(dev).train()
     from deepspeaker_pytorch_amd.optim import create_optimizer
@@ -51,7 +52,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     utt = 3 * args.batch * args.steps
-    print(json.dumps({"metric": "training utterances/sec (fwd + bwd + Adagrad), f32", "value": round(utt / dt, 1),
+    print(json.dumps({"metric": "training utterances/sec (fwd + bwd + Adagrad), " + args.precision, "value": round(utt / dt, 1),
                       "ms_per_step": round(dt / args.steps * 1e3, 2), "batch_triplets": args.batch,
                       "tflops_algorithmic": round(utt / dt * 6.9e9 / 1e12, 1), "final_loss": float(loss)}))
 
