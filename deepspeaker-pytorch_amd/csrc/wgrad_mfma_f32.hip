@@ -60,48 +60,112 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(const WgradK p) {
     const int pix_per_seg = p.RT * p.Wo;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int GV = COT / 4, XV = CIT / 4;           // float4 per staged pixel
+    constexpr int GSL = 8, XSL = 12;                    // staging slots per thread (host plan keeps within)
 
-    for (int tile = sp; tile < p.n_tiles; tile += p.S) {
-        const int seg0 = tile * p.NI;
-        __syncthreads();                                // previous tile's fragment reads are done
-        // ---- stage dY rows (zero for masked pixels) and the pixel table ----
-        for (int i = tid; i < p.P * GV; i += 256) {
-            const int pp = i / GV, v = i - pp * GV;
-            const int seg = pp / pix_per_seg;
-            const int rem = pp - seg * pix_per_seg;
+    // ---- tile-invariant staging descriptors: the (segment, row, column) of every slot is decomposed ONCE
+    //      (integer divisions), packed into one register per slot; per tile only the segment's image / first
+    //      row change, and those come from a small LDS table written by NI threads ----
+    int *segtab = pixtab + p.P;                         // [2][NI][2] = {image, first output row}, double-buffered
+    int g_desc[GSL], x_desc[XSL];                       // seg << 24 | row << 12 | col   (-1: unused slot)
+    const int n_g = p.P * GV, n_x = tile_in_pix * XV;
+#pragma unroll
+    for (int it = 0; it < GSL; ++it) {
+        const int i = tid + it * 256;
+        g_desc[it] = -1;
+        if (i < n_g) {
+            const int pp = i / GV;
+            const int seg = pp / pix_per_seg, rem = pp - seg * pix_per_seg;
             const int r = rem / p.Wo, c = rem - r * p.Wo;
-            const int gseg = seg0 + seg;
-            f32x4 val = zero4;
-            int base = 0;
-            if (seg < p.NI && gseg < p.n_segs) {
-                const int b = gseg / p.segs_per_img;
-                const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
-                if (rr < p.Ho) {
-                    val = *(const f32x4 *)(p.gz + ((size_t)(b * p.Ho + rr) * p.Wo + c) * p.Cout + cot * COT + v * 4);
-                    base = (seg * p.seg_pix + (p.IS * r) * p.cols_in + p.IS * c) * CIT;
-                }
-            }
-            *(f32x4 *)(gzt + pp * COT + v * 4) = val;
-            if (v == 0) pixtab[pp] = base;
+            g_desc[it] = (seg < p.NI) ? ((seg << 24) | (r << 12) | c) : (0xFF << 24);
         }
-        // ---- stage the input halo tile (zero outside the image) ----
-        for (int i = tid; i < tile_in_pix * XV; i += 256) {
-            const int pix = i / XV, v = i - pix * XV;
-            const int seg = pix / p.seg_pix;
-            const int pr = pix - seg * p.seg_pix;
+    }
+#pragma unroll
+    for (int it = 0; it < XSL; ++it) {
+        const int i = tid + it * 256;
+        x_desc[it] = -1;
+        if (i < n_x) {
+            const int pix = i / XV;
+            const int seg = pix / p.seg_pix, pr = pix - seg * p.seg_pix;
             const int rr = pr / p.cols_in, cc = pr - rr * p.cols_in;
-            const int gseg = seg0 + seg;
-            f32x4 val = zero4;
-            if (gseg < p.n_segs) {
-                const int b = gseg / p.segs_per_img;
-                const int r0 = (gseg - b * p.segs_per_img) * p.RT;
-                const int h = p.IS * r0 - p.pad + rr, w = cc - p.pad;
-                if (h >= 0 && h < p.H && w >= 0 && w < p.W)
-                    val = *(const f32x4 *)(p.x + ((size_t)(b * p.H + h) * p.W + w) * p.Cin + cit * CIT + v * 4);
-            }
-            *(f32x4 *)(xt + pix * CIT + v * 4) = val;
+            x_desc[it] = (seg << 24) | (rr << 12) | cc;
         }
+    }
+    // pixel table: float offset of each output pixel's (0,0)-tap input inside the tile (tile-invariant)
+    __syncthreads();
+    for (int pp = tid; pp < p.P; pp += 256) {
+        const int seg = pp / pix_per_seg, rem = pp - seg * pix_per_seg;
+        const int r = rem / p.Wo, c = rem - r * p.Wo;
+        pixtab[pp] = (seg < p.NI) ? (seg * p.seg_pix + (p.IS * r) * p.cols_in + p.IS * c) * CIT : 0;
+    }
+
+    // The accumulators alone take 144 registers, so only one workgroup fits per CU: the next tile's global
+    // loads are therefore issued into registers BEFORE this tile's matrix work and written to LDS after it
+    // (software pipeline over tiles; the per-tile segment table is double-buffered in LDS).
+    f32x4 gv[GSL], xv[XSL];
+    bool gok[GSL], xok[XSL];
+    auto fill_segtab = [&](int tile, int buf) {
+        if (tid < p.NI) {
+            const int gseg = tile * p.NI + tid;
+            int b = -1, r0 = 0;
+            if (gseg < p.n_segs) {
+                b = gseg / p.segs_per_img;
+                r0 = (gseg - b * p.segs_per_img) * p.RT;
+            }
+            segtab[(buf * p.NI + tid) * 2] = b;
+            segtab[(buf * p.NI + tid) * 2 + 1] = r0;
+        }
+    };
+    auto issue_loads = [&](int buf) {
+        const int *st = segtab + buf * p.NI * 2;
+#pragma unroll
+        for (int it = 0; it < GSL; ++it) {
+            const int d = g_desc[it];
+            gok[it] = false;
+            size_t off = 0;
+            if (d != -1) {
+                const int seg = (d >> 24) & 0xFF, r = (d >> 12) & 0xFFF, c = d & 0xFFF;
+                if (seg != 0xFF) {
+                    const int b = st[seg * 2], row = st[seg * 2 + 1] + r;
+                    if (b >= 0 && row < p.Ho) {
+                        gok[it] = true;
+                        off = ((size_t)(b * p.Ho + row) * p.Wo + c) * p.Cout + cot * COT + ((tid + it * 256) % GV) * 4;
+                    }
+                }
+                gv[it] = *(const f32x4 *)(p.gz + off);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < XSL; ++it) {
+            const int d = x_desc[it];
+            xok[it] = false;
+            size_t off = 0;
+            if (d != -1) {
+                const int seg = (d >> 24) & 0xFF, rr = (d >> 12) & 0xFFF, cc = d & 0xFFF;
+                const int b = st[seg * 2];
+                const int h = p.IS * st[seg * 2 + 1] - p.pad + rr, w = cc - p.pad;
+                if (b >= 0 && h >= 0 && h < p.H && w >= 0 && w < p.W) {
+                    xok[it] = true;
+                    off = ((size_t)(b * p.H + h) * p.W + w) * p.Cin + cit * CIT + ((tid + it * 256) % XV) * 4;
+                }
+                xv[it] = *(const f32x4 *)(p.x + off);
+            }
+        }
+    };
+    fill_segtab(sp, 0);
+    __syncthreads();
+    if (sp < p.n_tiles) issue_loads(0);
+    int buf = 0;
+    for (int tile = sp; tile < p.n_tiles; tile += p.S, buf ^= 1) {
+        __syncthreads();                                // previous tile's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < GSL; ++it)
+            if (g_desc[it] != -1) *(f32x4 *)(gzt + (size_t)(tid + it * 256) * 4) = gok[it] ? gv[it] : zero4;
+#pragma unroll
+        for (int it = 0; it < XSL; ++it)
+            if (x_desc[it] != -1) *(f32x4 *)(xt + (size_t)(tid + it * 256) * 4) = xok[it] ? xv[it] : zero4;
+        fill_segtab(tile + p.S, buf ^ 1);
         __syncthreads();
+        if (tile + p.S < p.n_tiles) issue_loads(buf ^ 1);   // in flight during this tile's matrix work
         // ---- contract: two pixels per MFMA (lane halves), one accumulator per tap ----
         const float *ga = gzt + co_sub * 32 + l31;
         const float *xb = xt + ci_sub * 32 + l31;
@@ -283,7 +347,9 @@ static int plan_wgrad(WgradPlan &pl, const ds_conv_shape *s) {
     if (S < 1) S = 1;
     k.S = S;
     pl.grid = base_blocks * S;
-    pl.lds_bytes = ((size_t)k.P * COT + (size_t)k.NI * k.seg_pix * CIT + k.P) * 4;
+    pl.lds_bytes = ((size_t)k.P * COT + (size_t)k.NI * k.seg_pix * CIT + k.P + 4 * k.NI) * 4;
+    DS_REQUIRE(k.P * (COT / 4) <= 8 * 256 && k.NI * k.seg_pix * (CIT / 4) <= 12 * 256 && k.NI <= 255 &&
+                   k.rows_in < 4096 && k.cols_in < 4096, DS_ERR_UNSUPPORTED);
     pl.partial_floats = (long long)S * s->KS * s->KS * s->Cout * s->Cin;
     return DS_OK;
 }
