@@ -15,7 +15,12 @@
 // LDS pixel records of 16 bf16 (+16 B pad, conflict-free ds_read_b128), no register prefetch of the
 // activation tile (two workgroups per CU overlap staging with the other's matrix work).
 #include <ds_device.h>
+#include <algorithm>
 #include "ds_common.h"
+
+#ifndef DS_BF16_ILV
+#define DS_BF16_ILV 1
+#endif
 
 namespace {
 
@@ -37,6 +42,7 @@ struct ConvKB {
     int RT, NI, segs_per_img, n_segs;
     int n_ntiles;
     int flags;
+    unsigned y_bytes;               // size of y (and of the residual) in bytes, for the buffer descriptors
 };
 
 // NIT: float4 staging slots per thread (compile time, so all loads of a chunk are issued together);
@@ -50,9 +56,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     constexpr int NTILE = NSUB * WN * 32;
     constexpr int NT = KS * KS;
     constexpr int RING = (KS == 3) ? (MSUB <= 2 ? 9 : 3) : (KS == 5 ? 5 : 1);
-    // 2-wave workgroups run one wave per SIMD with a 160x64 register tile each: nothing else hides LDS
-    // latency there, so the next tap's pixel fragments are fetched before this tap's matrix work
-    constexpr bool APREF = (WM * WN == 2);
+    // 160x64 register tiles run one wave per SIMD: nothing else hides LDS latency there, so the next
+    // tap's pixel fragments are fetched before (X3: in between) this tap's matrix work
+    constexpr bool APREF = (MSUB * NSUB >= 8);
+    constexpr bool ILV = DS_BF16_ILV && X3 && APREF;
 
     char *lds = (char *)ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,9 +70,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     const int seg0 = tile_m * p.NI;
     const int pix_per_seg = p.RT * p.Wc;
     const int tile_pix = p.NI * p.seg_pix;
+    // the pixel-tile region doubles as the epilogue's transposition buffers (32 x (NSUB*32+4) floats per wave)
+    constexpr int EPI_BYTES = WM * WN * 32 * (NSUB * 32 + 4) * 4;
+    const int tile_bytes = (X3 ? 2 : 1) * tile_pix * PSB;
+    const int stage_bytes = tile_bytes > EPI_BYTES ? tile_bytes : EPI_BYTES;
     char *lds_hi = lds;                                        // [tile_pix][PSB]
     char *lds_lo = lds + (X3 ? tile_pix * PSB : 0);
-    int *out_off = (int *)(lds + (X3 ? 2 : 1) * tile_pix * PSB);   // [MT]
+    int *out_off = (int *)(lds + stage_bytes);                 // [MT]
     int *pix_goff = out_off + MT;                              // [tile_pix] global float offset or -1
     float *red = (float *)(pix_goff + tile_pix);               // [WM][NTILE][2]
 
@@ -138,7 +149,6 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
 
     // ---- staging descriptors (chunk-invariant): global float offset / validity / LDS byte offset ----
     const int n_items = tile_pix * (CKB / 4);
-    const int dump_off = (X3 ? 2 : 1) * tile_pix * PSB + (MT + tile_pix) * 4 + WM * NTILE * 8;   // 16-B slot
     int g_off[NIT], l_off[NIT];
     bool g_ok[NIT];
     __syncthreads();                            // pix_goff is complete
@@ -163,7 +173,6 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
 #pragma unroll
         for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
     }
-    (void)dump_off;
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         __syncthreads();                       // previous chunk's fragment reads are done
@@ -198,6 +207,61 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         bf16x8 a_hi[APREF ? 2 : 1][MSUB], a_lo[APREF ? 2 : 1][X3 ? MSUB : 1];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if constexpr (ILV) {
+                // One wave per SIMD: nothing but this wave's own instruction order hides the LDS / L2
+                // latency, so the next tap's fragment reads and the ring refills are dealt out between
+                // PAIRS of MFMAs (each MFMA holds the matrix pipe for 8 issue slots) instead of in a
+                // block in front of them.
+                constexpr int NM = 3 * MSUB * NSUB, NA = 2 * MSUB, NL = NA + 2 * NSUB;
+                const int slot = t % RING, cur = t & 1;
+                auto tap_off = [&](int tt) {
+                    const int kw = tt % KS;
+                    return ((tt / KS) * p.pitch + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw)) * PSB;
+                };
+                if (t == 0) {
+                    const int toff = tap_off(0);
+#pragma unroll
+                    for (int ms = 0; ms < MSUB; ++ms) {
+                        a_lo[0][ms] = *(const bf16x8 *)(lds_lo + a_off[ms] + toff);
+                        a_hi[0][ms] = *(const bf16x8 *)(lds_hi + a_off[ms] + toff);
+                    }
+                }
+                const bool more = t + 1 < NT;
+                const char *nlo = lds_lo + tap_off(more ? t + 1 : t);
+                const char *nhi = lds_hi + tap_off(more ? t + 1 : t);
+                int gn = g0 + t - 1 + RING;                 // refills the slot the previous tap consumed
+                gn = gn < last_tap ? gn : last_tap;
+                const int rslot = (t + RING - 1) % RING;
+                const __bf16 *rhi = p.w_hi + lane_w + (size_t)gn * w_tap_stride;
+                const __bf16 *rlo = p.w_lo + lane_w + (size_t)gn * w_tap_stride;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NM; ++q) {
+                    const int term = q / (MSUB * NSUB), ms = (q % (MSUB * NSUB)) / NSUB, ns = q % NSUB;
+                    if (term == 0) acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_hi[slot][ns], a_lo[cur][ms], acc[ms][ns]);
+                    else if (term == 1) acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_lo[slot][ns], a_hi[cur][ms], acc[ms][ns]);
+                    else acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_hi[slot][ns], a_hi[cur][ms], acc[ms][ns]);
+                    if (q & 1) {
+                        const int l = q >> 1;
+                        if (l < NA) {
+                            if (more) {
+                                const int lm = l % MSUB;
+                                if (l < MSUB) a_lo[cur ^ 1][lm] = *(const bf16x8 *)(nlo + a_off[lm]);
+                                else a_hi[cur ^ 1][lm] = *(const bf16x8 *)(nhi + a_off[lm]);
+                            }
+                        } else if (l < NL) {
+                            const int ln = (l - NA) >> 1;
+                            if (t > 0) {
+                                if ((l - NA) & 1) bq_lo[rslot][ln] = *(const bf16x8 *)(rlo + (size_t)ln * 32 * CKB);
+                                else bq_hi[rslot][ln] = *(const bf16x8 *)(rhi + (size_t)ln * 32 * CKB);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             const int slot = t % RING;
             if (t > 0) {                       // refill the slot the previous tap consumed
                 int gn = g0 + t - 1 + RING;
@@ -240,18 +304,18 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                 for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
                     for (int ns = 0; ns < NSUB; ++ns)
-                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_lo[cur][ms], bq_hi[slot][ns], acc[ms][ns]);
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_hi[slot][ns], a_lo[cur][ms], acc[ms][ns]);
 #pragma unroll
                 for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
                     for (int ns = 0; ns < NSUB; ++ns)
-                        acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[cur][ms], bq_lo[slot][ns], acc[ms][ns]);
+                        acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_lo[slot][ns], a_hi[cur][ms], acc[ms][ns]);
             }
 #pragma unroll
             for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns)
-                    acc[ms][ns] = ds_mfma_32x32x16_bf16(a_hi[cur][ms], bq_hi[slot][ns], acc[ms][ns]);
+                    acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_hi[slot][ns], a_hi[cur][ms], acc[ms][ns]);
             __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -266,59 +330,92 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         }
     }
 
-    // ---- epilogue (identical to the f32 kernel's) ----
+    // ---- epilogue ----
+    // The filters were the A operand of every MFMA, so the accumulators hold the TRANSPOSED product: a lane
+    // owns one output pixel (l31 of the 32-pixel sub-tile) and, per register quad g, four consecutive output
+    // channels 8g + 4*lhi .. +3.  Each 32-pixel sub-tile is turned around through a wave-private LDS buffer
+    // (the pixel tile's space, free now) so that residual loads and stores move whole pixel rows: the
+    // NSUB*32 channels of a pixel are contiguous across NSUB*8 lanes, 16 bytes per lane.
+    constexpr int TP = NSUB * 32 + 4;           // buffer row pitch in floats (conflict-free 16-byte writes)
+    constexpr int LPP = NSUB * 8;               // lanes per pixel row
+    constexpr int PPI = 64 / LPP;               // pixel rows per instruction
+    constexpr int NRI = 32 / PPI;               // instructions per sub-tile
     const int flags = p.flags;
-    float sc[NSUB], sh[NSUB], s1[NSUB], s2[NSUB];
-    int col[NSUB];
-#pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns) {
-        col[ns] = n_base + ns * 32 + l31;
-        sc[ns] = (flags & DS_EPI_AFFINE) ? p.scale[col[ns]] : 1.0f;
-        sh[ns] = (flags & DS_EPI_AFFINE) ? p.shift[col[ns]] : 0.0f;
-        s1[ns] = 0.0f;
-        s2[ns] = 0.0f;
+    __syncthreads();                            // every wave is done reading the pixel tile
+    float *tb = (float *)lds + wave * (32 * TP);
+    const int my_c = (lane % LPP) * 4, my_p = lane / LPP;
+    const int col = n_base + my_c;
+    f32x4 sc4 = {1.0f, 1.0f, 1.0f, 1.0f}, sh4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (flags & DS_EPI_AFFINE) {
+        sc4 = *(const f32x4 *)(p.scale + col);
+        sh4 = *(const f32x4 *)(p.shift + col);
     }
+    // Rows of a ragged tile get an out-of-range buffer offset (the store is dropped, the load returns
+    // zeros) and a layer without residual reads "out of range" too: no branch around any memory
+    // instruction, so the waits on the residual rows never include the stores issued in between.
+    const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
+    const ds_buffer rbuf = ds_make_buffer((flags & DS_EPI_RESIDUAL) ? (const void *)p.res : (const void *)p.y,
+                                          (flags & DS_EPI_RESIDUAL) ? p.y_bytes : 0u);
+    float ps1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ps2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned voff[2][NRI];
+    f32x4 resv[2][NRI];
+    auto fetch_rows = [&](int ms, int buf) {    // byte offsets and residual rows of sub-tile ms
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            const int off = out_off[(wm * MSUB + ms) * 32 + k * PPI + my_p];
+            voff[buf][k] = off >= 0 ? (unsigned)(off + col) * 4u : DS_BUFFER_OOB;
+        }
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) resv[buf][k] = ds_buffer_load_f32x4(rbuf, voff[buf][k]);
+    };
+    fetch_rows(0, 0);
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
-        // all 16 row offsets and (if any) the 16 residual rows of this sub-tile are fetched up front, branch
-        // free, so their latencies overlap instead of queueing behind one another
-        int offs[16];
+        const int cb = ms & 1;
+        if (ms + 1 < MSUB) fetch_rows(ms + 1, cb ^ 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) offs[r] = out_off[(wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
-        float resv[16][NSUB];
-        if (flags & DS_EPI_RESIDUAL) {
+        for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
 #pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns)
-                    resv[r][ns] = p.res[(size_t)(offs[r] >= 0 ? offs[r] : 0) + col[ns]];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int off = offs[r];
-            if (off >= 0) {
-#pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns) {
-                    float v = acc[ms][ns][r];
-                    s1[ns] += v;
-                    s2[ns] += v * v;
-                    if (flags & DS_EPI_AFFINE) v = v * sc[ns] + sh[ns];
-                    if (flags & DS_EPI_RESIDUAL) v += resv[r][ns];
-                    if (flags & DS_EPI_CLIP) v = fminf(fmaxf(v, 0.0f), 20.0f);
-                    p.y[(size_t)off + col[ns]] = v;
-                }
+                for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
+                *(f32x4 *)(tb + l31 * TP + ns * 32 + 8 * g + 4 * lhi) = v;
             }
+        ds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c);
+            const bool live = voff[cb][k] != DS_BUFFER_OOB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[j];
+                if (flags & DS_EPI_STATS) {
+                    ps1[j] += live ? t : 0.0f;
+                    ps2[j] += live ? t * t : 0.0f;
+                }
+                t = t * sc4[j] + sh4[j];
+                t += resv[cb][k][j];
+                if (flags & DS_EPI_CLIP) t = fminf(fmaxf(t, 0.0f), 20.0f);
+                v[j] = t;
+            }
+            ds_buffer_store_f32x4(ybuf, voff[cb][k], v);
         }
+        ds_wave_sync();                         // the buffer is rewritten by the next sub-tile
     }
     if (flags & DS_EPI_STATS) {
+        // per-channel sums over this wave's pixels: fold the PPI lane groups that share a channel quad
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) {
-            s1[ns] += ds_shfl_xor(s1[ns], 32);
-            s2[ns] += ds_shfl_xor(s2[ns], 32);
-            if (lhi == 0) {
-                const int c = wn * NSUB * 32 + ns * 32 + l31;
-                red[(wm * NTILE + c) * 2 + 0] = s1[ns];
-                red[(wm * NTILE + c) * 2 + 1] = s2[ns];
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int mk = LPP; mk < 64; mk <<= 1) {
+                ps1[j] += ds_shfl_xor(ps1[j], mk);
+                ps2[j] += ds_shfl_xor(ps2[j], mk);
+            }
+            if (my_p == 0) {
+                const int c = wn * NSUB * 32 + my_c + j;
+                red[(wm * NTILE + c) * 2 + 0] = ps1[j];
+                red[(wm * NTILE + c) * 2 + 1] = ps2[j];
             }
         }
         __syncthreads();
@@ -390,13 +487,27 @@ static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in
 
 // ---- host-side plan (same objective as the f32 planner; limits: 64 KiB LDS, 2 workgroups per CU) ----
 struct TileCfgB { int MT, NTILE, WM, wg_per_cu, NTHR; };
-constexpr int kNumCfgB = 4;
+constexpr int kNumCfgB = 8;
 constexpr TileCfgB kCfgB[kNumCfgB] = {
     {128, 64, 2, 3, 256},      // <KS,2,1,2,2>
     {160, 128, 1, 2, 256},     // <KS,5,1,1,4>
     {256, 64, 2, 2, 256},      // <KS,4,1,2,2>
     {160, 128, 1, 2, 128},     // <KS,5,2,1,2>: two waves, 160x64 register tile each, one wave per SIMD; up to 80 KiB LDS
+    // one workgroup per CU, four waves with a 160x64 register tile each and the whole 160 KiB of LDS: the
+    // stride-2 layers, whose input tile is 4x the output tile, keep full M tiles this way
+    {160, 256, 1, 1, 256},     // <KS,5,2,1,4>
+    {320, 128, 2, 1, 256},     // <KS,5,2,2,2>
+    {320, 64, 2, 2, 128},      // <KS,5,2,2,1>: the 2-wave shape for 64-channel layers
+    {128, 128, 1, 2, 128},     // <KS,4,2,1,2>: 128x64 register tiles where 160-row tiles quantise badly
 };
+constexpr size_t kLdsCapB[kNumCfgB] = {64 * 1024, 64 * 1024, 64 * 1024, 80 * 1024, 160 * 1024 - 64, 160 * 1024 - 64,
+                                       80 * 1024, 80 * 1024};
+
+// bytes of the epilogue's per-wave transposition buffers (they alias the pixel tile)
+static size_t epi_bytes(const TileCfgB &cf) {
+    const int waves = cf.NTHR / 64, nsub = cf.NTILE / (waves / cf.WM) / 32;
+    return (size_t)waves * 32 * (nsub * 32 + 4) * 4;
+}
 
 struct PlanB {
     int cfg, grid, n_mtiles, nit;
@@ -415,7 +526,7 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     const int Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
     DS_REQUIRE(Ho > 0 && Wo > 0 && Wo <= 128, DS_ERR_BAD_SHAPE);
     DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
-    DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 31), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);   // 32-bit byte offsets
     const int IS = s->stride;
     const bool big_tile_ok = x3;                 // the 2-wave shape is tuned for (and only built for) bf16x3
     double best = -1.0;
@@ -423,9 +534,9 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     for (int c = 0; c < kNumCfgB; ++c) {
         const TileCfgB &cf = kCfgB[c];
         if (s->Cout % cf.NTILE) continue;
-        if (c == 3 && !big_tile_ok) continue;
-        const size_t lds_cap = c == 3 ? 80 * 1024 : 64 * 1024;       // two workgroups of the 2-wave shape per CU
-        const long long item_cap = c == 3 ? 32 * cf.NTHR : 16 * cf.NTHR;
+        if (c >= 3 && !big_tile_ok) continue;
+        const size_t lds_cap = kLdsCapB[c];
+        const long long item_cap = c >= 3 ? 32 * cf.NTHR : 16 * cf.NTHR;
         for (int rt = 1; rt <= Ho; ++rt) {
             if ((long long)rt * Wo > cf.MT) break;
             const int segs_per_img = ds_ceil_div(Ho, rt);
@@ -437,7 +548,7 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
             // itself is chosen once, for the winning geometry (this function runs on every launch)
             auto lds_of = [&](int n) {
                 const size_t tp = (size_t)n * rows_in * (cols_in + 4);
-                return tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
+                return std::max(tp * PSB * (x3 ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
             };
             auto items_of = [&](int n) { return (long long)n * rows_in * (cols_in + 4) * (CKB / 4); };
             while (ni > 1 && (lds_of(ni) > lds_cap || items_of(ni) > item_cap)) --ni;
@@ -447,7 +558,8 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
             const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * cf.wg_per_cu;
             if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
             else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
-            eff += 1e-9 * rt + 1e-6 * (c == 3 ? 3 : (c == 1 ? 2 : (c == 2 ? 1 : 0)));
+            static const int pref[kNumCfgB] = {0, 2, 1, 7, 4, 5, 6, 3};
+            eff += 1e-9 * rt + 1e-6 * pref[c];
             if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; }
         }
     }
@@ -473,11 +585,12 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     k.pitch = best_pitch;
     k.seg_pix = k.rows_in * k.pitch;
     k.n_ntiles = s->Cout / cf.NTILE;
+    k.y_bytes = (unsigned)((long long)s->B * Ho * Wo * s->Cout * 4);
     pl.cfg = bc;
     pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
     pl.grid = pl.n_mtiles * k.n_ntiles;
     const size_t tp = (size_t)k.NI * k.seg_pix;
-    pl.lds_bytes = tp * PSB * (x3 ? 2 : 1) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8 + 16;
+    pl.lds_bytes = std::max(tp * PSB * (x3 ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8 + 16;
     pl.nit = ds_ceil_div((int)tp * (CKB / 4), cf.NTHR);
     return DS_OK;
 }
@@ -492,18 +605,28 @@ static void launch_nit_b(const PlanB &pl, void *stream) {
         DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 16, false>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
 }
 
+template <int KS, int MSUB, int WM, int WN>
+static void launch_big_b(const PlanB &pl, void *stream) {
+    constexpr int NTHR = WM * WN * 64;
+    if (pl.nit <= 8)
+        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 8, true>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+    else if (pl.nit <= 16)
+        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 16, true>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+    else
+        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 32, false>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+}
+
 template <int KS, bool X3>
 static void launch_b(const PlanB &pl, void *stream) {
     if (pl.cfg == 0) launch_nit_b<KS, 2, 1, 2, 2, X3>(pl, stream);
     else if (pl.cfg == 1) launch_nit_b<KS, 5, 1, 1, 4, X3>(pl, stream);
     else if (pl.cfg == 2) launch_nit_b<KS, 4, 1, 2, 2, X3>(pl, stream);
-    else if constexpr (X3) {                    // 2-wave shape: 128 threads, up to 80 KiB of LDS per workgroup
-        if (pl.nit <= 8)
-            DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, 5, 2, 1, 2, true, 8, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
-        else if (pl.nit <= 16)
-            DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, 5, 2, 1, 2, true, 16, true>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
-        else
-            DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, 5, 2, 1, 2, true, 32, false>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
+    else if constexpr (X3) {                    // 160x64 register tiles, opt-in LDS sizes
+        if (pl.cfg == 3) launch_big_b<KS, 5, 1, 2>(pl, stream);
+        else if (pl.cfg == 4) launch_big_b<KS, 5, 1, 4>(pl, stream);
+        else if (pl.cfg == 5) launch_big_b<KS, 5, 2, 2>(pl, stream);
+        else if (pl.cfg == 6) launch_big_b<KS, 5, 2, 1>(pl, stream);
+        else launch_big_b<KS, 4, 1, 2>(pl, stream);
     }
 }
 
@@ -533,6 +656,17 @@ extern "C" int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3) {
     PlanB pl;
     int rc = plan_bf16(pl, s, x3 != 0);
     return rc == DS_OK ? pl.n_mtiles : rc;
+}
+
+extern "C" int ds_conv_bf16_plan_describe(const ds_conv_shape *s, int x3, int *out8) {
+    DS_REQUIRE(out8 != nullptr, DS_ERR_NULL);
+    PlanB pl;
+    int rc = plan_bf16(pl, s, x3 != 0);
+    if (rc != DS_OK) return rc;
+    const TileCfgB &cf = kCfgB[pl.cfg];
+    out8[0] = cf.MT; out8[1] = cf.NTILE; out8[2] = pl.k.RT; out8[3] = pl.k.NI;
+    out8[4] = pl.grid; out8[5] = (int)pl.lds_bytes; out8[6] = cf.NTHR; out8[7] = pl.k.pitch;
+    return DS_OK;
 }
 
 extern "C" int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, const void *w_lo,

@@ -29,6 +29,29 @@ __device__ __forceinline__ float ds_shfl_xor(float v, int mask) { return __shfl_
 __device__ __forceinline__ float ds_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
 __device__ __forceinline__ int ds_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ unsigned long long ds_ballot(int pred) { return __ballot(pred); }
+// orders this wavefront's LDS traffic: writes issued before it are visible to every lane's reads after it
+// (LDS executes one wavefront's instructions in order, so no workgroup barrier is needed for wave-private data)
+__device__ __forceinline__ void ds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Raw buffer access (stride 0, byte offsets): an offset outside [0, bytes) reads zeros / drops the store in
+// hardware, which keeps ragged-tile epilogues free of branches -- and of the conservative s_waitcnt the
+// compiler must place around conditionally executed memory instructions.
+typedef __amdgpu_buffer_rsrc_t ds_buffer;
+typedef unsigned int ds_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned DS_BUFFER_OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ ds_buffer ds_make_buffer(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ds_u32x4, v), b, (int)byte_off, 0, 0);
+}
 
 // 16-byte aligned base of the dynamic LDS allocation (no static __shared__ objects are
 // declared anywhere, so the base is the start of the workgroup's LDS segment)

@@ -125,6 +125,9 @@ int ds_pack_conv_weight_dgrad_bf16(const float *w_oihw, void *w_hi, void *w_lo, 
 int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const void *w_hi, const void *w_lo,
                        float *gx, void *stream);            /* 3x3 stride-1 data gradient */
 int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3);
+/* tiling the bf16 planner picks: out8 = {M tile, N tile, rows per segment, segments per tile, workgroups,
+ * LDS bytes, threads per workgroup, LDS row pitch in pixel records} */
+int ds_conv_bf16_plan_describe(const ds_conv_shape *s, int x3, int *out8);
 int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, const void *w_lo,
                      const float *scale, const float *shift, const float *residual, float *y,
                      float *stats_partial, int flags, void *stream);

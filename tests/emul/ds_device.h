@@ -67,6 +67,21 @@ static inline int ds_shfl_xor_i(int v, int mask) {
     memcpy(&r, &all[(threadIdx.x & 63) ^ mask], 4);
     return r;
 }
+struct ds_buffer { char *base; unsigned bytes; };
+constexpr unsigned DS_BUFFER_OOB = 0xFFFFFFF0u;
+static inline ds_buffer ds_make_buffer(const void *base, unsigned bytes) { return ds_buffer{(char *)base, bytes}; }
+static inline f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte_off) {
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if ((unsigned long long)byte_off + 16 <= b.bytes) memcpy(&v, b.base + byte_off, 16);
+    return v;
+}
+static inline void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
+    if ((unsigned long long)byte_off + 16 <= b.bytes) memcpy(b.base + byte_off, &v, 16);
+}
+static inline void ds_wave_sync() {
+    float all[64];
+    emu::wave_exchange(0.0f, all);
+}
 static inline unsigned long long ds_ballot(int pred) {
     float all[64];
     emu::wave_exchange(pred ? 1.0f : 0.0f, all);
