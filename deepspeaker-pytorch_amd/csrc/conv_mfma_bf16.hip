@@ -77,59 +77,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     char *lds_hi = lds;                                        // [tile_pix][PSB]
     char *lds_lo = lds + (X3 ? tile_pix * PSB : 0);
     int *out_off = (int *)(lds + stage_bytes);                 // [MT]
-    int *pix_goff = out_off + MT;                              // [tile_pix] global float offset or -1
-    float *red = (float *)(pix_goff + tile_pix);               // [WM][NTILE][2]
+    int *seg_lo = out_off + MT;                                // [NI] first in-image row of each segment's tile
+    int *seg_cnt = seg_lo + p.NI;                              // [NI] number of in-image rows
+    float *red = (float *)(seg_cnt + p.NI);                    // [WM][NTILE][2]
 
-    for (int m = tid; m < MT; m += NTHR) {
-        const int seg = m / pix_per_seg;
-        const int rem = m - seg * pix_per_seg;
-        const int r = rem / p.Wc, c = rem - r * p.Wc;
-        const int gseg = seg0 + seg;
-        int off = -1;
-        if (seg < p.NI && gseg < p.n_segs) {
-            const int b = gseg / p.segs_per_img;
-            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
-            if (rr < p.Hr) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
-        }
-        out_off[m] = off;
-    }
-    for (int pix = tid; pix < tile_pix; pix += NTHR) {
-        const int seg = pix / p.seg_pix;
-        const int pr = pix - seg * p.seg_pix;
-        const int rr = pr / p.pitch, pc = pr - rr * p.pitch;
-        // stride-2 layers keep even input columns in slots [0, half) and odd ones in [half, cols_in), so
-        // that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
-        const int cc = (p.IS == 2) ? (pc < p.half ? 2 * pc : 2 * (pc - p.half) + 1) : pc;
-        const int gseg = seg0 + seg;
-        int g = -1;
-        if (gseg < p.n_segs && pc < p.cols_in) {
-            const int b = gseg / p.segs_per_img;
-            const int r0 = (gseg - b * p.segs_per_img) * p.RT;
-            const int h = p.IS * r0 + p.dh_min + rr, w = p.dw_min + cc;
-            if (h >= 0 && h < p.H && w >= 0 && w < p.W) g = ((b * p.H + h) * p.W + w) * p.Cin;
-        }
-        pix_goff[pix] = g;
-    }
-
-    int a_off[MSUB];                                           // byte offset of this lane's fragment
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) {
-        const int m = (wm * MSUB + ms) * 32 + l31;
-        const int seg = m / pix_per_seg;
-        const int rem = m - seg * pix_per_seg;
-        const int r = rem / p.Wc, c = rem - r * p.Wc;
-        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
-        a_off[ms] = pix * PSB + 16 * lhi;
-    }
-
-    f32x16 acc[MSUB][NSUB];
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
-
+    // the first filter slices are requested before anything else: their latency hides behind the tables
     const int n_chunks = p.Cin / CKB;
     const int n_base = tile_n * NTILE + wn * NSUB * 32;
     const size_t lane_w = ((size_t)(n_base + l31) * CKB + 8 * lhi);      // in bf16 elements
@@ -147,25 +99,87 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
             if constexpr (X3) bq_lo[d][ns] = *(const bf16x8 *)(p.w_lo + o);
         }
 
-    // ---- staging descriptors (chunk-invariant): global float offset / validity / LDS byte offset ----
-    const int n_items = tile_pix * (CKB / 4);
+    const float rcp_pps = 1.0f / (float)pix_per_seg, rcp_wc = 1.0f / (float)p.Wc, rcp_w = 1.0f / (float)p.W,
+                rcp_spi = 1.0f / (float)p.segs_per_img;
+    for (int m = tid; m < MT; m += NTHR) {
+        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
+        const int rem = m - seg * pix_per_seg;
+        const int r = ds_div_small(rem, p.Wc, rcp_wc), c = rem - r * p.Wc;
+        const int gseg = seg0 + seg;
+        int off = -1;
+        if (seg < p.NI && gseg < p.n_segs) {
+            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
+            if (rr < p.Hr) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+        }
+        out_off[m] = off;
+    }
+    // Only in-image pixels are ever staged: the zero halo (and the row padding) is written once, here.
+    for (int i = tid; i < tile_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int seg = tid; seg < p.NI; seg += NTHR) {
+        const int gseg = seg0 + seg;
+        int lo = 0, cnt = 0;
+        if (gseg < p.n_segs) {
+            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+            const int h0 = p.IS * (gseg - b * p.segs_per_img) * p.RT + p.dh_min;      // image row of tile row 0
+            lo = h0 < 0 ? -h0 : 0;
+            const int hi = p.H - h0 < p.rows_in ? p.H - h0 : p.rows_in;
+            cnt = hi > lo ? hi - lo : 0;
+        }
+        seg_lo[seg] = lo;
+        seg_cnt[seg] = cnt;
+    }
+
+    int a_off[MSUB];                                           // byte offset of this lane's fragment
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int m = (wm * MSUB + ms) * 32 + l31;
+        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
+        const int rem = m - seg * pix_per_seg;
+        const int r = ds_div_small(rem, p.Wc, rcp_wc), c = rem - r * p.Wc;
+        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
+        a_off[ms] = pix * PSB + 16 * lhi;
+    }
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+
+    // ---- staging descriptors (chunk-invariant) of this thread's items: 4 channels of one in-image pixel each.
+    // Item idx -> (quarter q, column c, valid row) in segment order; slots past the last item load x[0..3]
+    // and drop it into the unused pad bytes of pixel record 0, so the chunk loop has no branches.
     int g_off[NIT], l_off[NIT];
-    bool g_ok[NIT];
-    __syncthreads();                            // pix_goff is complete
+    __syncthreads();                            // seg_lo / seg_cnt are complete
+    int seg = 0, row0 = 0;                       // a thread's items ascend: the segment walk never restarts
+    int cnt = seg_cnt[0];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * NTHR;
+        const int q = idx & 3, v = idx >> 2;
+        const int vr = ds_div_small(v, p.W, rcp_w);
+        const int c = v - vr * p.W;
+        while (seg < p.NI && vr >= row0 + cnt) {
+            row0 += cnt;
+            ++seg;
+            cnt = seg < p.NI ? seg_cnt[seg] : 0;
+        }
         g_off[it] = 0;
-        g_ok[it] = false;
-        l_off[it] = -1;
-        if (idx < n_items) {
-            const int pix = idx >> 2, q = idx & 3;
-            const int g = pix_goff[pix];
-            l_off[it] = pix * PSB + q * 8;
-            if (g >= 0) {
-                g_off[it] = g + q * 4;
-                g_ok[it] = true;
-            }
+        l_off[it] = 32;
+        if (seg < p.NI) {
+            const int gseg = seg0 + seg;
+            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+            const int rr = seg_lo[seg] + vr - row0;
+            const int h = p.IS * (gseg - b * p.segs_per_img) * p.RT + p.dh_min + rr;
+            // stride-2 layers keep even tile columns in slots [0, half) and odd ones in [half, cols_in), so
+            // that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
+            const int cc = c - p.dw_min;
+            const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
+            g_off[it] = ((b * p.H + h) * p.W + c) * p.Cin + q * 4;
+            l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSB + q * 8;
         }
     }
     f32x4 st[NIT];
@@ -183,18 +197,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         // ---- convert: f32 pixels -> bf16 hi (+ lo) records ----
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            if (l_off[it] >= 0) {
-                const f32x4 v = g_ok[it] ? st[it] : f32x4{0.f, 0.f, 0.f, 0.f};
-                bf16x4 h;
+            const f32x4 v = st[it];
+            bf16x4 h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
-                *(bf16x4 *)(lds_hi + l_off[it]) = h;
-                if constexpr (X3) {
-                    bf16x4 l;
+            for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
+            *(bf16x4 *)(lds_hi + l_off[it]) = h;
+            if constexpr (X3) {
+                bf16x4 l;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) l[j] = (__bf16)(v[j] - (float)h[j]);
-                    *(bf16x4 *)(lds_lo + l_off[it]) = l;
-                }
+                for (int j = 0; j < 4; ++j) l[j] = (__bf16)(v[j] - (float)h[j]);
+                *(bf16x4 *)(lds_lo + l_off[it]) = l;
             }
         }
         __syncthreads();
@@ -526,6 +538,7 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     const int Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
     DS_REQUIRE(Ho > 0 && Wo > 0 && Wo <= 128, DS_ERR_BAD_SHAPE);
     DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * Ho < (1ll << 24), DS_ERR_BAD_SHAPE);                  // reciprocal index arithmetic
     DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);   // 32-bit byte offsets
     const int IS = s->stride;
     const bool big_tile_ok = x3;                 // the 2-wave shape is tuned for (and only built for) bf16x3
@@ -548,9 +561,10 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
             // itself is chosen once, for the winning geometry (this function runs on every launch)
             auto lds_of = [&](int n) {
                 const size_t tp = (size_t)n * rows_in * (cols_in + 4);
-                return std::max(tp * PSB * (x3 ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8;
+                return std::max(tp * PSB * (x3 ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)n * 8 + (size_t)cf.WM * cf.NTILE * 8;
             };
-            auto items_of = [&](int n) { return (long long)n * rows_in * (cols_in + 4) * (CKB / 4); };
+            // staged items: 4-channel quarters of the in-image pixels only
+            auto items_of = [&](int n) { return (long long)n * std::min(rows_in, s->H) * s->W * (CKB / 4); };
             while (ni > 1 && (lds_of(ni) > lds_cap || items_of(ni) > item_cap)) --ni;
             if (lds_of(ni) > lds_cap || items_of(ni) > item_cap) continue;
             const long long n_mt = ds_ceil_div_ll(n_segs, ni);
@@ -590,8 +604,8 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
     pl.grid = pl.n_mtiles * k.n_ntiles;
     const size_t tp = (size_t)k.NI * k.seg_pix;
-    pl.lds_bytes = std::max(tp * PSB * (x3 ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + tp * 4 + (size_t)cf.WM * cf.NTILE * 8 + 16;
-    pl.nit = ds_ceil_div((int)tp * (CKB / 4), cf.NTHR);
+    pl.lds_bytes = std::max(tp * PSB * (x3 ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)k.NI * 8 + (size_t)cf.WM * cf.NTILE * 8 + 16;
+    pl.nit = ds_ceil_div(k.NI * std::min(k.rows_in, s->H) * s->W * (CKB / 4), cf.NTHR);
     return DS_OK;
 }
 

@@ -67,6 +67,10 @@ static inline int ds_shfl_xor_i(int v, int mask) {
     memcpy(&r, &all[(threadIdx.x & 63) ^ mask], 4);
     return r;
 }
+static inline int ds_div_small(int n, int d, float rcp) {
+    (void)rcp;
+    return n / d;
+}
 struct ds_buffer { char *base; unsigned bytes; };
 constexpr unsigned DS_BUFFER_OOB = 0xFFFFFFF0u;
 static inline ds_buffer ds_make_buffer(const void *base, unsigned bytes) { return ds_buffer{(char *)base, bytes}; }

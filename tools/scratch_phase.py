@@ -29,4 +29,5 @@ for B in [int(a) for a in sys.argv[2:]] or [768]:
       torch.cuda.synchronize()
       d = dbg.view(grid, 8).double().cpu()
       m = d.mean(0)
-      print(f'B={B} {name:16s} cfg={list(o)} epilogue clk: barrier {m[0]:7.0f} fetch0 {m[1]:7.0f} scatter(sum) {m[2]:7.0f} gather+store(sum) {m[3]:7.0f} total {m[4]:7.0f}')
+      tot = d[:, 6] - d[:, 5]
+      print(f'B={B} {name:16s} cfg={list(o)} per-WG clk: prologue {m[0]:7.0f} barrier {m[1]:6.0f} stage {m[2]:7.0f} taps {m[3]:7.0f} epilogue {m[4]:7.0f} total {float(tot.mean()):8.0f}')
