@@ -101,21 +101,6 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
 
     const float rcp_pps = 1.0f / (float)pix_per_seg, rcp_wc = 1.0f / (float)p.Wc, rcp_w = 1.0f / (float)p.W,
                 rcp_spi = 1.0f / (float)p.segs_per_img;
-    for (int m = tid; m < MT; m += NTHR) {
-        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
-        const int rem = m - seg * pix_per_seg;
-        const int r = ds_div_small(rem, p.Wc, rcp_wc), c = rem - r * p.Wc;
-        const int gseg = seg0 + seg;
-        int off = -1;
-        if (seg < p.NI && gseg < p.n_segs) {
-            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
-            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
-            if (rr < p.Hr) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
-        }
-        out_off[m] = off;
-    }
-    // Only in-image pixels are ever staged: the zero halo (and the row padding) is written once, here.
-    for (int i = tid; i < tile_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     for (int seg = tid; seg < p.NI; seg += NTHR) {
         const int gseg = seg0 + seg;
         int lo = 0, cnt = 0;
@@ -128,17 +113,6 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         }
         seg_lo[seg] = lo;
         seg_cnt[seg] = cnt;
-    }
-
-    int a_off[MSUB];                                           // byte offset of this lane's fragment
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) {
-        const int m = (wm * MSUB + ms) * 32 + l31;
-        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
-        const int rem = m - seg * pix_per_seg;
-        const int r = ds_div_small(rem, p.Wc, rcp_wc), c = rem - r * p.Wc;
-        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
-        a_off[ms] = pix * PSB + 16 * lhi;
     }
 
     f32x16 acc[MSUB][NSUB];
@@ -154,38 +128,99 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     // and drop it into the unused pad bytes of pixel record 0, so the chunk loop has no branches.
     int g_off[NIT], l_off[NIT];
     __syncthreads();                            // seg_lo / seg_cnt are complete
-    int seg = 0, row0 = 0;                       // a thread's items ascend: the segment walk never restarts
-    int cnt = seg_cnt[0];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * NTHR;
-        const int q = idx & 3, v = idx >> 2;
-        const int vr = ds_div_small(v, p.W, rcp_w);
-        const int c = v - vr * p.W;
-        while (seg < p.NI && vr >= row0 + cnt) {
+    {
+        // a thread's items ascend by NTHR/4 pixels: (row, column) advance incrementally and the segment
+        // walk never restarts
+        const int q = tid & 3;
+        const int dvr = ds_div_small(NTHR / 4, p.W, rcp_w), dc = NTHR / 4 - dvr * p.W;
+        int vr = ds_div_small(tid >> 2, p.W, rcp_w);
+        int c = (tid >> 2) - vr * p.W;
+        int seg = -1, row0 = 0, cnt = 0, lo = 0, img_row = 0;
+        auto next_seg = [&]() {
             row0 += cnt;
             ++seg;
-            cnt = seg < p.NI ? seg_cnt[seg] : 0;
-        }
-        g_off[it] = 0;
-        l_off[it] = 32;
-        if (seg < p.NI) {
-            const int gseg = seg0 + seg;
-            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
-            const int rr = seg_lo[seg] + vr - row0;
-            const int h = p.IS * (gseg - b * p.segs_per_img) * p.RT + p.dh_min + rr;
-            // stride-2 layers keep even tile columns in slots [0, half) and odd ones in [half, cols_in), so
-            // that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
-            const int cc = c - p.dw_min;
-            const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
-            g_off[it] = ((b * p.H + h) * p.W + c) * p.Cin + q * 4;
-            l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSB + q * 8;
+            cnt = 0;
+            if (seg < p.NI) {
+                cnt = seg_cnt[seg];
+                lo = seg_lo[seg];
+                const int gseg = seg0 + seg;
+                const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+                img_row = b * p.H + p.IS * (gseg - b * p.segs_per_img) * p.RT + p.dh_min;   // of tile row 0
+            }
+        };
+        next_seg();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            while (seg < p.NI && vr >= row0 + cnt) next_seg();
+            g_off[it] = 0;
+            l_off[it] = 32;
+            if (seg < p.NI) {
+                const int rr = lo + vr - row0;
+                // stride-2 layers keep even tile columns in slots [0, half) and odd ones in [half, cols_in),
+                // so that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
+                const int cc = c - p.dw_min;
+                const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
+                g_off[it] = ((img_row + rr) * p.W + c) * p.Cin + q * 4;
+                l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSB + q * 8;
+            }
+            c += dc;
+            vr += dvr;
+            if (c >= p.W) {
+                c -= p.W;
+                ++vr;
+            }
         }
     }
     f32x4 st[NIT];
     if constexpr (PREF) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
+    }
+    // ---- everything below overlaps the first chunk's loads ----
+    // Only in-image pixels are ever staged: the zero halo (and the row padding) is written once, here.
+    for (int i = tid; i < tile_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int m = tid; m < MT; m += NTHR) {
+        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
+        const int rem = m - seg * pix_per_seg;
+        const int r = ds_div_small(rem, p.Wc, rcp_wc), c = rem - r * p.Wc;
+        const int gseg = seg0 + seg;
+        int off = -1;
+        if (seg < p.NI && gseg < p.n_segs) {
+            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
+            if (rr < p.Hr) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+        }
+        out_off[m] = off;
+    }
+    int a_off[MSUB];                                           // byte offset of this lane's fragment
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int m = (wm * MSUB + ms) * 32 + l31;
+        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
+        const int rem = m - seg * pix_per_seg;
+        const int r = ds_div_small(rem, p.Wc, rcp_wc), c = rem - r * p.Wc;
+        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
+        a_off[ms] = pix * PSB + 16 * lhi;
+    }
+
+    // CVI: the next chunk's pixels are split into hi/lo IN PLACE (4 floats -> 4+4 bf16, the same 16 bytes)
+    // between the MFMAs of this chunk's later taps; between two chunks only the LDS writes remain.
+    constexpr bool CVI = ILV && PREF;
+    constexpr int CV_FIRST = 3;                 // taps left for the prefetch to land before conversion starts
+    auto split_item = [&](int it) {
+        const f32x4 v = st[it];
+        bf16x8 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 h = (__bf16)v[j];
+            pk[j] = h;
+            pk[4 + j] = (__bf16)(v[j] - (float)h);
+        }
+        st[it] = __builtin_bit_cast(f32x4, pk);
+    };
+    if constexpr (CVI) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) split_item(it);
     }
 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
@@ -194,19 +229,28 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
 #pragma unroll
             for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + chunk * CKB);
         }
-        // ---- convert: f32 pixels -> bf16 hi (+ lo) records ----
+        if constexpr (CVI) {                   // records were split during the previous chunk's taps
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const f32x4 v = st[it];
-            bf16x4 h;
+            for (int it = 0; it < NIT; ++it) {
+                const bf16x8 pk = __builtin_bit_cast(bf16x8, st[it]);
+                *(bf16x4 *)(lds_hi + l_off[it]) = __builtin_shufflevector(pk, pk, 0, 1, 2, 3);
+                *(bf16x4 *)(lds_lo + l_off[it]) = __builtin_shufflevector(pk, pk, 4, 5, 6, 7);
+            }
+        } else {
+            // ---- convert: f32 pixels -> bf16 hi (+ lo) records ----
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
-            *(bf16x4 *)(lds_hi + l_off[it]) = h;
-            if constexpr (X3) {
-                bf16x4 l;
+            for (int it = 0; it < NIT; ++it) {
+                const f32x4 v = st[it];
+                bf16x4 h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) l[j] = (__bf16)(v[j] - (float)h[j]);
-                *(bf16x4 *)(lds_lo + l_off[it]) = l;
+                for (int j = 0; j < 4; ++j) h[j] = (__bf16)v[j];
+                *(bf16x4 *)(lds_hi + l_off[it]) = h;
+                if constexpr (X3) {
+                    bf16x4 l;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) l[j] = (__bf16)(v[j] - (float)h[j]);
+                    *(bf16x4 *)(lds_lo + l_off[it]) = l;
+                }
             }
         }
         __syncthreads();
@@ -253,6 +297,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                     if (term == 0) acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_hi[slot][ns], a_lo[cur][ms], acc[ms][ns]);
                     else if (term == 1) acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_lo[slot][ns], a_hi[cur][ms], acc[ms][ns]);
                     else acc[ms][ns] = ds_mfma_32x32x16_bf16(bq_hi[slot][ns], a_hi[cur][ms], acc[ms][ns]);
+                    if constexpr (CVI) {
+                        if (!(q & 1) && t >= CV_FIRST) {          // one pixel item split per even slot
+                            constexpr int SPAN = NT - CV_FIRST;
+                            const int it = (NIT * (t - CV_FIRST)) / SPAN + (q >> 1);
+                            if (it < (NIT * (t - CV_FIRST + 1)) / SPAN) {
+                                split_item(it);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
                     if (q & 1) {
                         const int l = q >> 1;
                         if (l < NA) {
