@@ -130,18 +130,20 @@ def main():
             with torch.no_grad():
                 if args.split_apn:
                     embs = [model(x) for x in data]
+                    e_all = torch.cat(embs)
                 else:                                   # eval mode: per-utterance results do not depend on batching
-                    embs = list(model(data_all).split(BATCH_TRIPLETS))
+                    e_all = model(data_all)
+                    embs = list(e_all.split(BATCH_TRIPLETS))
                 loss = loss_fn.forward(*embs)
                 sel = select_triplets(*embs, margin=0.1)
                 # cross-GPU semi-hard negative search over the all-gathered global batch (BASELINE configs[2]);
                 # at N = 1 the candidate set is the local batch, so per-GPU work has the same shape
                 if world > 1:
-                    dist.all_gather_into_tensor(emb_glob, torch.cat(embs))
+                    dist.all_gather_into_tensor(emb_glob, e_all)
                     dist.all_gather_into_tensor(lab_glob, labels_loc)
                     mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob)
                 else:
-                    mined = mine_semihard_negatives(embs[0], embs[1], c1, torch.cat(embs), labels_loc)
+                    mined = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels_loc)
             return loss, sel, mined
 
         eng.profile = []                        # warm-up with the event instrumentation on: the first

@@ -49,7 +49,16 @@ def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     return gy, gz, gg, gb
 
 
-def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0):
+def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0, x3: bool = False):
+    if x3 and shp.KS in (3, 5) and shp.Cin % 64 == 0:      # split-operand bf16 matrix cores
+        n_ws = eng.lib.raw("ds_conv_wgrad_bf16_workspace_floats")(ctypes.byref(shp))
+        if n_ws <= 0:
+            raise RuntimeError(f"ds_conv_wgrad_bf16_workspace_floats failed: {n_ws}")
+        ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
+        gw = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_conv_wgrad_bf16", ctypes.byref(shp), eng._p(x), eng._p(gz), eng._p(ws), eng._p(gw),
+                     eng._stream(x))
+        return gw
     n_ws = eng.lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp))
     if n_ws <= 0:
         raise RuntimeError(f"ds_conv_wgrad_workspace_floats failed: {n_ws}")
@@ -73,8 +82,8 @@ def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad, w_dgrad_bf16=None):
 def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
                    ge: torch.Tensor, reducer=None, precision: str = "f32") -> Dict[str, torch.Tensor]:
     """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512].
-    precision "bf16x3": the 3x3 data gradients run on the bf16 matrix cores with split operands; filter
-    gradients and the 5x5 stride-2 data gradients stay on the f32 matrix cores."""
+    precision "bf16x3": the 3x3 data gradients and the 3x3 / 5x5 filter gradients run on the bf16 matrix
+    cores with split operands; the 5x5 stride-2 data gradients, conv1 and fc stay on the f32 matrix cores."""
     x3 = precision == "bf16x3"
     lib = eng.lib
     grads: Dict[str, torch.Tensor] = {}
@@ -115,13 +124,13 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         g_out, gz, gg, gbeta = _bn_bwd(eng, g, None, None if g_is_masked else c_act, saved.raws[name],
                                        saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
-        grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3))
+        grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3), x3=x3)
         g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad, pw.stages[s].l_conv2_dgrad_bf16 if x3 else None)
         # y = clip(bn1(conv1(r)))                  (model.py:69-71)
         name = f"model.layer{i}.0.bn1"
         _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
-        grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3))
+        grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3), x3=x3)
         g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad, pw.stages[s].l_conv1_dgrad_bf16 if x3 else None)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv-path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
@@ -130,7 +139,7 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
         shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)
         x_in = saved.x if s == 0 else saved.acts[f"stage{s}.c"]
-        grads[f"model.conv{i}.weight"] = _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5))
+        grads[f"model.conv{i}.weight"] = _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5), x3=x3)
         if s > 0:
             g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad)        # unmasked: the next bn2 step masks it
             g_is_masked = False

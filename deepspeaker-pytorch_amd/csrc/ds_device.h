@@ -37,6 +37,16 @@ __device__ __forceinline__ void ds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ds_read_b64_tr_b16 (gfx950 transposing LDS read).  Within each group of 16 lanes, lane i supplies the
+// address of an 8-byte piece -- row i>>2, column quad i&3 of a [4 rows][16 columns] block of 16-bit
+// elements -- and receives COLUMN i of that block (rows 0..3).  Verified on MI355X with row strides of
+// 32 / 48 / 64 bytes; addresses must be 8-byte aligned.
+typedef short ds_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 ds_read_tr16_b64(const char *lds_piece) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                          (__attribute__((address_space(3))) ds_s16x4 *)lds_piece));
+}
+
 // n / d for 0 <= n < 2^24 with a reciprocal computed once per divisor (rcp = 1.0f / d): a handful of
 // instructions instead of the ~40 of an integer division (index tables are built per workgroup)
 __device__ __forceinline__ int ds_div_small(int n, int d, float rcp) {

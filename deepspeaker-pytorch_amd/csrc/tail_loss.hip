@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(256) avgpool_time_bwd_kernel(const float *gpoo
 constexpr int MINE_A = 8;          // anchors per workgroup
 constexpr int MINE_K = 32;         // dimensions per staged slab
 constexpr int MINE_C = 256;        // candidates per workgroup
+constexpr int MINE_P = MINE_K + 4;  // candidate-tile row pitch in floats (16-byte aligned, conflict-free)
 
 __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor, const float *d_p,
                                                             const long long *anchor_label, const float *cand,
@@ -236,16 +237,18 @@ __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor,
                                                             int N, int M, int D, float eps, int n_agroups) {
     float *lds = ds_dynamic_lds();
     float *arow = lds;                                     // [MINE_A][D]
-    float *ctile = arow + MINE_A * D;                      // [256][MINE_K + 1]
+    float *ctile = arow + MINE_A * D;                      // [256][MINE_P]
     // the reduction scratch aliases the candidate tile (dead by then): 2 x [2][MINE_A][256] words
     float *red_d = ctile;
     int *red_j = (int *)(ctile + 2 * MINE_A * 256);
     const int tid = threadIdx.x;
     const int ag = blockIdx.x % n_agroups, ct = blockIdx.x / n_agroups;
     const int a0 = ag * MINE_A, j0 = ct * MINE_C;
-    for (int i = tid; i < MINE_A * D; i += 256) {
-        const int a = i / D;
-        arow[i] = (a0 + a < N) ? anchor[(size_t)(a0 + a) * D + (i - a * D)] : 0.0f;
+    for (int i = tid; i < MINE_A * D / 4; i += 256) {
+        const int a = i / (D / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a0 + a < N) v = *(const f32x4 *)(anchor + (size_t)(a0 + a) * D + (i - a * (D / 4)) * 4);
+        *(f32x4 *)(arow + i * 4) = v;
     }
     float accd[MINE_A];
 #pragma unroll
@@ -257,17 +260,23 @@ __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor,
             const int row = i / (MINE_K / 4), q = i - row * (MINE_K / 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (j0 + row < M && k0 + q * 4 < D) v = *(const f32x4 *)(cand + (size_t)(j0 + row) * D + k0 + q * 4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ctile[row * (MINE_K + 1) + q * 4 + u] = v[u];
+            *(f32x4 *)(ctile + row * MINE_P + q * 4) = v;
         }
         __syncthreads();
         const int kmax = (D - k0) < MINE_K ? (D - k0) : MINE_K;
-        for (int k = 0; k < kmax; ++k) {
-            const float c = ctile[tid * (MINE_K + 1) + k];
+        // four dimensions per step: one 16-byte read of this thread's candidate (row pitch 36 floats: the
+        // 16-lane groups of a ds_read_b128 cover all 64 banks) and one broadcast read per anchor; the sum
+        // over dimensions stays strictly sequential per (anchor, candidate)
+        for (int k = 0; k < kmax; k += 4) {
+            const f32x4 c = *(const f32x4 *)(ctile + tid * MINE_P + k);
 #pragma unroll
             for (int a = 0; a < MINE_A; ++a) {
-                const float df = fabsf(arow[a * D + k0 + k] - c);
-                accd[a] += df * df;
+                const f32x4 av = *(const f32x4 *)(arow + a * D + k0 + k);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float df = av[u] - c[u];
+                    accd[a] += df * df;
+                }
             }
         }
     }
@@ -365,9 +374,9 @@ extern "C" int ds_mine_semihard_f32(const float *anchor, const float *d_p, const
                                     long long *out_index, float *out_dist, int N, int M, int D, void *stream) {
     DS_REQUIRE(anchor && d_p && anchor_label && cand && cand_label && workspace && out_index, DS_ERR_NULL);
     DS_REQUIRE(N > 0 && M > 0 && D > 0 && D <= 8192, DS_ERR_BAD_SHAPE);
-    DS_REQUIRE(D % 4 == 0 && DS_ALIGNED16(cand), DS_ERR_ALIGNMENT);
+    DS_REQUIRE(D % 4 == 0 && DS_ALIGNED16(cand) && DS_ALIGNED16(anchor), DS_ERR_ALIGNMENT);
     const float eps = (float)(1e-4 / (double)D);
-    const size_t tile_words = 256 * (MINE_K + 1) > 4 * MINE_A * 256 ? 256 * (MINE_K + 1) : 4 * MINE_A * 256;
+    const size_t tile_words = 256 * MINE_P > 4 * MINE_A * 256 ? 256 * MINE_P : 4 * MINE_A * 256;
     const size_t lds = ((size_t)MINE_A * D + tile_words) * 4;
     DS_REQUIRE(lds <= 64 * 1024, DS_ERR_BAD_SHAPE);
     const int n_agroups = ds_ceil_div(N, MINE_A), n_ctiles = ds_ceil_div(M, MINE_C);

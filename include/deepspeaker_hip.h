@@ -177,6 +177,12 @@ int ds_conv_dgrad_f32(const ds_conv_shape *s, const float *gy, const float *w_dg
 long long ds_conv_wgrad_workspace_floats(const ds_conv_shape *s);
 int ds_conv_wgrad_f32(const ds_conv_shape *s, const float *x, const float *gy, float *workspace,
                       float *gw_oihw, int fc_F, void *stream);
+/* the same filter gradient on the bf16 matrix cores with split operands (bf16x3, f32-class accuracy):
+ * 3x3 stride 1 and 5x5 stride 2 layers with Cin, Cout multiples of 64.  `workspace`:
+ * ds_conv_wgrad_bf16_workspace_floats(s) floats.  Deterministic (fixed-order reduction). */
+long long ds_conv_wgrad_bf16_workspace_floats(const ds_conv_shape *s);
+int ds_conv_wgrad_bf16(const ds_conv_shape *s, const float *x, const float *gy, float *workspace,
+                       float *gw_oihw, void *stream);
 /* BatchNorm (train mode) backward in one call: gy = (g1 [+ g2]) masked by the clipped-ReLU of `act`
  * (NULL: unmasked); reductions sum gy, sum gy*xhat; ggamma, gbeta; gz = dL/d(conv output).
  * partial: ds_bn_bwd_partial_rows(n_pix) * C * 2 floats; coef: 3*C floats; gy is written (it is the

@@ -67,6 +67,25 @@ static inline int ds_shfl_xor_i(int v, int mask) {
     memcpy(&r, &all[(threadIdx.x & 63) ^ mask], 4);
     return r;
 }
+// transposing LDS read: lane i of a 16-lane group supplies piece (row i>>2, quad i&3), receives column i
+static inline bf16x4 ds_read_tr16_b64(const char *lds_piece) {
+    float mine[2], all0[64], all1[64];
+    memcpy(mine, lds_piece, 8);
+    emu::wave_exchange(mine[0], all0);
+    emu::wave_exchange(mine[1], all1);
+    const int lane = threadIdx.x & 63, g0 = lane & ~15, i = lane & 15;
+    unsigned short col[4];
+    for (int r = 0; r < 4; ++r) {
+        const int src = g0 + 4 * r + (i >> 2);          // the lane that supplied row r, quad i>>2
+        unsigned short piece[4];
+        memcpy(piece, &all0[src], 4);
+        memcpy(piece + 2, &all1[src], 4);
+        col[r] = piece[i & 3];
+    }
+    bf16x4 out;
+    memcpy(&out, col, 8);
+    return out;
+}
 static inline int ds_div_small(int n, int d, float rcp) {
     (void)rcp;
     return n / d;

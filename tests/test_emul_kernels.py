@@ -228,6 +228,30 @@ def test_conv_wgrad(case):
     assert rel_err(gw, gw_ref) < 3e-6
 
 
+WGRAD_BF16_CASES = [c for c in WGRAD_CASES if c[5] in (3, 5)] + [(4, 128, 128, 10, 4, 5, 2)]
+
+
+@pytest.mark.parametrize("case", WGRAD_BF16_CASES)
+def test_conv_wgrad_bf16x3(case):
+    """split-operand bf16 filter gradient (transposing LDS reads) against the float64 oracle"""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(abs(hash(case)) % 2**31)
+    x = rs.randn(b, ci, h, w)
+    wt = rs.randn(co, ci, k, k)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    gy = rs.randn(b, co, ho, wo)
+    _, gw_ref = O.conv2d_bwd(x, wt, gy, s, k // 2, need_gx=False)
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    n_ws = lib.raw("ds_conv_wgrad_bf16_workspace_floats")(ctypes.byref(shp))
+    assert n_ws > 0
+    ws = aligned(n_ws, fill=np.nan)
+    xh, gyh = nhwc(x.astype(np.float32)), nhwc(gy.astype(np.float32))
+    gw = aligned((co, ci, k, k), fill=np.nan)
+    lib.call("ds_conv_wgrad_bf16", ctypes.byref(shp), ptr(xh), ptr(gyh), ptr(ws), ptr(gw), None)
+    assert rel_err(gw, gw_ref) < 3e-5          # 16 mantissa bits per operand
+
+
 def test_fc_wgrad_feature_permutation():
     lib = emul_lib()
     rs = np.random.RandomState(8)

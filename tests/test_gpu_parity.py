@@ -320,6 +320,9 @@ def test_conv_backward_kernels_vs_oracle(dev, case):
     gw = _wgrad(eng, shp, xh, gyh, (co, ci, k, k))
     assert rel_err(gx.cpu().numpy().transpose(0, 3, 1, 2), gx_ref) < 1e-5
     assert rel_err(gw.cpu().numpy(), gw_ref) < 1e-5
+    gw3 = _wgrad(eng, shp, xh, gyh, (co, ci, k, k), x3=True)        # split-operand bf16 matrix cores
+    assert rel_err(gw3.cpu().numpy(), gw_ref) < 3e-5
+    assert torch.equal(gw3, _wgrad(eng, shp, xh, gyh, (co, ci, k, k), x3=True))     # deterministic
 
 
 def test_mining_kernel_vs_oracle(dev):
