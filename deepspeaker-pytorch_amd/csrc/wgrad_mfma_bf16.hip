@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
     char *gzt = lds;                                    // [P] records
     char *xt = gzt + (size_t)p.P * WB_REC;              // [tile_in_pix] records
     int *pixtab = (int *)(xt + (size_t)tile_in_pix * WB_REC);   // [P] byte offset of each pixel's (0,0)-tap input record
-    int *segtab = pixtab + p.P;                         // [2][NI][2] = {image, first output row}, double-buffered
+    int *segtab = pixtab + p.P;                         // [2][NI][4] per-tile segment origins, double-buffered
 
     f32x16 acc[TG];
 #pragma unroll
@@ -76,29 +76,36 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
     constexpr int QV = WB_C / 4;                        // float4 per staged pixel
     constexpr int GSL = 4, XSL = 12;                    // staging slots per thread (the host plan keeps within)
 
-    // ---- tile-invariant staging descriptors (see wgrad_mfma_f32.hip): seg << 24 | row << 12 | col ----
-    int g_desc[GSL], x_desc[XSL];
+    // ---- tile-invariant staging descriptors: per slot the float offset RELATIVE to the segment's origin and
+    //      (segment << 16 | row); per tile only four numbers per segment change (segtab) ----
+    int g_rel[GSL], g_sr[GSL], x_rel[XSL], x_sr[XSL];   // *_sr = -1: unused slot, -2: always-zero slot
     const int n_g = p.P * QV, n_x = tile_in_pix * QV;
 #pragma unroll
     for (int it = 0; it < GSL; ++it) {
         const int i = tid + it * 256;
-        g_desc[it] = -1;
+        g_sr[it] = -1;
+        g_rel[it] = 0;
         if (i < n_g) {
-            const int pp = i / QV;
+            const int pp = i / QV, q = i - pp * QV;
             const int seg = pp / pix_per_seg, rem = pp - seg * pix_per_seg;
             const int r = rem / p.Wo, c = rem - r * p.Wo;
-            g_desc[it] = (seg < p.NI) ? ((seg << 24) | (r << 12) | c) : (0xFF << 24);
+            g_sr[it] = (seg < p.NI) ? ((seg << 16) | r) : -2;
+            g_rel[it] = (r * p.Wo + c) * p.Cout + cot * WB_C + q * 4;
         }
     }
 #pragma unroll
     for (int it = 0; it < XSL; ++it) {
         const int i = tid + it * 256;
-        x_desc[it] = -1;
+        x_sr[it] = -1;
+        x_rel[it] = 0;
         if (i < n_x) {
-            const int pix = i / QV;
+            const int pix = i / QV, q = i - pix * QV;
             const int seg = pix / p.seg_pix, pr = pix - seg * p.seg_pix;
             const int rr = pr / p.cols_in, cc = pr - rr * p.cols_in;
-            x_desc[it] = (seg << 24) | (rr << 12) | cc;
+            const int hrel = (TG == 5) ? p.IS * rr + tg : rr;          // image row = IS*r0 - pad + hrel
+            const int w = cc - p.pad;
+            x_sr[it] = (w >= 0 && w < p.W) ? ((seg << 16) | hrel) : -2;
+            x_rel[it] = (hrel * p.W + cc) * p.Cin + cit * WB_C + q * 4;
         }
     }
     for (int pp = tid; pp < p.P; pp += 256) {
@@ -111,49 +118,52 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
     // software pipeline over tiles: the next tile's global loads are issued into registers before this
     // tile's matrix work and split / written to LDS after it
     f32x4 gv[GSL], xv[XSL];
-    auto fill_segtab = [&](int tile, int buf) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto fill_segtab = [&](int tile, int buf) {          // {dY origin, output rows left, X origin, first image row}
         if (tid < p.NI) {
             const int gseg = tile * p.NI + tid;
-            int b = -1, r0 = 0;
+            int gbase = 0, rows_left = 0, xbase = 0, h0 = -(1 << 20);
             if (gseg < p.n_segs) {
-                b = gseg / p.segs_per_img;
-                r0 = (gseg - b * p.segs_per_img) * p.RT;
+                const int b = gseg / p.segs_per_img;
+                const int r0 = (gseg - b * p.segs_per_img) * p.RT;
+                gbase = (b * p.Ho + r0) * p.Wo * p.Cout;
+                rows_left = p.Ho - r0;
+                h0 = p.IS * r0 - p.pad;
+                xbase = ((b * p.H + h0) * p.W - p.pad) * p.Cin;
             }
-            segtab[(buf * p.NI + tid) * 2] = b;
-            segtab[(buf * p.NI + tid) * 2 + 1] = r0;
+            int *e = segtab + (buf * p.NI + tid) * 4;
+            e[0] = gbase; e[1] = rows_left; e[2] = xbase; e[3] = h0;
         }
     };
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // branch-free: all segment-table reads first, then every load (masked slots read element 0 and are
+    // zeroed when written to LDS) -- a conditional load per slot serialises LDS latency + branch + load
+    unsigned g_ok = 0, x_ok = 0;                        // validity bits of the loaded tile
     auto issue_loads = [&](int buf) {
-        const int *st = segtab + buf * p.NI * 2;
+        const int *st = segtab + buf * p.NI * 4;
+        int goff[GSL], xoff[XSL];
+        g_ok = 0;
+        x_ok = 0;
 #pragma unroll
         for (int it = 0; it < GSL; ++it) {
-            const int d = g_desc[it];
-            gv[it] = zero4;
-            if (d != -1) {
-                const int seg = (d >> 24) & 0xFF, r = (d >> 12) & 0xFFF, c = d & 0xFFF;
-                if (seg != 0xFF) {
-                    const int b = st[seg * 2], row = st[seg * 2 + 1] + r;
-                    if (b >= 0 && row < p.Ho)
-                        gv[it] = *(const f32x4 *)(p.gz + ((size_t)(b * p.Ho + row) * p.Wo + c) * p.Cout + cot * WB_C +
-                                                  ((tid + it * 256) % QV) * 4);
-                }
-            }
+            const int sr = g_sr[it] >= 0 ? g_sr[it] : 0;
+            const int *e = st + (sr >> 16) * 4;
+            const bool ok = g_sr[it] >= 0 && (sr & 0xFFFF) < e[1];
+            goff[it] = ok ? e[0] + g_rel[it] : 0;
+            g_ok |= ok ? (1u << it) : 0u;
         }
 #pragma unroll
         for (int it = 0; it < XSL; ++it) {
-            const int d = x_desc[it];
-            xv[it] = zero4;
-            if (d != -1) {
-                const int seg = (d >> 24) & 0xFF, rr = (d >> 12) & 0xFFF, cc = d & 0xFFF;
-                const int b = st[seg * 2];
-                const int h = (TG == 5) ? p.IS * (st[seg * 2 + 1] + rr) - p.pad + tg : p.IS * st[seg * 2 + 1] - p.pad + rr;
-                const int w = cc - p.pad;
-                if (b >= 0 && h >= 0 && h < p.H && w >= 0 && w < p.W)
-                    xv[it] = *(const f32x4 *)(p.x + ((size_t)(b * p.H + h) * p.W + w) * p.Cin + cit * WB_C +
-                                              ((tid + it * 256) % QV) * 4);
-            }
+            const int sr = x_sr[it] >= 0 ? x_sr[it] : 0;
+            const int *e = st + (sr >> 16) * 4;
+            const int h = e[3] + (sr & 0xFFFF);
+            const bool ok = x_sr[it] >= 0 && h >= 0 && h < p.H;
+            xoff[it] = ok ? e[2] + x_rel[it] : 0;
+            x_ok |= ok ? (1u << it) : 0u;
         }
+#pragma unroll
+        for (int it = 0; it < GSL; ++it) gv[it] = *(const f32x4 *)(p.gz + goff[it]);
+#pragma unroll
+        for (int it = 0; it < XSL; ++it) xv[it] = *(const f32x4 *)(p.x + xoff[it]);
     };
     auto put_split = [&](char *rec, int q, const f32x4 v) {     // 4 channels -> hi / lo halves of the record
         bf16x4 h, l;
@@ -180,15 +190,15 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
         __syncthreads();                                // previous tile's fragment reads are done
 #pragma unroll
         for (int it = 0; it < GSL; ++it)
-            if (g_desc[it] != -1) {
+            if (g_sr[it] != -1) {
                 const int i = tid + it * 256;
-                put_split(gzt + (size_t)(i / QV) * WB_REC, i % QV, gv[it]);
+                put_split(gzt + (size_t)(i / QV) * WB_REC, i % QV, (g_ok >> it) & 1 ? gv[it] : zero4);
             }
 #pragma unroll
         for (int it = 0; it < XSL; ++it)
-            if (x_desc[it] != -1) {
+            if (x_sr[it] != -1) {
                 const int i = tid + it * 256;
-                put_split(xt + (size_t)(i / QV) * WB_REC, i % QV, xv[it]);
+                put_split(xt + (size_t)(i / QV) * WB_REC, i % QV, (x_ok >> it) & 1 ? xv[it] : zero4);
             }
         fill_segtab(tile + p.S, buf ^ 1);
         __syncthreads();
@@ -282,8 +292,8 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     if (S < 1) S = 1;
     k.S = S;
     pl.grid = base_blocks * S;
-    pl.lds_bytes = ((size_t)k.P + (size_t)k.NI * k.seg_pix) * WB_REC + ((size_t)k.P + 4 * k.NI) * 4;
-    DS_REQUIRE(k.P * (WB_C / 4) <= 4 * 256 && k.NI <= 255 && k.rows_in < 4096 && k.cols_in < 4096 &&
+    pl.lds_bytes = ((size_t)k.P + (size_t)k.NI * k.seg_pix) * WB_REC + ((size_t)k.P + 8 * k.NI) * 4;
+    DS_REQUIRE(k.P * (WB_C / 4) <= 4 * 256 && k.NI <= 255 && s->stride * k.rows_in + s->KS < 4096 &&
                    pl.lds_bytes <= 80 * 1024, DS_ERR_UNSUPPORTED);
     pl.partial_floats = (long long)S * s->KS * s->KS * s->Cout * s->Cin;
     return DS_OK;
