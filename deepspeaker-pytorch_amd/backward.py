@@ -71,7 +71,7 @@ def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0, x3: boo
 
 def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad, w_dgrad_bf16=None):
     gx = torch.empty((shp.B, shp.H, shp.W, shp.Cin), dtype=torch.float32, device=gz.device)
-    if w_dgrad_bf16 is not None:       # bf16x3 data gradient (3x3 stride 1)
+    if w_dgrad_bf16 is not None:       # bf16x3 data gradient (3x3 stride 1 / 5x5 stride 2)
         eng.lib.call("ds_conv_dgrad_bf16", ctypes.byref(shp), eng._p(gz), eng._p(w_dgrad_bf16[0]),
                      eng._p(w_dgrad_bf16[1]), eng._p(gx), eng._stream(gz))
         return gx
@@ -82,8 +82,8 @@ def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad, w_dgrad_bf16=None):
 def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
                    ge: torch.Tensor, reducer=None, precision: str = "f32") -> Dict[str, torch.Tensor]:
     """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512].
-    precision "bf16x3": the 3x3 data gradients and the 3x3 / 5x5 filter gradients run on the bf16 matrix
-    cores with split operands; the 5x5 stride-2 data gradients, conv1 and fc stay on the f32 matrix cores."""
+    precision "bf16x3": data and filter gradients of the 3x3 / 5x5 layers run on the bf16 matrix cores with
+    split operands; conv1 and fc stay on the f32 matrix cores."""
     x3 = precision == "bf16x3"
     lib = eng.lib
     grads: Dict[str, torch.Tensor] = {}
@@ -141,6 +141,6 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         x_in = saved.x if s == 0 else saved.acts[f"stage{s}.c"]
         grads[f"model.conv{i}.weight"] = _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5), x3=x3)
         if s > 0:
-            g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad)        # unmasked: the next bn2 step masks it
+            g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad, pw.stages[s].conv_dgrad_bf16 if x3 else None)   # unmasked: the next bn2 step masks it
             g_is_masked = False
     return grads

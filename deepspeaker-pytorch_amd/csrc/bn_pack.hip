@@ -20,33 +20,45 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const float *gamma, const 
     }
 }
 
-// One workgroup per 32 channels; 8 row-lanes stride over the partial rows in double precision.
+// Fold of [n_partial][C][2] partial sums in double precision, fixed order: one workgroup per 8 channels,
+// 32 row-lanes stride over the partial rows (stage-1 layers have thousands of rows and only 64 channels --
+// a channel-per-thread layout left the chip idle), then lane 0 folds the 32 lane sums.
+constexpr int FOLD_C = 8, FOLD_R = 32;
+__device__ __forceinline__ bool fold_partials(const float *partial, int n_partial, int C, double *red, int &c,
+                                              double &t1, double &t2) {
+    const int cl = threadIdx.x % FOLD_C, rl = threadIdx.x / FOLD_C;
+    c = blockIdx.x * FOLD_C + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int r = rl; r < n_partial; r += FOLD_R) {
+            const float *src = partial + ((size_t)r * C + c) * 2;
+            s1 += (double)src[0];
+            s2 += (double)src[1];
+        }
+    }
+    red[(rl * FOLD_C + cl) * 2 + 0] = s1;
+    red[(rl * FOLD_C + cl) * 2 + 1] = s2;
+    __syncthreads();
+    if (rl != 0 || c >= C) return false;
+    t1 = 0.0;
+    t2 = 0.0;
+    for (int k = 0; k < FOLD_R; ++k) {
+        t1 += red[(k * FOLD_C + cl) * 2 + 0];
+        t2 += red[(k * FOLD_C + cl) * 2 + 1];
+    }
+    return true;
+}
+
 __global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const float *partial, int n_partial, double count,
                                                                 const float *gamma, const float *beta, float eps,
                                                                 float momentum, float *running_mean,
                                                                 float *running_var, float *batch_mean,
                                                                 float *batch_invstd, float *scale, float *shift,
                                                                 int C) {
-    double *red = (double *)ds_dynamic_lds();              // [8][32][2]
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        for (int r = rl; r < n_partial; r += 8) {
-            const float *src = partial + ((size_t)r * C + c) * 2;
-            s1 += (double)src[0];
-            s2 += (double)src[1];
-        }
-    }
-    red[(rl * 32 + cl) * 2 + 0] = s1;
-    red[(rl * 32 + cl) * 2 + 1] = s2;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < 8; ++k) {
-            t1 += red[(k * 32 + cl) * 2 + 0];
-            t2 += red[(k * 32 + cl) * 2 + 1];
-        }
+    double *red = (double *)ds_dynamic_lds();              // [FOLD_R][FOLD_C][2]
+    int c;
+    double t1, t2;
+    if (fold_partials(partial, n_partial, C, red, c, t1, t2)) {
         const double mean = t1 / count;
         double var = t2 / count - mean * mean;             // biased (normalisation) variance
         if (var < 0.0) var = 0.0;
@@ -213,7 +225,7 @@ extern "C" int ds_bn_stats_finalize_f32(const float *partial, int n_partial, lon
     DS_REQUIRE(partial && gamma && beta && scale && shift, DS_ERR_NULL);
     DS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DS_ERR_NULL);
     DS_REQUIRE(C > 0 && n_partial > 0 && count > 0, DS_ERR_BAD_SHAPE);
-    DS_LAUNCH(bn_stats_finalize_kernel, ds_ceil_div(C, 32), 256, 8 * 32 * 2 * sizeof(double), stream, partial,
+    DS_LAUNCH(bn_stats_finalize_kernel, ds_ceil_div(C, FOLD_C), 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream, partial,
               n_partial, (double)count, gamma, beta, eps, momentum, running_mean, running_var, batch_mean,
               batch_invstd, scale, shift, C);
     return ds_last_launch_error();
@@ -356,24 +368,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *g1, con
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float *partial, int n_partial, double count,
                                                               const float *gamma, const float *invstd,
                                                               float *ggamma, float *gbeta, float *coef, int C) {
-    double *red = (double *)ds_dynamic_lds();              // [8][32][2]
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rl; r < n_partial; r += 8) {
-            s1 += (double)partial[((size_t)r * C + c) * 2 + 0];
-            s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
-        }
-    red[(rl * 32 + cl) * 2 + 0] = s1;
-    red[(rl * 32 + cl) * 2 + 1] = s2;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < 8; ++k) {
-            t1 += red[(k * 32 + cl) * 2 + 0];
-            t2 += red[(k * 32 + cl) * 2 + 1];
-        }
+    double *red = (double *)ds_dynamic_lds();              // [FOLD_R][FOLD_C][2]
+    int c;
+    double t1, t2;
+    if (fold_partials(partial, n_partial, C, red, c, t1, t2)) {
         gbeta[c] = (float)t1;
         ggamma[c] = (float)t2;
         coef[c] = gamma[c] * invstd[c];
@@ -548,7 +546,7 @@ extern "C" int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act,
               partial, n_pix, C, ppb);
     int rc = ds_last_launch_error();
     if (rc) return rc;
-    DS_LAUNCH(bn_bwd_finalize_kernel, ds_ceil_div(C, 32), 256, 8 * 32 * 2 * sizeof(double), stream,
+    DS_LAUNCH(bn_bwd_finalize_kernel, ds_ceil_div(C, FOLD_C), 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream,
               (const float *)partial, blocks, (double)n_pix, gamma, invstd, ggamma, gbeta, coef, C);
     rc = ds_last_launch_error();
     if (rc) return rc;

@@ -43,6 +43,7 @@ struct ConvKB {
     int n_ntiles;
     int flags;
     unsigned y_bytes;               // size of y (and of the residual) in bytes, for the buffer descriptors
+    int OS, OH0, OW0;               // output pixel (r, c) of the tile grid lands at (OS*r + OH0, OS*c + OW0) of y
 };
 
 // NIT: float4 staging slots per thread (compile time, so all loads of a chunk are issued together);
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         if (seg < p.NI && gseg < p.n_segs) {
             const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
             const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
-            if (rr < p.Hr) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+            if (rr < p.Hr) off = ((b * p.Ho + p.OS * rr + p.OH0) * p.Wo + p.OS * c + p.OW0) * p.Cout;
         }
         out_off[m] = off;
     }
@@ -581,19 +582,24 @@ struct PlanB {
     ConvKB k;
 };
 
-static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
+// `s` describes the tile grid: input [B,H,W,Cin], KS x KS taps, stride s->stride, output grid Ho x Wo computed
+// with `pad`.  The forward convolution writes that grid densely; the stride-2 data gradient runs four such
+// grids (parity classes) whose outputs interleave in y (out_* arguments).
+static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3, int out_stride = 1, int out_h0 = 0, int out_w0 = 0,
+                     int out_H = 0, int out_W = 0, int grid_H = 0, int grid_W = 0) {
     DS_REQUIRE(s != nullptr, DS_ERR_NULL);
     DS_REQUIRE(s->B > 0 && s->H > 0 && s->W > 0 && s->Cin > 0 && s->Cout > 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(s->KS == 3 || s->KS == 5, DS_ERR_UNSUPPORTED);
     DS_REQUIRE(s->stride == 1 || s->stride == 2, DS_ERR_UNSUPPORTED);
     DS_REQUIRE(s->Cin % CKB == 0 && s->Cout % 64 == 0, DS_ERR_BAD_SHAPE);
     const int pad = s->KS / 2;
-    const int Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
-    const int Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
+    const int Ho = grid_H > 0 ? grid_H : (s->H + 2 * pad - s->KS) / s->stride + 1;
+    const int Wo = grid_W > 0 ? grid_W : (s->W + 2 * pad - s->KS) / s->stride + 1;
+    const int yH = out_H > 0 ? out_H : Ho, yW = out_W > 0 ? out_W : Wo;
     DS_REQUIRE(Ho > 0 && Wo > 0 && Wo <= 128, DS_ERR_BAD_SHAPE);
     DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
     DS_REQUIRE((long long)s->B * Ho < (1ll << 24), DS_ERR_BAD_SHAPE);                  // reciprocal index arithmetic
-    DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);   // 32-bit byte offsets
+    DS_REQUIRE((long long)s->B * yH * yW * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);   // 32-bit byte offsets
     const int IS = s->stride;
     const bool big_tile_ok = x3;                 // the 2-wave shape is tuned for (and only built for) bf16x3
     double best = -1.0;
@@ -635,7 +641,8 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     const TileCfgB &cf = kCfgB[bc];
     ConvKB &k = pl.k;
     k.H = s->H; k.W = s->W; k.Cin = s->Cin;
-    k.Hr = Ho; k.Wc = Wo; k.Ho = Ho; k.Wo = Wo; k.Cout = s->Cout;
+    k.Hr = Ho; k.Wc = Wo; k.Ho = yH; k.Wo = yW; k.Cout = s->Cout;
+    k.OS = out_stride; k.OH0 = out_h0; k.OW0 = out_w0;
     k.IS = IS; k.dh_min = -pad; k.dw_min = -pad;
     k.RT = brt; k.NI = bni;
     k.segs_per_img = ds_ceil_div(Ho, brt);
@@ -653,7 +660,7 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3) {
     k.pitch = best_pitch;
     k.seg_pix = k.rows_in * k.pitch;
     k.n_ntiles = s->Cout / cf.NTILE;
-    k.y_bytes = (unsigned)((long long)s->B * Ho * Wo * s->Cout * 4);
+    k.y_bytes = (unsigned)((long long)s->B * yH * yW * s->Cout * 4);
     pl.cfg = bc;
     pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
     pl.grid = pl.n_mtiles * k.n_ntiles;
@@ -757,14 +764,82 @@ extern "C" int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const vo
     return ds_last_launch_error();
 }
 
-// stride-1 data gradient on the bf16 matrix cores: the forward kernel on dY with the flipped/transposed bank
+// banks of the 5x5 stride-2 data gradient: parity class (ph, pw) of dX only receives taps kh = ph (mod 2),
+// kw = pw (mod 2), at input offsets d = (p + 2 - k) / 2 in {1, 0, -1} -- a 3x3 stride-1 convolution over dY
+// per class; classes with two taps per axis carry zero filters for the third (window row/col 0, d = -1).
+// Layout: [class ph*2+pw][Cout/16][tap (d_h+1)*3 + (d_w+1)][Cin][16] bf16 hi (+ lo).
+__global__ void __launch_bounds__(256) pack_conv_dgrad_s2_bf16_kernel(const float *w, __bf16 *hi, __bf16 *lo, int Cout,
+                                                                      int Cin) {
+    const long long per_class = (long long)9 * Cout * Cin;
+    const long long n = 4 * per_class;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int cls = (int)(i / per_class);
+        long long r = i - cls * per_class;
+        const int kk = (int)(r & 15);
+        r >>= 4;
+        const int ci = (int)(r % Cin);
+        r /= Cin;
+        const int t = (int)(r % 9);
+        const int kc = (int)(r / 9);
+        const int co = kc * 16 + kk;                    // contraction channel = forward output channel
+        const int ph = cls >> 1, pw = cls & 1;
+        const int dh = t / 3 - 1, dw = t % 3 - 1;       // input offset of this window position
+        const int kh = ph + 2 - 2 * dh, kw = pw + 2 - 2 * dw;
+        float v = 0.0f;
+        if (kh >= 0 && kh < 5 && kw >= 0 && kw < 5) v = w[(((size_t)co * Cin + ci) * 5 + kh) * 5 + kw];
+        const __bf16 h = (__bf16)v;
+        hi[i] = h;
+        lo[i] = (__bf16)(v - (float)h);
+    }
+}
+
+extern "C" int ds_pack_conv_weight_dgrad_s2_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin,
+                                                 void *stream) {
+    DS_REQUIRE(w_oihw && w_hi && w_lo, DS_ERR_NULL);
+    DS_REQUIRE(Cout > 0 && Cin > 0 && (Cout % CKB) == 0, DS_ERR_BAD_SHAPE);
+    const long long n = (long long)36 * Cout * Cin;
+    long long g = (n + 255) / 256;
+    DS_LAUNCH(pack_conv_dgrad_s2_bf16_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w_oihw, (__bf16 *)w_hi,
+              (__bf16 *)w_lo, Cout, Cin);
+    return ds_last_launch_error();
+}
+
+// data gradient on the bf16 matrix cores.  3x3 stride 1: the forward kernel on dY with the flipped /
+// transposed bank (ds_pack_conv_weight_dgrad_bf16).  5x5 stride 2: four parity-class launches over the dY
+// grid with the banks of ds_pack_conv_weight_dgrad_s2_bf16, outputs interleaved in dX.
 extern "C" int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const void *w_hi, const void *w_lo,
                                   float *gx, void *stream) {
     DS_REQUIRE(s, DS_ERR_NULL);
-    DS_REQUIRE(s->stride == 1 && s->KS == 3, DS_ERR_UNSUPPORTED);
-    ds_conv_shape t = *s;
-    t.Cin = s->Cout;
-    t.Cout = s->Cin;
-    return ds_conv_fwd_bf16(&t, gy, w_hi, w_lo, nullptr, nullptr, nullptr, gx, nullptr, 0, stream);
+    if (s->stride == 1) {
+        DS_REQUIRE(s->KS == 3, DS_ERR_UNSUPPORTED);
+        ds_conv_shape t = *s;
+        t.Cin = s->Cout;
+        t.Cout = s->Cin;
+        return ds_conv_fwd_bf16(&t, gy, w_hi, w_lo, nullptr, nullptr, nullptr, gx, nullptr, 0, stream);
+    }
+    DS_REQUIRE(s->KS == 5 && s->stride == 2 && gy && w_hi && w_lo && gx, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(DS_ALIGNED16(gy) && DS_ALIGNED16(w_hi) && DS_ALIGNED16(w_lo) && DS_ALIGNED16(gx), DS_ERR_ALIGNMENT);
+    const int Ho = (s->H - 1) / 2 + 1, Wo = (s->W - 1) / 2 + 1;          // dY grid
+    const size_t bank = (size_t)9 * s->Cout * s->Cin;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        const int Hr = (s->H - ph + 1) / 2, Wc = (s->W - pw + 1) / 2;    // dX rows / columns of this parity
+        if (Hr <= 0 || Wc <= 0) continue;
+        ds_conv_shape t = {s->B, Ho, Wo, s->Cout, s->Cin, 3, 1};
+        PlanB pl;
+        int rc = plan_bf16(pl, &t, true, 2, ph, pw, s->H, s->W, Hr, Wc);
+        if (rc != DS_OK) return rc;
+        pl.k.x = gy;
+        pl.k.w_hi = (const __bf16 *)w_hi + cls * bank;
+        pl.k.w_lo = (const __bf16 *)w_lo + cls * bank;
+        pl.k.y = gx;
+        pl.k.scale = pl.k.shift = pl.k.res = nullptr;
+        pl.k.stats = nullptr;
+        pl.k.flags = 0;
+        launch_b<3, true>(pl, stream);
+        rc = ds_last_launch_error();
+        if (rc) return rc;
+    }
+    return DS_OK;
 }
 

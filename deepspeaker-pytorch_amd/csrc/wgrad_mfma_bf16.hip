@@ -135,35 +135,25 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
             e[0] = gbase; e[1] = rows_left; e[2] = xbase; e[3] = h0;
         }
     };
-    // branch-free: all segment-table reads first, then every load (masked slots read element 0 and are
-    // zeroed when written to LDS) -- a conditional load per slot serialises LDS latency + branch + load
-    unsigned g_ok = 0, x_ok = 0;                        // validity bits of the loaded tile
     auto issue_loads = [&](int buf) {
         const int *st = segtab + buf * p.NI * 4;
-        int goff[GSL], xoff[XSL];
-        g_ok = 0;
-        x_ok = 0;
 #pragma unroll
         for (int it = 0; it < GSL; ++it) {
-            const int sr = g_sr[it] >= 0 ? g_sr[it] : 0;
-            const int *e = st + (sr >> 16) * 4;
-            const bool ok = g_sr[it] >= 0 && (sr & 0xFFFF) < e[1];
-            goff[it] = ok ? e[0] + g_rel[it] : 0;
-            g_ok |= ok ? (1u << it) : 0u;
+            gv[it] = zero4;
+            if (g_sr[it] >= 0) {
+                const int *e = st + (g_sr[it] >> 16) * 4;
+                if ((g_sr[it] & 0xFFFF) < e[1]) gv[it] = *(const f32x4 *)(p.gz + (e[0] + g_rel[it]));
+            }
         }
 #pragma unroll
         for (int it = 0; it < XSL; ++it) {
-            const int sr = x_sr[it] >= 0 ? x_sr[it] : 0;
-            const int *e = st + (sr >> 16) * 4;
-            const int h = e[3] + (sr & 0xFFFF);
-            const bool ok = x_sr[it] >= 0 && h >= 0 && h < p.H;
-            xoff[it] = ok ? e[2] + x_rel[it] : 0;
-            x_ok |= ok ? (1u << it) : 0u;
+            xv[it] = zero4;
+            if (x_sr[it] >= 0) {
+                const int *e = st + (x_sr[it] >> 16) * 4;
+                const int h = e[3] + (x_sr[it] & 0xFFFF);
+                if (h >= 0 && h < p.H) xv[it] = *(const f32x4 *)(p.x + (e[2] + x_rel[it]));
+            }
         }
-#pragma unroll
-        for (int it = 0; it < GSL; ++it) gv[it] = *(const f32x4 *)(p.gz + goff[it]);
-#pragma unroll
-        for (int it = 0; it < XSL; ++it) xv[it] = *(const f32x4 *)(p.x + xoff[it]);
     };
     auto put_split = [&](char *rec, int q, const f32x4 v) {     // 4 channels -> hi / lo halves of the record
         bf16x4 h, l;
@@ -192,13 +182,13 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
         for (int it = 0; it < GSL; ++it)
             if (g_sr[it] != -1) {
                 const int i = tid + it * 256;
-                put_split(gzt + (size_t)(i / QV) * WB_REC, i % QV, (g_ok >> it) & 1 ? gv[it] : zero4);
+                put_split(gzt + (size_t)(i / QV) * WB_REC, i % QV, gv[it]);
             }
 #pragma unroll
         for (int it = 0; it < XSL; ++it)
             if (x_sr[it] != -1) {
                 const int i = tid + it * 256;
-                put_split(xt + (size_t)(i / QV) * WB_REC, i % QV, (x_ok >> it) & 1 ? xv[it] : zero4);
+                put_split(xt + (size_t)(i / QV) * WB_REC, i % QV, xv[it]);
             }
         fill_segtab(tile + p.S, buf ^ 1);
         __syncthreads();

@@ -50,6 +50,7 @@ class StageWeights:
     l_conv2_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
     l_conv1_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
     l_conv2_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+    conv_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None     # 5x5 stride 2: four parity-class banks
 
 
 @dataclass
@@ -135,6 +136,11 @@ class Engine:
                 sw.l_conv1_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3)
                 sw.l_conv2_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3)
                 if with_dgrad:
+                    if i > 1:
+                        hi = torch.empty(36 * co * ci, dtype=torch.bfloat16, device=w.device)
+                        lo = torch.empty_like(hi)
+                        lib.call("ds_pack_conv_weight_dgrad_s2_bf16", self._p(w), self._p(hi), self._p(lo), co, ci, st)
+                        sw.conv_dgrad_bf16 = (hi, lo)
                     sw.l_conv1_dgrad_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3, True)
                     sw.l_conv2_dgrad_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3, True)
             if with_dgrad:

@@ -122,8 +122,13 @@ int ds_pack_conv_weight_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Co
                              void *stream);             /* -> [Cin/16][KS*KS][Cout][16] bf16 (x2) */
 int ds_pack_conv_weight_dgrad_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin,
                                    int KS, void *stream);   /* flipped / transposed bank, stride 1 */
+/* the four parity-class banks of the 5x5 stride-2 data gradient: 36 * Cout * Cin bf16 each (hi, lo) */
+int ds_pack_conv_weight_dgrad_s2_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int Cin,
+                                      void *stream);
+/* data gradient: 3x3 stride 1 (banks of ds_pack_conv_weight_dgrad_bf16) or 5x5 stride 2 (banks of
+ * ds_pack_conv_weight_dgrad_s2_bf16; `s` is the FORWARD layer shape in both cases) */
 int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const void *w_hi, const void *w_lo,
-                       float *gx, void *stream);            /* 3x3 stride-1 data gradient */
+                       float *gx, void *stream);
 int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3);
 /* tiling the bf16 planner picks: out8 = {M tile, N tile, rows per segment, segments per tile, workgroups,
  * LDS bytes, threads per workgroup, LDS row pitch in pixel records} */

@@ -167,6 +167,36 @@ def test_conv_dgrad(case):
     assert rel_err(nchw(gx), gx_ref) < 2e-6
 
 
+DGRAD_BF16_CASES = [(2, 64, 64, 9, 32, 3, 1), (2, 64, 64, 16, 32, 5, 2), (2, 64, 16, 13, 16, 5, 2),
+                    (3, 128, 64, 7, 8, 5, 2), (1, 64, 32, 1, 4, 5, 2)]
+
+
+@pytest.mark.parametrize("case", DGRAD_BF16_CASES)
+def test_conv_dgrad_bf16x3(case):
+    """split-operand bf16 data gradient: stride 1 (flipped bank) and the four stride-2 parity classes
+    (zero-padded 3x3 banks, interleaved stores)"""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(abs(hash(case)) % 2**31)
+    x = rs.randn(b, ci, h, w)
+    wt = rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    gy = rs.randn(b, co, ho, wo)
+    gx_ref, _ = O.conv2d_bwd(x, wt, gy, s, k // 2)
+    wsrc = to_aligned(wt.astype(np.float32))
+    n = wt.size if s == 1 else 36 * co * ci
+    whi, wlo = aligned((n + 1) // 2), aligned((n + 1) // 2)          # bf16 storage in float32 words
+    if s == 1:
+        lib.call("ds_pack_conv_weight_dgrad_bf16", ptr(wsrc), ptr(whi), ptr(wlo), co, ci, k, None)
+    else:
+        lib.call("ds_pack_conv_weight_dgrad_s2_bf16", ptr(wsrc), ptr(whi), ptr(wlo), co, ci, None)
+    gyh = nhwc(gy.astype(np.float32))
+    gx = aligned((b, h, w, ci), fill=np.nan)
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    lib.call("ds_conv_dgrad_bf16", ctypes.byref(shp), ptr(gyh), ptr(whi), ptr(wlo), ptr(gx), None)
+    assert rel_err(nchw(gx), gx_ref) < 3e-5
+
+
 @pytest.mark.parametrize("C,npix,with_g2,with_act", [(64, 700, True, True), (128, 300, False, True),
                                                        (512, 50, False, False), (256, 1030, True, False)])
 def test_bn_bwd(C, npix, with_g2, with_act):

@@ -320,7 +320,17 @@ def test_conv_backward_kernels_vs_oracle(dev, case):
     gw = _wgrad(eng, shp, xh, gyh, (co, ci, k, k))
     assert rel_err(gx.cpu().numpy().transpose(0, 3, 1, 2), gx_ref) < 1e-5
     assert rel_err(gw.cpu().numpy(), gw_ref) < 1e-5
-    gw3 = _wgrad(eng, shp, xh, gyh, (co, ci, k, k), x3=True)        # split-operand bf16 matrix cores
+    # split-operand bf16 matrix cores
+    n = wt.size if s == 1 else 36 * co * ci
+    whi = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    wlo = torch.empty_like(whi)
+    if s == 1:
+        eng.lib.call("ds_pack_conv_weight_dgrad_bf16", eng._p(tw), eng._p(whi), eng._p(wlo), co, ci, k, eng._stream(tw))
+    else:
+        eng.lib.call("ds_pack_conv_weight_dgrad_s2_bf16", eng._p(tw), eng._p(whi), eng._p(wlo), co, ci, eng._stream(tw))
+    gx3 = _dgrad(eng, shp, gyh, None, (whi, wlo))
+    assert rel_err(gx3.cpu().numpy().transpose(0, 3, 1, 2), gx_ref) < 3e-5
+    gw3 = _wgrad(eng, shp, xh, gyh, (co, ci, k, k), x3=True)
     assert rel_err(gw3.cpu().numpy(), gw_ref) < 3e-5
     assert torch.equal(gw3, _wgrad(eng, shp, xh, gyh, (co, ci, k, k), x3=True))     # deterministic
 
