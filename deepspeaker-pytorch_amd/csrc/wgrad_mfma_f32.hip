@@ -257,12 +257,18 @@ __global__ void __launch_bounds__(256) wgrad_c1_kernel(const Wgrad1K p) {
     }
 }
 
-// gw[co][0][tap] = sum_blk partial[blk][tap][co]
+// gw[co][0][tap] = sum_blk partial[blk][tap][co]: 8 lanes share one output (fixed interleave), then a fixed
+// xor-tree over the 8 lanes -- deterministic, and 50 workgroups instead of 7 serial ones
 __global__ void __launch_bounds__(256) wgrad_c1_reduce_kernel(const float *partial, float *gw, int n_blk) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < 1600) {
-        float s = 0.f;
-        for (int k = 0; k < n_blk; ++k) s += partial[(size_t)k * 1600 + i];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 3, r = t & 7;
+    float s = 0.f;
+    if (i < 1600)
+        for (int k = r; k < n_blk; k += 8) s += partial[(size_t)k * 1600 + i];
+    s += ds_shfl_xor(s, 1);
+    s += ds_shfl_xor(s, 2);
+    s += ds_shfl_xor(s, 4);
+    if (i < 1600 && r == 0) {
         const int tap = i / 64, co = i - tap * 64;
         gw[co * 25 + tap] = s;
     }
@@ -368,7 +374,7 @@ extern "C" int ds_conv_wgrad_f32(const ds_conv_shape *s, const float *x, const f
         DS_LAUNCH(wgrad_c1_kernel, grid, 256, lds, stream, k);
         int rc = ds_last_launch_error();
         if (rc) return rc;
-        DS_LAUNCH(wgrad_c1_reduce_kernel, 7, 256, 0, stream, (const float *)workspace, gw_oihw, grid);
+        DS_LAUNCH(wgrad_c1_reduce_kernel, 50, 256, 0, stream, (const float *)workspace, gw_oihw, grid);
         return ds_last_launch_error();
     }
     WgradPlan pl;
