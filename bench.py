@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--split-apn", action="store_true",
                     help="three separate 256-utterance forwards (the reference's call pattern, "
                          "train_triplet.py:215) instead of one 768-utterance forward")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="take the N > 1 code path (RCCL all-gathers, barrier, max-over-ranks) with a single rank; "
+                         "launch with torch.distributed.run --nproc-per-node 1 (self-test of the multi-GPU path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +94,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_collectives           # the data-parallel code path
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
@@ -112,12 +116,12 @@ def main():
     c2 = (c1 + 1 + torch.randint(0, 63, (BATCH_TRIPLETS,), generator=g)) % 64
     c1, c2 = c1.to(dev), c2.to(dev)
     labels_loc = torch.cat([c1, c1, c2])
-    emb_glob = torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if world > 1 else None
-    lab_glob = torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if world > 1 else None
+    emb_glob = torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if multi else None
+    lab_glob = torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if multi else None
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -134,13 +138,17 @@ def main():
                 else:                                   # eval mode: per-utterance results do not depend on batching
                     e_all = model(data_all)
                     embs = list(e_all.split(BATCH_TRIPLETS))
+                # cross-GPU semi-hard negative search over the all-gathered global batch (BASELINE configs[2]);
+                # at N = 1 the candidate set is the local batch, so per-GPU work has the same shape.  The
+                # gathers run on RCCL's stream while the local loss / filter kernels run on ours.
+                if multi:
+                    h_emb = dist.all_gather_into_tensor(emb_glob, e_all, async_op=True)
+                    h_lab = dist.all_gather_into_tensor(lab_glob, labels_loc, async_op=True)
                 loss = loss_fn.forward(*embs)
                 sel = select_triplets(*embs, margin=0.1)
-                # cross-GPU semi-hard negative search over the all-gathered global batch (BASELINE configs[2]);
-                # at N = 1 the candidate set is the local batch, so per-GPU work has the same shape
-                if world > 1:
-                    dist.all_gather_into_tensor(emb_glob, e_all)
-                    dist.all_gather_into_tensor(lab_glob, labels_loc)
+                if multi:
+                    h_emb.wait()
+                    h_lab.wait()
                     mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob)
                 else:
                     mined = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels_loc)
@@ -161,7 +169,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         prof, eng.profile = eng.profile, None
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -241,7 +249,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
