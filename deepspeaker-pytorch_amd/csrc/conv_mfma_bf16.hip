@@ -193,10 +193,15 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         }
         out_off[m] = off;
     }
+    // Which pixel of its 32-pixel sub-tile a lane owns is free (the epilogue un-permutes): it is chosen so
+    // that the two 16-lane SERVICE GROUPS of a ds_read_b128 -- lanes {0-3,12-15,20-27} and {4-11,16-19,
+    // 28-31} -- each read 16 CONSECUTIVE pixels, i.e. consecutive 48-byte records that walk all 64 banks.
+    const int lpix = (l31 < 4 || l31 >= 28) ? l31
+                   : (l31 < 12) ? l31 + 12 : (l31 < 16) ? l31 - 8 : (l31 < 20) ? l31 + 8 : l31 - 12;
     int a_off[MSUB];                                           // byte offset of this lane's fragment
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
-        const int m = (wm * MSUB + ms) * 32 + l31;
+        const int m = (wm * MSUB + ms) * 32 + lpix;
         const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
         const int rem = m - seg * pix_per_seg;
         const int r = ds_div_small(rem, p.Wc, rcp_wc), c = rem - r * p.Wc;
@@ -447,7 +452,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
-                *(f32x4 *)(tb + l31 * TP + ns * 32 + 8 * g + 4 * lhi) = v;
+                *(f32x4 *)(tb + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
             }
         ds_wave_sync();
 #pragma unroll
@@ -525,11 +530,9 @@ __global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float 
 }
 
 // LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for a candidate row pitch: simulates
-// the two 16-lane service groups of lanes 0..31 (the upper half-wave behaves identically) over every
-// 32-row sub-tile of the M tile.  Bank slot of a record = (record * PSB / 16) mod 16.
+// the two 16-lane service groups of lanes 0..31 (the upper half-wave behaves identically; each group
+// holds 16 consecutive pixels, see `lpix` in the kernel) over every 32-row sub-tile of the M tile.  Bank slot of a record = (record * PSB / 16) mod 16.
 static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in, int pitch) {
-    static const int G0[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
-    static const int G1[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
     const int pix_per_seg = RT * Wc, seg_pix = rows_in * pitch;
     double total = 0.0;
     int n = 0;
@@ -538,7 +541,7 @@ static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in
             int cnt[16] = {0};
             int worst = 0;
             for (int j = 0; j < 16; ++j) {
-                const int m = m0 + (g ? G1[j] : G0[j]);
+                const int m = m0 + 16 * g + j;       // the lane -> pixel permutation makes a group's pixels consecutive
                 const int seg = m / pix_per_seg, rem = m % pix_per_seg;
                 const int r = rem / Wc, c = rem % Wc;
                 const int rec = (seg < NI) ? seg * seg_pix + (IS * r) * pitch + c : 0;
@@ -554,7 +557,7 @@ static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in
 
 // ---- host-side plan (same objective as the f32 planner; limits: 64 KiB LDS, 2 workgroups per CU) ----
 struct TileCfgB { int MT, NTILE, WM, wg_per_cu, NTHR; };
-constexpr int kNumCfgB = 8;
+constexpr int kNumCfgB = 9;
 constexpr TileCfgB kCfgB[kNumCfgB] = {
     {128, 64, 2, 3, 256},      // <KS,2,1,2,2>
     {160, 128, 1, 2, 256},     // <KS,5,1,1,4>
@@ -566,9 +569,10 @@ constexpr TileCfgB kCfgB[kNumCfgB] = {
     {320, 128, 2, 1, 256},     // <KS,5,2,2,2>
     {320, 64, 2, 2, 128},      // <KS,5,2,2,1>: the 2-wave shape for 64-channel layers
     {128, 128, 1, 2, 128},     // <KS,4,2,1,2>: 128x64 register tiles where 160-row tiles quantise badly
+    {128, 256, 1, 1, 256},     // <KS,4,2,1,4>: the same with the whole LDS (three 10x4 maps of the last 5x5 layer)
 };
 constexpr size_t kLdsCapB[kNumCfgB] = {64 * 1024, 64 * 1024, 64 * 1024, 80 * 1024, 160 * 1024 - 64, 160 * 1024 - 64,
-                                       80 * 1024, 80 * 1024};
+                                       80 * 1024, 80 * 1024, 160 * 1024 - 64};
 
 // bytes of the epilogue's per-wave transposition buffers (they alias the pixel tile)
 static size_t epi_bytes(const TileCfgB &cf) {
@@ -632,7 +636,7 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3, int out_stride 
             const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * cf.wg_per_cu;
             if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
             else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
-            static const int pref[kNumCfgB] = {0, 2, 1, 7, 4, 5, 6, 3};
+            static const int pref[kNumCfgB] = {0, 2, 1, 8, 5, 6, 7, 4, 3};
             eff += 1e-9 * rt + 1e-6 * pref[c];
             if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; }
         }
@@ -701,7 +705,8 @@ static void launch_b(const PlanB &pl, void *stream) {
         else if (pl.cfg == 4) launch_big_b<KS, 5, 1, 4>(pl, stream);
         else if (pl.cfg == 5) launch_big_b<KS, 5, 2, 2>(pl, stream);
         else if (pl.cfg == 6) launch_big_b<KS, 5, 2, 1>(pl, stream);
-        else launch_big_b<KS, 4, 1, 2>(pl, stream);
+        else if (pl.cfg == 7) launch_big_b<KS, 4, 1, 2>(pl, stream);
+        else launch_big_b<KS, 4, 1, 4>(pl, stream);
     }
 }
 
