@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int C1_RT = 4;          // output rows per workgroup
+constexpr int C1_RT = 8;          // output rows per workgroup
 constexpr int C1_COUT = 64;
 
 struct Conv1K {
