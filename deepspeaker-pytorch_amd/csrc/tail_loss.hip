@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor,
                                                             const long long *cand_label, float *partial,
                                                             int N, int M, int D, float eps, int n_agroups) {
     float *lds = ds_dynamic_lds();
-    float *arow = lds;                                     // [MINE_A][D]
+    float *arow = lds;                                     // [D][MINE_A]: the 8 anchors' values of one dimension are adjacent
     float *ctile = arow + MINE_A * D;                      // [256][MINE_P]
     // the reduction scratch aliases the candidate tile (dead by then): 2 x [2][MINE_A][256] words
     float *red_d = ctile;
@@ -244,42 +244,60 @@ __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor,
     const int tid = threadIdx.x;
     const int ag = blockIdx.x % n_agroups, ct = blockIdx.x / n_agroups;
     const int a0 = ag * MINE_A, j0 = ct * MINE_C;
-    for (int i = tid; i < MINE_A * D / 4; i += 256) {
-        const int a = i / (D / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (a0 + a < N) v = *(const f32x4 *)(anchor + (size_t)(a0 + a) * D + (i - a * (D / 4)) * 4);
-        *(f32x4 *)(arow + i * 4) = v;
+    for (int i = tid; i < MINE_A * D; i += 256) {          // coalesced rows in, dimension-major out
+        const int a = i / D, k = i - a * D;
+        arow[k * MINE_A + a] = (a0 + a < N) ? anchor[(size_t)(a0 + a) * D + k] : 0.0f;
     }
-    float accd[MINE_A];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[MINE_A / 2];                                // anchors (2p, 2p+1): packed f32 math, two anchors per lane op
 #pragma unroll
-    for (int a = 0; a < MINE_A; ++a) accd[a] = 0.0f;
-    for (int k0 = 0; k0 < D; k0 += MINE_K) {
-        __syncthreads();
-        // stage candidates j0..j0+255, dims k0..k0+31: 8 threads cover one 128-byte row segment
-        for (int i = tid; i < MINE_C * (MINE_K / 4); i += 256) {
+    for (int a = 0; a < MINE_A / 2; ++a) acc2[a] = f32x2{0.0f, 0.0f};
+    // software pipeline over 32-dimension slabs: the next slab's rows are in registers while this one is used
+    constexpr int SLOTS = MINE_C * (MINE_K / 4) / 256;     // 8 float4 per thread and slab
+    f32x4 pre[SLOTS];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < SLOTS; ++it) {
+            const int i = tid + it * 256;
             const int row = i / (MINE_K / 4), q = i - row * (MINE_K / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j0 + row < M && k0 + q * 4 < D) v = *(const f32x4 *)(cand + (size_t)(j0 + row) * D + k0 + q * 4);
-            *(f32x4 *)(ctile + row * MINE_P + q * 4) = v;
+            pre[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j0 + row < M && k0 + q * 4 < D) pre[it] = *(const f32x4 *)(cand + (size_t)(j0 + row) * D + k0 + q * 4);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < D; k0 += MINE_K) {
+        __syncthreads();                                   // previous slab consumed (and the anchor rows are written)
+#pragma unroll
+        for (int it = 0; it < SLOTS; ++it) {
+            const int i = tid + it * 256;
+            const int row = i / (MINE_K / 4), q = i - row * (MINE_K / 4);
+            *(f32x4 *)(ctile + row * MINE_P + q * 4) = pre[it];
         }
         __syncthreads();
+        if (k0 + MINE_K < D) fetch(k0 + MINE_K);
         const int kmax = (D - k0) < MINE_K ? (D - k0) : MINE_K;
         // four dimensions per step: one 16-byte read of this thread's candidate (row pitch 36 floats: the
-        // 16-lane groups of a ds_read_b128 cover all 64 banks) and one broadcast read per anchor; the sum
-        // over dimensions stays strictly sequential per (anchor, candidate)
+        // 16-lane groups of a ds_read_b128 cover all 64 banks) and, per dimension, two broadcast reads of the
+        // 8 anchors; the sum over dimensions stays strictly sequential per (anchor, candidate)
         for (int k = 0; k < kmax; k += 4) {
             const f32x4 c = *(const f32x4 *)(ctile + tid * MINE_P + k);
 #pragma unroll
-            for (int a = 0; a < MINE_A; ++a) {
-                const f32x4 av = *(const f32x4 *)(arow + a * D + k0 + k);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float df = av[u] - c[u];
-                    accd[a] += df * df;
-                }
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a03 = *(const f32x4 *)(arow + (k0 + k + u) * MINE_A);
+                const f32x4 a47 = *(const f32x4 *)(arow + (k0 + k + u) * MINE_A + 4);
+                const f32x2 cc = {c[u], c[u]};
+                const f32x2 d0 = f32x2{a03[0], a03[1]} - cc, d1 = f32x2{a03[2], a03[3]} - cc;
+                const f32x2 d2 = f32x2{a47[0], a47[1]} - cc, d3 = f32x2{a47[2], a47[3]} - cc;
+                acc2[0] = d0 * d0 + acc2[0];
+                acc2[1] = d1 * d1 + acc2[1];
+                acc2[2] = d2 * d2 + acc2[2];
+                acc2[3] = d3 * d3 + acc2[3];
             }
         }
     }
+    float accd[MINE_A];
+#pragma unroll
+    for (int a = 0; a < MINE_A; ++a) accd[a] = acc2[a >> 1][a & 1];
     __syncthreads();
     const int j = j0 + tid;
     const long long lc = j < M ? cand_label[j] : 0;
