@@ -307,6 +307,39 @@ class _ResCNNTrainFn(torch.autograd.Function):
         return (None, None) + tuple(grads.get(n) for n in ctx.param_names)
 
 
+class GraphedEmbedder:
+    """The eval forward of one input shape captured once into a HIP graph and replayed per call.
+
+    `emb = g(x)` copies x into the graph's static input, replays, and returns the graph's static output
+    tensor (valid until the next call; clone it to keep it).  Weights are read at replay time through the
+    packed copies made at capture: re-capture after changing parameters."""
+
+    def __init__(self, model: "DeepSpeakerModel", example: torch.Tensor):
+        _require_cuda(example, "GraphedEmbedder")
+        if model.training:
+            raise RuntimeError("GraphedEmbedder captures the eval forward: call model.eval() first")
+        self.model = model
+        self.static_x = example.detach().contiguous().float().clone()
+        cur = torch.cuda.current_stream(example.device)
+        side = torch.cuda.Stream(device=example.device)
+        side.wait_stream(cur)
+        with torch.no_grad(), torch.cuda.stream(side):     # warm-up off the capture: launch plans, LDS opt-ins
+            for _ in range(3):
+                model(self.static_x)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(example.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_e = model(self.static_x)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if tuple(x.shape) != tuple(self.static_x.shape):
+            raise ValueError(f"captured for inputs of shape {tuple(self.static_x.shape)}, got {tuple(x.shape)}")
+        self.static_x.copy_(x)
+        self.graph.replay()
+        return self.static_e
+
+
 class DeepSpeakerModel(nn.Module):
     """reference model.py:153-223.
 
@@ -435,6 +468,11 @@ class DeepSpeakerModel(nn.Module):
             self.features = get_engine().forward_eval_planned(x, self._packed(with_bf16=lowp), self._folded(),
                                                               precision=self.precision)
         return self.features
+
+    def graphed(self, example: torch.Tensor) -> "GraphedEmbedder":
+        """HIP-graph replay of the eval forward for inputs of `example`'s shape (serving: at small batch the
+        17 launches of a forward are launch-bound).  New capability; the reference has no counterpart."""
+        return GraphedEmbedder(self, example)
 
     def forward_classifier(self, x):
         """reference model.py:220-223: logits = classifier(embedding x10), on the f32 matrix cores."""

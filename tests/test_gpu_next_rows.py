@@ -102,3 +102,19 @@ def test_softmax_pretraining_regime(golden):
     assert torch.isfinite(g).all() and float(g.abs().max()) > 0
     v = CrossEntropyLoss().forward(torch.from_numpy(golden["ce_logits"]).cuda(), torch.from_numpy(golden["ce_labels"]).cuda())
     assert abs(float(v) - float(golden["ce_value"])) < 1e-6
+
+
+def test_graph_replay_matches_eager():
+    """HIP-graph replay of the eval forward (DeepSpeakerModel.graphed) is bit-identical to eager launches."""
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel
+    sd = O.make_state_dict(seed=3, num_classes=8)
+    m = DeepSpeakerModel(512, 8, precision="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    x = torch.from_numpy(O.make_input(seed=11, batch=4)).cuda()
+    g = m.graphed(x)
+    with torch.no_grad():
+        ref = m(x).clone()
+        assert torch.equal(g(x), ref)
+        x2 = torch.from_numpy(O.make_input(seed=12, batch=4)).cuda()
+        assert torch.equal(g(x2), m(x2))
