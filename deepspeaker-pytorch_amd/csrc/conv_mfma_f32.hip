@@ -42,6 +42,7 @@ struct ConvK {
     int RT, NI, segs_per_img, n_segs;
     int n_ntiles;
     int flags;
+    unsigned y_bytes;       // bytes of y (and of the residual): buffer descriptors of the epilogue
     int tap_off[MAX_TAPS + 3];     // LDS pixel offset of each tap inside a segment (table-driven path)
 };
 
@@ -269,35 +270,38 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f32_kernel(const ConvK
         s1[ns] = 0.0f;
         s2[ns] = 0.0f;
     }
+    // Ragged-tile rows get an out-of-range buffer offset (store dropped, load returns zero) and a layer
+    // without residual reads "out of range" too: no branch around any memory instruction, so the waits on
+    // the residual rows never include the stores issued in between (see conv_mfma_bf16_kernel.h).
+    const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
+    const ds_buffer rbuf = ds_make_buffer((flags & DS_EPI_RESIDUAL) ? (const void *)p.res : (const void *)p.y,
+                                          (flags & DS_EPI_RESIDUAL) ? p.y_bytes : 0u);
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
-        // all 16 row offsets and (if any) the 16 residual rows of this sub-tile are fetched up front, branch
-        // free, so their latencies overlap instead of queueing behind one another
-        int offs[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) offs[r] = out_off[(wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+        unsigned voff[16][NSUB];
         float resv[16][NSUB];
-        if (flags & DS_EPI_RESIDUAL) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns)
-                    resv[r][ns] = p.res[(size_t)(offs[r] >= 0 ? offs[r] : 0) + col[ns]];
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int off = offs[r];
-            if (off >= 0) {
+            const int off = out_off[(wm * MSUB + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
 #pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns) {
-                    float v = acc[ms][ns][r];
-                    s1[ns] += v;
-                    s2[ns] += v * v;
-                    if (flags & DS_EPI_AFFINE) v = v * sc[ns] + sh[ns];
-                    if (flags & DS_EPI_RESIDUAL) v += resv[r][ns];
-                    if (flags & DS_EPI_CLIP) v = fminf(fmaxf(v, 0.0f), 20.0f);
-                    p.y[(size_t)off + col[ns]] = v;
-                }
+            for (int ns = 0; ns < NSUB; ++ns) voff[r][ns] = off >= 0 ? (unsigned)(off + col[ns]) * 4u : DS_BUFFER_OOB;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) resv[r][ns] = ds_buffer_load_f32(rbuf, voff[r][ns]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) {
+                float v = acc[ms][ns][r];
+                const bool live = voff[r][ns] != DS_BUFFER_OOB;
+                s1[ns] += live ? v : 0.0f;
+                s2[ns] += live ? v * v : 0.0f;
+                v = v * sc[ns] + sh[ns];
+                v += resv[r][ns];
+                if (flags & DS_EPI_CLIP) v = fminf(fmaxf(v, 0.0f), 20.0f);
+                ds_buffer_store_f32(ybuf, voff[r][ns], v);
             }
         }
     }
@@ -353,6 +357,8 @@ struct ConvPlan {
 // last round of workgroups), then tile size and segment height.  Full-width segments only.
 static int plan_tiles(ConvPlan &pl, int B, int Hr, int Wc, int IS, int ext_h, int ext_w, int Cout,
                       bool stats) {
+    DS_REQUIRE((long long)B * pl.k.Ho * pl.k.Wo * pl.k.Cout < (1ll << 30), DS_ERR_BAD_SHAPE);   // 32-bit byte offsets
+    pl.k.y_bytes = (unsigned)((long long)B * pl.k.Ho * pl.k.Wo * pl.k.Cout * 4);
     double best_eff = -1.0;
     int best_cfg = -1, best_rt = 0, best_ni = 0;
     for (int c = 0; c < kNumCfg; ++c) {

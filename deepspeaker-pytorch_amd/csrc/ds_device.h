@@ -71,6 +71,12 @@ __device__ __forceinline__ f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte
 __device__ __forceinline__ void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ds_u32x4, v), b, (int)byte_off, 0, 0);
 }
+__device__ __forceinline__ float ds_buffer_load_f32(ds_buffer b, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void ds_buffer_store_f32(ds_buffer b, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b, (int)byte_off, 0, 0);
+}
 
 // 16-byte aligned base of the dynamic LDS allocation (no static __shared__ objects are
 // declared anywhere, so the base is the start of the workgroup's LDS segment)

@@ -101,6 +101,14 @@ static inline f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte_off) {
 static inline void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
     if ((unsigned long long)byte_off + 16 <= b.bytes) memcpy(b.base + byte_off, &v, 16);
 }
+static inline float ds_buffer_load_f32(ds_buffer b, unsigned byte_off) {
+    float v = 0.0f;
+    if ((unsigned long long)byte_off + 4 <= b.bytes) memcpy(&v, b.base + byte_off, 4);
+    return v;
+}
+static inline void ds_buffer_store_f32(ds_buffer b, unsigned byte_off, float v) {
+    if ((unsigned long long)byte_off + 4 <= b.bytes) memcpy(b.base + byte_off, &v, 4);
+}
 static inline void ds_wave_sync() {
     float all[64];
     emu::wave_exchange(0.0f, all);
