@@ -45,6 +45,7 @@ _SIGNATURES = {
     "ds_conv_plan_describe": (c_int, [POINTER(ConvShape), POINTER(c_int)]),
     "ds_conv5x5s2_c1_stats_rows": (c_int, [c_int, c_int]),
     "ds_conv5x5s2_c1_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv5x5s2_c1_fwd_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv_fwd_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_pack_conv_weight_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_pack_conv_weight_dgrad_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

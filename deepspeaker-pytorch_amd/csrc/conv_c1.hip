@@ -97,6 +97,157 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_kernel(const Conv1K p) {
     }
 }
 
+// ---- the same layer on the bf16 matrix cores with split operands (bf16x3) ----------------------------------
+// As a GEMM the layer is [64 channels x 25 taps] x [25 taps x pixels]: K = 25 is padded to two k-steps of 16.
+// The filters are the A operand (each lane builds its hi / lo fragments once, from the same packed f32 bank
+// as the VALU kernel); a lane's B fragment is 8 taps of ONE output pixel, gathered from the f32 input tile
+// in LDS by 8 scalar reads and split into hi / lo in registers.  Accumulators hold the transposed product
+// (lane = pixel), so the epilogue is the convolution kernel's: turn each 32-pixel sub-tile around through a
+// wave-private LDS buffer and store whole 256-byte pixel rows with raw buffer stores.  ~5x fewer issued
+// instructions per pixel than the VALU kernel (which is issue-bound at 1.6x the time of its HBM traffic).
+__global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, unsigned y_bytes) {
+    float *lds = ds_dynamic_lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.x / p.tiles_per_img;
+    const int r0 = (blockIdx.x - b * p.tiles_per_img) * C1_RT;
+    constexpr int ROWS_IN = 2 * (C1_RT - 1) + 5;
+    constexpr int TP = C1_COUT + 4;                         // transposition-buffer row pitch (floats)
+    const int n_in = ROWS_IN * p.cols_in;
+    float *tb = lds + ((n_in + 3) & ~3) + wave * (32 * TP);  // [32][TP] per wave
+    float *red = lds + ((n_in + 3) & ~3) + 4 * 32 * TP;      // [4 waves][64][2]
+
+    // filter fragments: lane (channel l31 of sub-tile ns, taps 16*ks + 8*lhi .. +7)
+    bf16x8 w_hi[2][2], w_lo[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = 16 * ks + 8 * lhi + i;
+                const float v = t < 25 ? p.w[t * C1_COUT + ns * 32 + l31] : 0.0f;
+                const __bf16 h = (__bf16)v;
+                w_hi[ks][ns][i] = h;
+                w_lo[ks][ns][i] = (__bf16)(v - (float)h);
+            }
+    // tap offsets of this lane's 16 taps inside the input tile (taps >= 25 are padding: read word 0, times 0)
+    int toff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = 16 * ks + 8 * lhi + i;
+            toff[ks][i] = t < 25 ? (t / 5) * p.cols_in + (t % 5) : -1;
+        }
+
+    // stage the zero-padded input tile
+    const float *xb = p.x + (size_t)b * p.H * p.W;
+    for (int i = tid; i < n_in; i += 256) {
+        const int rr = i / p.cols_in, cc = i - rr * p.cols_in;
+        const int h = 2 * r0 - 2 + rr, w = cc - 2;
+        lds[i] = (h >= 0 && h < p.H && w >= 0 && w < p.W) ? xb[(size_t)h * p.W + w] : 0.0f;
+    }
+    __syncthreads();
+
+    const int n_pix = C1_RT * p.Wo, n_sub = (n_pix + 31) >> 5;
+    const float rcp_wo = 1.0f / (float)p.Wo;
+    constexpr int LPP = 16, PPI = 4, NRI = 8;               // lanes per pixel row, rows per instruction
+    const int my_c = (lane % LPP) * 4, my_p = lane / LPP;
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.flags & DS_EPI_AFFINE) {
+        sc4 = *(const f32x4 *)(p.scale + my_c);
+        sh4 = *(const f32x4 *)(p.shift + my_c);
+    }
+    const ds_buffer ybuf = ds_make_buffer(p.y, y_bytes);
+    float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sub = wave; sub < n_sub; sub += 4) {
+        // ---- B fragments: 16 taps of this lane's pixel ----
+        const int m = sub * 32 + l31;
+        const int r = ds_div_small(m, p.Wo, rcp_wo), c = m - r * p.Wo;
+        const float *in = lds + ((m < n_pix) ? (2 * r) * p.cols_in + 2 * c : 0);
+        bf16x8 x_hi[2], x_lo[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float raw = in[toff[ks][i] >= 0 ? toff[ks][i] : 0];
+                const float v = toff[ks][i] >= 0 ? raw : 0.0f;
+                const __bf16 h = (__bf16)v;
+                x_hi[ks][i] = h;
+                x_lo[ks][i] = (__bf16)(v - (float)h);
+            }
+        f32x16 acc[2];
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[ns][q] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], x_lo[ks], acc[ns]);
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_lo[ks][ns], x_hi[ks], acc[ns]);
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], x_hi[ks], acc[ns]);
+        }
+        // ---- epilogue of the sub-tile: lane = pixel, register quad g = channels 8g + 4*lhi .. +3 ----
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ns][4 * g + j];
+                *(f32x4 *)(tb + l31 * TP + ns * 32 + 8 * g + 4 * lhi) = v;
+            }
+        ds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            const int pm = sub * 32 + k * PPI + my_p;
+            const int pr = ds_div_small(pm, p.Wo, rcp_wo), pc = pm - pr * p.Wo;
+            const bool live = pm < n_pix && r0 + pr < p.Ho;
+            const unsigned voff = live ? (unsigned)((((b * p.Ho + r0 + pr) * p.Wo + pc) * C1_COUT) + my_c) * 4u : DS_BUFFER_OOB;
+            f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[j];
+                ps1[j] += live ? t : 0.0f;
+                ps2[j] += live ? t * t : 0.0f;
+                t = t * sc4[j] + sh4[j];
+                if (p.flags & DS_EPI_CLIP) t = fminf(fmaxf(t, 0.0f), 20.0f);
+                v[j] = t;
+            }
+            ds_buffer_store_f32x4(ybuf, voff, v);
+        }
+        ds_wave_sync();
+    }
+    if (p.flags & DS_EPI_STATS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ps1[j] += ds_shfl_xor(ps1[j], 16);
+            ps2[j] += ds_shfl_xor(ps2[j], 16);
+            ps1[j] += ds_shfl_xor(ps1[j], 32);
+            ps2[j] += ds_shfl_xor(ps2[j], 32);
+            if (my_p == 0) {
+                red[(wave * C1_COUT + my_c + j) * 2 + 0] = ps1[j];
+                red[(wave * C1_COUT + my_c + j) * 2 + 1] = ps2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < C1_COUT) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int s = 0; s < 4; ++s) {
+                a1 += red[(s * C1_COUT + tid) * 2 + 0];
+                a2 += red[(s * C1_COUT + tid) * 2 + 1];
+            }
+            float *dst = p.stats + ((size_t)blockIdx.x * C1_COUT + tid) * 2;
+            dst[0] = a1;
+            dst[1] = a2;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ds_conv5x5s2_c1_stats_rows(int B, int H) {
@@ -125,5 +276,34 @@ extern "C" int ds_conv5x5s2_c1_fwd_f32(const float *x, const float *w_packed, co
     k.flags = flags;
     const size_t lds = ((size_t)(2 * (C1_RT - 1) + 5) * k.cols_in + 16 * C1_COUT * 2) * 4;
     DS_LAUNCH(conv5x5s2_c1_kernel, B * k.tiles_per_img, 256, lds, stream, k);
+    return ds_last_launch_error();
+}
+
+// the same contract on the bf16 matrix cores with split operands (f32-class accuracy); same packed filter
+// bank (ds_pack_conv1_weight_f32), same statistics rows
+extern "C" int ds_conv5x5s2_c1_fwd_bf16(const float *x, const float *w_packed, const float *scale,
+                                        const float *shift, float *y, float *stats_partial, int B,
+                                        int H, int W, int Cout, int flags, void *stream) {
+    DS_REQUIRE(x && w_packed && y, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_AFFINE) || (scale && shift), DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_STATS) || stats_partial, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_RESIDUAL), DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(B > 0 && H > 0 && W > 0 && W <= 256, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(Cout == C1_COUT, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(DS_ALIGNED16(w_packed) && DS_ALIGNED16(y) && (!scale || DS_ALIGNED16(scale)) &&
+                   (!shift || DS_ALIGNED16(shift)), DS_ERR_ALIGNMENT);
+    Conv1K k;
+    k.x = x; k.w = w_packed; k.scale = scale; k.shift = shift; k.y = y; k.stats = stats_partial;
+    k.H = H; k.W = W;
+    k.Ho = (H - 1) / 2 + 1;
+    k.Wo = (W - 1) / 2 + 1;
+    DS_REQUIRE((long long)B * k.Ho * k.Wo * C1_COUT < (1ll << 30), DS_ERR_BAD_SHAPE);     // 32-bit byte offsets
+    k.tiles_per_img = ds_ceil_div(k.Ho, C1_RT);
+    k.cols_in = 2 * (k.Wo - 1) + 5;
+    k.flags = flags;
+    const size_t n_in = (size_t)(2 * (C1_RT - 1) + 5) * k.cols_in;
+    const size_t lds = (((n_in + 3) & ~(size_t)3) + 4 * 32 * (C1_COUT + 4) + 4 * C1_COUT * 2) * 4;
+    DS_LAUNCH(conv5x5s2_c1_bf16_kernel, B * k.tiles_per_img, 256, lds, stream, k,
+              (unsigned)((long long)B * k.Ho * k.Wo * C1_COUT * 4));
     return ds_last_launch_error();
 }

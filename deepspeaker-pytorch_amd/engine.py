@@ -231,7 +231,7 @@ class Engine:
         return (y, stats) if want_stats else y
 
     def conv1(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, scale=None, shift=None,
-              flags: int = 0, want_stats: bool = False):
+              flags: int = 0, want_stats: bool = False, lowp: bool = False):
         ho, wo = conv_out(H, 5, 2), conv_out(W, 5, 2)
         y = torch.empty((B, ho, wo, 64), dtype=torch.float32, device=x.device)
         stats = None
@@ -239,8 +239,9 @@ class Engine:
             rows = self.lib.raw("ds_conv5x5s2_c1_stats_rows")(B, H)
             stats = torch.empty((rows, 64, 2), dtype=torch.float32, device=x.device)
             flags |= DS_EPI_STATS
-        self.lib.call("ds_conv5x5s2_c1_fwd_f32", self._p(x), self._p(wp), self._p(scale), self._p(shift),
-                      self._p(y), self._p(stats), B, H, W, 64, flags, self._stream(x))
+        # lowp: the split-operand bf16 matrix-core kernel (same bank, same contract); f32: the exact VALU kernel
+        self.lib.call("ds_conv5x5s2_c1_fwd_bf16" if lowp else "ds_conv5x5s2_c1_fwd_f32", self._p(x), self._p(wp),
+                      self._p(scale), self._p(shift), self._p(y), self._p(stats), B, H, W, 64, flags, self._stream(x))
         return y, stats
 
     def bn_finalize(self, stats: torch.Tensor, count: int, bn: BNParams, update_running: bool = True,
@@ -346,7 +347,7 @@ class Engine:
             if i == 1:
                 ho, wo = conv_out(h, 5, 2), conv_out(w, 5, 2)
                 a = buf(B, ho, wo, 64)
-                calls.append((self.lib.raw("ds_conv5x5s2_c1_fwd_f32"),
+                calls.append((self.lib.raw("ds_conv5x5s2_c1_fwd_bf16" if precision != "f32" else "ds_conv5x5s2_c1_fwd_f32"),
                               (x_slot, self._p(sw.conv), self._p(sc), self._p(sh), self._p(a), None, B, h, w, 64, AC,
                                st_slot), None, 0.0))
                 h, w = ho, wo
@@ -409,7 +410,8 @@ class Engine:
         the convolution epilogues -- 3 launches per stage, no intermediate normalisation pass.
 
         precision: "f32" exact-f32 MFMA (the parity path); "bf16x3" split-operand bf16 MFMA (f32-class
-        accuracy); "bf16" plain bf16 operands (speed mode).  conv1, fc and the tail are f32 in all modes."""
+        accuracy); "bf16" plain bf16 operands (speed mode).  conv1 runs its split-operand bf16 kernel in both
+        low-precision modes; fc and the tail are f32 in all modes."""
         if precision not in ("f32", "bf16x3", "bf16"):
             raise ValueError(f"unknown precision {precision!r}")
         lowp = precision != "f32"
@@ -427,7 +429,7 @@ class Engine:
             i, c = s + 1, STAGE_CHANNELS[s]
             sc, sh = folded[f"model.bn{i}"]
             if i == 1:
-                a, _ = self.conv1(a, sw.conv, B, h, w, sc, sh, AC)
+                a, _ = self.conv1(a, sw.conv, B, h, w, sc, sh, AC, lowp=lowp)
             elif lowp:
                 a = self.conv_bf16(a, sw.conv_bf16, x3, B, h, w, cin, c, 5, 2, sc, sh, None, AC)
             else:
@@ -477,7 +479,7 @@ class Engine:
         for s, sw in enumerate(pw.stages):
             i, c = s + 1, STAGE_CHANNELS[s]
             if i == 1:
-                z, st = self.conv1(a, sw.conv, B, h, w, want_stats=True)
+                z, st = self.conv1(a, sw.conv, B, h, w, want_stats=True, lowp=x3)
             else:
                 z, st = conv_s(a, sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2)
             h, w, cin = conv_out(h, 5, 2), conv_out(w, 5, 2), c

@@ -106,6 +106,10 @@ int ds_conv5x5s2_c1_stats_rows(int B, int H);
 int ds_conv5x5s2_c1_fwd_f32(const float *x, const float *w_packed, const float *scale,
                             const float *shift, float *y, float *stats_partial, int B, int H,
                             int W, int Cout, int flags, void *stream);
+/* the same layer on the bf16 matrix cores with split operands (bf16x3); same packed bank and statistics rows */
+int ds_conv5x5s2_c1_fwd_bf16(const float *x, const float *w_packed, const float *scale,
+                             const float *shift, float *y, float *stats_partial, int B, int H,
+                             int W, int Cout, int flags, void *stream);
 /* generic implicit-GEMM convolution on the f32 matrix cores: 3x3 s1 p1 (model.py:47-50,69,73),
  * 5x5 s2 p2 (model.py:98,102,106 / :192,197,202) and 1x1 (the fc GEMM, model.py:209), with the
  * BatchNorm / residual / clipped-ReLU epilogue selected by `flags`. */

@@ -133,6 +133,15 @@ def test_conv1(shape):
     tot = stats.astype(np.float64).sum(axis=0)
     np.testing.assert_allclose(tot[:, 0], z.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(tot[:, 1], (z * z).sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-4)
+    # the same layer on the bf16 matrix cores with split operands
+    y3 = aligned((b, ho, wo, 64), fill=np.nan)
+    stats3 = aligned((rows, 64, 2), fill=np.nan)
+    lib.call("ds_conv5x5s2_c1_fwd_bf16", ptr(xa), ptr(wp), ptr(sc), ptr(sh),
+             ptr(y3), ptr(stats3), b, h, w, 64, DS_EPI_AFFINE | DS_EPI_CLIP | DS_EPI_STATS, None)
+    assert np.abs(nchw(y3) - ref).max() < 3e-4 and rel_err(nchw(y3), ref) < 3e-5
+    tot3 = stats3.astype(np.float64).sum(axis=0)
+    np.testing.assert_allclose(tot3[:, 0], z.sum(axis=(0, 2, 3)), rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(tot3[:, 1], (z * z).sum(axis=(0, 2, 3)), rtol=1e-3, atol=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -69,25 +69,26 @@ def probe(path, B=768, reps=20):
     lib.call("ds_pack_conv1_weight_f32", p(w), p(wp), 64, st)
     y = torch.empty(B, 80, 32, 64, device=dev)
     sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
-    run1 = lambda: lib.call("ds_conv5x5s2_c1_fwd_f32", p(x), p(wp), p(sc), p(sh), p(y), None, B, 160, 64, 64, 1 | 4, st)
-    for _ in range(3):
-        run1()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        run1()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    out.append(("conv1 5x5 1>64", us, 2.0 * B * 80 * 32 * 64 * 25 / us * 1e-6, float(y.double().sum())))
+    for fn in ("ds_conv5x5s2_c1_fwd_f32", "ds_conv5x5s2_c1_fwd_bf16"):
+        run1 = lambda: lib.call(fn, p(x), p(wp), p(sc), p(sh), p(y), None, B, 160, 64, 64, 1 | 4, st)
+        for _ in range(3):
+            run1()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run1()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out.append(("conv1 " + fn[-4:].strip("_"), us, 2.0 * B * 80 * 32 * 64 * 25 / us * 1e-6, float(y.double().sum())))
     return out
 
 
 if __name__ == "__main__":
     paths = sys.argv[1:] or [os.path.join(_native._HERE, _native.LIB_NAME)]
     res = {q: probe(q) for q in paths}
-    for i, lay in enumerate(LAYERS + [("conv1 5x5 1>64",)]):
+    for i, lay in enumerate(LAYERS + [("conv1 VALU f32",), ("conv1 MFMA bf16x3",)]):
         cells = "  ".join(f"{res[q][i][1]:8.1f}us {res[q][i][2]:6.1f}TF" for q in paths)
         print(f"{lay[0]:16s} {cells}")
     print(" " * 16, "  ".join(f"{sum(r[1] for r in res[q][:len(LAYERS)]):8.1f}us" + " " * 9 for q in paths))
