@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int C1_RT = 8;          // output rows per workgroup
+constexpr int C1_RT = 16;         // output rows per workgroup
 constexpr int C1_COUT = 64;
 
 struct Conv1K {
@@ -143,8 +143,9 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
 
     // stage the zero-padded input tile
     const float *xb = p.x + (size_t)b * p.H * p.W;
+    const float rcp_ci = 1.0f / (float)p.cols_in;
     for (int i = tid; i < n_in; i += 256) {
-        const int rr = i / p.cols_in, cc = i - rr * p.cols_in;
+        const int rr = ds_div_small(i, p.cols_in, rcp_ci), cc = i - rr * p.cols_in;
         const int h = 2 * r0 - 2 + rr, w = cc - 2;
         lds[i] = (h >= 0 && h < p.H && w >= 0 && w < p.W) ? xb[(size_t)h * p.W + w] : 0.0f;
     }
