@@ -170,6 +170,49 @@ def test_full_size_properties(dev):
     assert rel_err(e1[:4].cpu().numpy(), ref) < EMB_TOL
 
 
+def test_bench_size_properties_bf16x3(dev):
+    """The bench.py step at its full size (768 utterances, default bf16x3 arithmetic): size-independent
+    properties -- bitwise determinism, unit norm x10, batch-composition invariance, a small slice against
+    the float64 oracle, the filter's indices == ascending where(mask) of the distances it reports, and the
+    semi-hard search's contract (other speaker; farther than the positive when such a candidate exists)."""
+    from deepspeaker_pytorch_amd.mining import mine_semihard_negatives, select_triplets
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, PairwiseDistance
+    sd = O.make_state_dict(seed=0, num_classes=16)
+    m = DeepSpeakerModel(512, 16, precision="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(768, 1, 160, 64, generator=g).cuda()
+    with torch.no_grad():
+        e1 = m(x).clone()
+        e2 = m(x).clone()
+        e_part = m(x[256:512].contiguous()).clone()
+    assert torch.isfinite(e1).all() and torch.equal(e1, e2)
+    assert float((e1.double().norm(dim=1) - 10).abs().max()) < 1e-4
+    assert torch.equal(e1[256:512], e_part)             # the contraction order of a pixel does not depend on tiling
+    ref = O.forward(sd, x[764:768].cpu().numpy(), dtype=np.float64)
+    assert rel_err(e1[764:768].cpu().numpy(), ref) < 3e-5
+    a, p, n = e1[:256], e1[256:512], e1[512:]
+    sel = select_triplets(a, p, n, margin=0.1)
+    d_p = PairwiseDistance(2).forward(a, p).cpu().numpy()
+    d_n = PairwiseDistance(2).forward(a, n).cpu().numpy()
+    np.testing.assert_array_equal(sel.indices.cpu().numpy(), np.where(d_n - d_p < 0.1)[0])
+    c1 = torch.randint(0, 64, (256,), generator=g).cuda()
+    c2 = (c1 + 1 + torch.randint(0, 63, (256,), generator=g).cuda()) % 64
+    labels = torch.cat([c1, c1, c2])
+    idx, dist = mine_semihard_negatives(a, p, c1, e1, labels)
+    idx_h, lab_h, c1_h = idx.cpu().numpy(), labels.cpu().numpy(), c1.cpu().numpy()
+    assert (idx_h >= 0).all() and (lab_h[idx_h] != c1_h).all()
+    d_all = torch.cdist(a.double(), e1.double()).cpu().numpy()
+    other = lab_h[None, :] != c1_h[:, None]
+    semi = other & (d_all > d_p[:, None].astype(np.float64) + 1e-4)
+    has_semi = semi.any(axis=1)
+    assert (dist.cpu().numpy()[has_semi] > d_p[has_semi]).all()
+    best = np.where(semi, d_all, np.inf).min(axis=1)
+    # closest among the semi-hard ones (candidates within 1e-4 of d_p are semi-hard for the kernel, not for `semi`)
+    assert (dist.cpu().numpy()[has_semi] <= best[has_semi] + 1e-3).all()
+
+
 CONV_CASES = [
     (2, 8, 64, 9, 32, 3, 1), (1, 16, 64, 8, 16, 3, 1), (3, 8, 128, 20, 8, 3, 1), (5, 8, 128, 10, 4, 3, 1),
     (2, 8, 64, 16, 32, 5, 2), (2, 8, 128, 13, 16, 5, 2), (3, 16, 128, 7, 8, 5, 2), (70, 24, 64, 1, 1, 1, 1),
