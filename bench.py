@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--split-apn", action="store_true",
                     help="three separate 256-utterance forwards (the reference's call pattern, "
                          "train_triplet.py:215) instead of one 768-utterance forward")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="steps in flight: consecutive (independent) steps alternate over this many HIP streams, so one "
+                         "step's HBM- / latency-bound kernels run beside another's matrix kernels (+6 %% at 2; the "
+                         "default 1 keeps every kernel alone on the GPU, which is what the roofline object times)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="take the N > 1 code path (RCCL all-gathers, barrier, max-over-ranks) with a single rank; "
                          "launch with torch.distributed.run --nproc-per-node 1 (self-test of the multi-GPU path)")
@@ -116,8 +120,12 @@ def main():
     c2 = (c1 + 1 + torch.randint(0, 63, (BATCH_TRIPLETS,), generator=g)) % 64
     c1, c2 = c1.to(dev), c2.to(dev)
     labels_loc = torch.cat([c1, c1, c2])
-    emb_glob = torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if multi else None
-    lab_glob = torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if multi else None
+    n_slots = max(1, args.streams)              # steps in flight, each with its own gather buffers
+    emb_globs = [torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if multi else None for _ in range(n_slots)]
+    lab_globs = [torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if multi else None
+                 for _ in range(n_slots)]
+
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -130,7 +138,8 @@ def main():
         model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
         model = model.to(dev).eval()
 
-        def step():
+        def step(slot=0):
+            emb_glob, lab_glob = emb_globs[slot], lab_globs[slot]
             with torch.no_grad():
                 if args.split_apn:
                     embs = [model(x) for x in data]
@@ -161,11 +170,24 @@ def main():
         eng.profile = []
         for _ in range(warmup):
             step()
+        for j, st_ in enumerate(streams):       # launch plans / allocator pools of the side streams
+            with torch.cuda.stream(st_):
+                step(j)
         fence()
         eng.profile = []
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        if args.streams > 1:
+            cur = torch.cuda.current_stream(dev)
+            for st_ in streams:
+                st_.wait_stream(cur)
+            for i in range(steps):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    step(i % len(streams))
+            for st_ in streams:
+                cur.wait_stream(st_)
+        else:
+            for _ in range(steps):
+                step()
         fence()
         elapsed = time.perf_counter() - t0
         prof, eng.profile = eng.profile, None
@@ -237,7 +259,7 @@ def main():
                                    "batch, 256 triplets = 768 x [1,160,64] utterances per GPU per step",
                        "batch_triplets": BATCH_TRIPLETS, "utterances_per_step_per_gpu": 3 * BATCH_TRIPLETS,
                        "frames": FRAMES, "parallelism": f"dp{world}",
-                       "forward_calls_per_step": 3 if args.split_apn else 1,
+                       "forward_calls_per_step": 3 if args.split_apn else 1, "steps_in_flight": max(1, args.streams),
                        "arith": arith},
             "roofline": roofline_of(args.precision, prof, args.steps),
             "whole_forward_tflops": round(value * FWD_FLOPS_PER_EMB / 1e12, 2),

@@ -379,7 +379,9 @@ class Engine:
             raise ValueError("input must be [B,1,T,F] (reference model.py:185, SURVEY F1)")
         if precision != "f32" and pw.stages[0].l_conv1_bf16 is None:
             raise ValueError("pack_weights(..., with_bf16=True) is required for the bf16 precisions")
-        key = (tuple(x.shape), precision, id(pw), id(folded), x.device)
+        # the plan owns its intermediate activations: forwards in flight on different streams need their own
+        stream_id = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
+        key = (tuple(x.shape), precision, id(pw), id(folded), x.device, stream_id)
         plans = self.__dict__.setdefault("_eval_plans", {})
         plan = plans.get(key)
         if plan is None:
