@@ -161,6 +161,9 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
         sh4 = *(const f32x4 *)(p.shift + my_c);
     }
     const ds_buffer ybuf = ds_make_buffer(p.y, y_bytes);
+    const int pix0 = (b * p.Ho + r0) * p.Wo;               // first output pixel of the tile
+    const int rows_left = p.Ho - r0;
+    const int pix_lim = (rows_left < C1_RT ? rows_left : C1_RT) * p.Wo;
     float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
     for (int sub = wave; sub < n_sub; sub += 4) {
         // ---- B fragments: 16 taps of this lane's pixel ----
@@ -205,16 +208,18 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
         ds_wave_sync();
 #pragma unroll
         for (int k = 0; k < NRI; ++k) {
+            // the tile's pixels are consecutive rows of one image: pixel pm of the tile is pixel pix0 + pm of y
             const int pm = sub * 32 + k * PPI + my_p;
-            const int pr = ds_div_small(pm, p.Wo, rcp_wo), pc = pm - pr * p.Wo;
-            const bool live = pm < n_pix && r0 + pr < p.Ho;
-            const unsigned voff = live ? (unsigned)((((b * p.Ho + r0 + pr) * p.Wo + pc) * C1_COUT) + my_c) * 4u : DS_BUFFER_OOB;
+            const bool live = pm < pix_lim;
+            const unsigned voff = live ? (unsigned)((pix0 + pm) * C1_COUT + my_c) * 4u : DS_BUFFER_OOB;
             f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = v[j];
-                ps1[j] += live ? t : 0.0f;
-                ps2[j] += live ? t * t : 0.0f;
+                if (p.flags & DS_EPI_STATS) {
+                    ps1[j] += live ? t : 0.0f;
+                    ps2[j] += live ? t * t : 0.0f;
+                }
                 t = t * sc4[j] + sh4[j];
                 if (p.flags & DS_EPI_CLIP) t = fminf(fmaxf(t, 0.0f), 20.0f);
                 v[j] = t;
