@@ -351,7 +351,8 @@ class DeepSpeakerModel(nn.Module):
     def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4, precision: str = "f32"):
         super().__init__()
         # arithmetic of the stage convolutions: "f32" (exact-f32 MFMA), "bf16x3" (split-operand bf16 MFMA,
-        # f32-class accuracy; in training: forward and 3x3 data gradients, the rest stays f32) or "bf16"
+        # f32-class accuracy; in training: forward, data and filter gradients of the 3x3 / 5x5 layers; the fc
+        # layer, conv1's filter gradient and the BatchNorm / loss passes stay f32) or "bf16"
         # (eval-only speed mode; training then runs in f32)
         self.precision = precision
         if feature_dim != 64:

@@ -268,7 +268,7 @@ def test_planned_eval_forward_equals_unplanned(precision):
 
 
 def test_training_step_bf16x3_matches_oracle():
-    """Train-mode forward + backward with the bf16x3 convolutions (forward and 3x3 data gradients)."""
+    """Train-mode forward + backward with the bf16x3 convolutions (forward, data and filter gradients)."""
     from deepspeaker_pytorch_amd.backward import backward_train
     eng = Engine(emul_lib())
     n_stages, B, T, seed = 2, 2, 23, 13

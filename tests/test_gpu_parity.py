@@ -457,7 +457,7 @@ def test_bf16_precisions_vs_reference(dev, golden, precision, tol):
 
 
 def test_training_step_bf16x3(dev, golden):
-    """bf16x3 training (forward + 3x3 data gradients on the bf16 matrix cores): loss and gradients stay within
+    """bf16x3 training (forward, data and filter gradients on the bf16 matrix cores): loss and gradients stay within
     the fp32 noise band of the reference (same bounds as the f32 training test)."""
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
     sd = O.make_state_dict(seed=31, num_classes=16)
