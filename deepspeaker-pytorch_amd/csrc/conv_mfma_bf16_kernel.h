@@ -6,10 +6,6 @@
 #include <ds_device.h>
 #include "ds_common.h"
 
-#ifndef DS_BF16_ILV
-#define DS_BF16_ILV 1
-#endif
-
 
 constexpr int CKB = 16;             // input channels per chunk = K of one bf16 MFMA
 constexpr int PSB = 48;             // bytes per staged pixel record: 16 bf16 + 16 B pad
@@ -63,7 +59,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     // 160x64 register tiles run one wave per SIMD: nothing else hides LDS latency there, so the next
     // tap's pixel fragments are fetched before (X3: in between) this tap's matrix work
     constexpr bool APREF = (MSUB * NSUB >= 8);
-    constexpr bool ILV = DS_BF16_ILV && X3 && APREF;
+    constexpr bool ILV = X3 && APREF;
 
     char *lds = (char *)ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
