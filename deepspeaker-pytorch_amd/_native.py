@@ -11,7 +11,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_v
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libdeepspeaker_hip.so"
 
-DS_EPI_AFFINE, DS_EPI_RESIDUAL, DS_EPI_CLIP, DS_EPI_STATS = 1, 2, 4, 8
+DS_EPI_AFFINE, DS_EPI_RESIDUAL, DS_EPI_CLIP, DS_EPI_STATS, DS_EPI_OUT_F32, DS_EPI_OUT_F16 = 1, 2, 4, 8, 16, 32
+DS_CONV_HINT_SINGLE_BUFFER = 64
 DS_CONV_CK = 8
 
 
@@ -54,6 +55,11 @@ _SIGNATURES = {
     "ds_conv_bf16_stats_rows": (c_int, [POINTER(ConvShape), c_int]),
     "ds_conv_bf16_plan_describe": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
     "ds_conv_fwd_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "ds_pack_conv_weight_f16": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_conv_fwd_f16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "ds_conv_f16_plan_describe": (c_int, [POINTER(ConvShape), POINTER(c_int)]),
+    "ds_cast_f32_to_f16": (c_int, [_P, _P, c_longlong, _P]),
+    "ds_cast_f16_to_f32": (c_int, [_P, _P, c_longlong, _P]),
     "ds_avgpool_time_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_l2norm_scale_f32": (c_int, [_P, _P, c_int, c_int, c_float, c_float, _P]),
     "ds_fc_workspace_floats": (c_longlong, [c_int, c_int, c_int]),

@@ -211,7 +211,8 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
             // the tile's pixels are consecutive rows of one image: pixel pm of the tile is pixel pix0 + pm of y
             const int pm = sub * 32 + k * PPI + my_p;
             const bool live = pm < pix_lim;
-            const unsigned voff = live ? (unsigned)((pix0 + pm) * C1_COUT + my_c) * 4u : DS_BUFFER_OOB;
+            const unsigned eoff = (unsigned)((pix0 + pm) * C1_COUT + my_c);
+            const unsigned voff = live ? eoff * 4u : DS_BUFFER_OOB;
             f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -224,7 +225,14 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
                 if (p.flags & DS_EPI_CLIP) t = fminf(fmaxf(t, 0.0f), 20.0f);
                 v[j] = t;
             }
-            ds_buffer_store_f32x4(ybuf, voff, v);
+            if (p.flags & DS_EPI_OUT_F16) {     // fp16 activations for the fp16 convolution path
+                f16x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
+                ds_buffer_store_b64(ybuf, live ? eoff * 2u : DS_BUFFER_OOB, __builtin_bit_cast(ds_u32x2, h));
+            } else {
+                ds_buffer_store_f32x4(ybuf, voff, v);
+            }
         }
         ds_wave_sync();
     }
@@ -288,8 +296,9 @@ extern "C" int ds_conv5x5s2_c1_fwd_f32(const float *x, const float *w_packed, co
 // the same contract on the bf16 matrix cores with split operands (f32-class accuracy); same packed filter
 // bank (ds_pack_conv1_weight_f32), same statistics rows
 extern "C" int ds_conv5x5s2_c1_fwd_bf16(const float *x, const float *w_packed, const float *scale,
-                                        const float *shift, float *y, float *stats_partial, int B,
+                                        const float *shift, void *y_out, float *stats_partial, int B,
                                         int H, int W, int Cout, int flags, void *stream) {
+    float *y = (float *)y_out;                 // fp16 storage with DS_EPI_OUT_F16
     DS_REQUIRE(x && w_packed && y, DS_ERR_NULL);
     DS_REQUIRE(!(flags & DS_EPI_AFFINE) || (scale && shift), DS_ERR_NULL);
     DS_REQUIRE(!(flags & DS_EPI_STATS) || stats_partial, DS_ERR_NULL);
@@ -310,6 +319,6 @@ extern "C" int ds_conv5x5s2_c1_fwd_bf16(const float *x, const float *w_packed, c
     const size_t n_in = (size_t)(2 * (C1_RT - 1) + 5) * k.cols_in;
     const size_t lds = (((n_in + 3) & ~(size_t)3) + 4 * 32 * (C1_COUT + 4) + 4 * C1_COUT * 2) * 4;
     DS_LAUNCH(conv5x5s2_c1_bf16_kernel, B * k.tiles_per_img, 256, lds, stream, k,
-              (unsigned)((long long)B * k.Ho * k.Wo * C1_COUT * 4));
+              (unsigned)((long long)B * k.Ho * k.Wo * C1_COUT * ((flags & DS_EPI_OUT_F16) ? 2 : 4)));
     return ds_last_launch_error();
 }

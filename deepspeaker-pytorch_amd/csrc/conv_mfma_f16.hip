@@ -1,0 +1,227 @@
+// conv_mfma_f16.hip -- planner and C ABI of the fp16 implicit-GEMM convolution (kernel: conv_mfma_f16_kernel.h):
+// the eval-forward throughput path for reference model.py:69,73,192,197,202 with the fused
+// BatchNorm-affine / residual / clipped-ReLU epilogue (model.py:70-80,188-205).  Activations are fp16
+// channels-last in HBM, products run on v_mfma_f32_32x32x16_f16 with f32 accumulation.
+#include <ds_device.h>
+#include <algorithm>
+#include "ds_common.h"
+
+#include "conv_mfma_f16_kernel.h"
+
+namespace {
+
+// OIHW f32 -> [Cin/16][tap][Cout][16] fp16 (round to nearest even)
+__global__ void __launch_bounds__(256) pack_conv_weight_f16_kernel(const float *w, _Float16 *out, int Cout, int Cin,
+                                                                   int KS) {
+    const int T = KS * KS;
+    const long long n = (long long)Cout * Cin * T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int kk = (int)(i & 15);
+        long long r = i >> 4;
+        const int co = (int)(r % Cout);
+        r /= Cout;
+        const int t = (int)(r % T);
+        const int kc = (int)(r / T);
+        const int ci = kc * 16 + kk;
+        const int kh = t / KS, kw = t - kh * KS;
+        out[i] = (_Float16)w[(((size_t)co * Cin + ci) * KS + kh) * KS + kw];
+    }
+}
+
+__global__ void __launch_bounds__(256) cast_f32_to_f16_kernel(const float *x, _Float16 *y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = (_Float16)x[i];
+}
+
+__global__ void __launch_bounds__(256) cast_f16_to_f32_kernel(const _Float16 *x, float *y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = (float)x[i];
+}
+
+// LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for a candidate row pitch: the two 16-lane
+// service groups of lanes 0..31 each hold 16 consecutive pixels of the M tile (`lpix` in the kernel).
+// Bank slot of a record = (record * PSH / 16) mod 16.
+static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in, int pitch) {
+    const int pix_per_seg = RT * Wc, seg_pix = rows_in * pitch;
+    double total = 0.0;
+    int n = 0;
+    for (int m0 = 0; m0 + 32 <= MT; m0 += 32) {
+        for (int g = 0; g < 2; ++g) {
+            int cnt[16] = {0};
+            int worst = 0;
+            for (int j = 0; j < 16; ++j) {
+                const int m = m0 + 16 * g + j;
+                const int seg = m / pix_per_seg, rem = m % pix_per_seg;
+                const int r = rem / Wc, c = rem % Wc;
+                const int rec = (seg < NI) ? seg * seg_pix + (IS * r) * pitch + c : 0;
+                const int slot = (rec * (PSH / 16)) & 15;
+                if (++cnt[slot] > worst) worst = cnt[slot];
+            }
+            total += worst;
+            ++n;
+        }
+    }
+    return n ? total / n : 1.0;
+}
+
+struct TileCfgH { int MT, NTILE, WM, NTHR; };
+constexpr int kNumCfgH = 7;
+constexpr TileCfgH kCfgH[kNumCfgH] = {
+    {160, 128, 1, 128},     // <KS,5,2,1,2>: two waves, 160x64 register tile each
+    {160, 256, 1, 256},     // <KS,5,2,1,4>
+    {320, 128, 2, 256},     // <KS,5,2,2,2>
+    {320, 64, 2, 128},      // <KS,5,2,2,1>: the 2-wave shape for 64-channel layers
+    {128, 128, 1, 128},     // <KS,4,2,1,2>: 128x64 register tiles where 160-row tiles quantise badly
+    {128, 256, 1, 256},     // <KS,4,2,1,4>
+    {640, 64, 4, 256},      // <KS,5,2,4,1>: four waves on a 64-channel layer
+};
+constexpr size_t kLdsTotal = 160 * 1024;     // per CU
+
+static size_t epi_bytes(const TileCfgH &cf) {
+    const int waves = cf.NTHR / 64, nsub = cf.NTILE / (waves / cf.WM) / 32;
+    return (size_t)waves * 32 * (nsub * 32 + 4) * 4;
+}
+
+// One wave per SIMD is the design point (the register tile takes most of the 512 VGPRs): a CU holds
+// 256 / NTHR workgroups, each with an equal share of the LDS.
+static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true) {
+    DS_REQUIRE(s != nullptr, DS_ERR_NULL);
+    DS_REQUIRE(s->B > 0 && s->H > 0 && s->W > 0 && s->Cin > 0 && s->Cout > 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(s->KS == 3 || s->KS == 5, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(s->stride == 1 || s->stride == 2, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(s->Cin % CKH == 0 && s->Cout % 64 == 0, DS_ERR_BAD_SHAPE);
+    const int pad = s->KS / 2;
+    const int Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
+    const int Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
+    DS_REQUIRE(Ho > 0 && Wo > 0 && Wo <= 128, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * Ho < (1ll << 24), DS_ERR_BAD_SHAPE);                  // reciprocal index arithmetic
+    DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);   // 32-bit byte offsets
+    const int IS = s->stride;
+    double best = -1.0;
+    int bc = -1, brt = 0, bni = 0, bdb = 0;
+    for (int c = 0; c < kNumCfgH; ++c) {
+        const TileCfgH &cf = kCfgH[c];
+        if (s->Cout % cf.NTILE) continue;
+        const int wg_per_cu = 256 / cf.NTHR;
+        const size_t lds_cap = kLdsTotal / wg_per_cu - 64;
+        for (int db = allow_db ? 1 : 0; db >= 0; --db) {
+            const long long item_cap = (db ? 16 : 32) * cf.NTHR;
+            for (int rt = 1; rt <= Ho; ++rt) {
+                if ((long long)rt * Wo > cf.MT) break;
+                const int segs_per_img = ds_ceil_div(Ho, rt);
+                const long long n_segs = (long long)s->B * segs_per_img;
+                int ni = cf.MT / (rt * Wo);
+                if (ni > n_segs) ni = (int)n_segs;
+                const int rows_in = IS * (rt - 1) + s->KS, cols_in = IS * (Wo - 1) + s->KS;
+                auto lds_of = [&](int n) {
+                    const size_t tp = (size_t)n * rows_in * (cols_in + 4);
+                    return std::max(tp * PSH * (db ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)n * 8;
+                };
+                auto items_of = [&](int n) { return (long long)n * std::min(rows_in, s->H) * s->W * (CKH / 8); };
+                while (ni > 1 && (lds_of(ni) > lds_cap || items_of(ni) > item_cap)) --ni;
+                if (lds_of(ni) > lds_cap || items_of(ni) > item_cap) continue;
+                const long long n_mt = ds_ceil_div_ll(n_segs, ni);
+                double eff = (double)s->B * Ho * Wo / ((double)n_mt * cf.MT);
+                const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * wg_per_cu;
+                if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
+                else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
+                if (!db) eff *= (s->KS == 3 ? 0.90 : 0.96);      // two barriers and exposed LDS writes per chunk
+                static const int pref[kNumCfgH] = {6, 4, 3, 5, 2, 1, 0};
+                eff += 1e-9 * rt + 1e-6 * pref[c];
+                if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; bdb = db; }
+            }
+        }
+    }
+    if (bc < 0) return DS_ERR_UNSUPPORTED;
+    const TileCfgH &cf = kCfgH[bc];
+    ConvKH &k = pl.k;
+    k.H = s->H; k.W = s->W; k.Cin = s->Cin;
+    k.Ho = Ho; k.Wo = Wo; k.Cout = s->Cout;
+    k.IS = IS; k.dh_min = -pad; k.dw_min = -pad;
+    k.RT = brt; k.NI = bni;
+    k.segs_per_img = ds_ceil_div(Ho, brt);
+    k.n_segs = s->B * k.segs_per_img;
+    k.rows_in = IS * (brt - 1) + s->KS;
+    k.cols_in = IS * (Wo - 1) + s->KS;
+    k.half = (k.cols_in + 1) / 2;
+    int best_pitch = k.cols_in;
+    double best_cost = 1e30;
+    for (int pt = k.cols_in; pt <= k.cols_in + 4; ++pt) {
+        const double c = frag_read_cost(cf.MT, bni, brt, Wo, IS, k.rows_in, pt);
+        if (c < best_cost - 1e-9) { best_cost = c; best_pitch = pt; }
+    }
+    k.pitch = best_pitch;
+    k.seg_pix = k.rows_in * k.pitch;
+    k.n_ntiles = s->Cout / cf.NTILE;
+    pl.cfg = bc;
+    pl.db = bdb;
+    pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
+    pl.grid = pl.n_mtiles * k.n_ntiles;
+    const size_t tp = (size_t)k.NI * k.seg_pix;
+    pl.lds_bytes = std::max(tp * PSH * (bdb ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)k.NI * 8 + 16;
+    pl.nit = ds_ceil_div(k.NI * std::min(k.rows_in, s->H) * s->W * (CKH / 8), cf.NTHR);
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_pack_conv_weight_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, void *stream) {
+    DS_REQUIRE(w_oihw && w_f16, DS_ERR_NULL);
+    DS_REQUIRE(Cout > 0 && Cin > 0 && (KS == 3 || KS == 5) && (Cin % 16) == 0, DS_ERR_BAD_SHAPE);
+    const long long n = (long long)Cout * Cin * KS * KS;
+    long long g = (n + 255) / 256;
+    DS_LAUNCH(pack_conv_weight_f16_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w_oihw, (_Float16 *)w_f16, Cout,
+              Cin, KS);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_cast_f32_to_f16(const float *x, void *y_f16, long long n, void *stream) {
+    DS_REQUIRE(x && y_f16, DS_ERR_NULL);
+    DS_REQUIRE(n > 0, DS_ERR_BAD_SHAPE);
+    long long g = (n + 255) / 256;
+    DS_LAUNCH(cast_f32_to_f16_kernel, (int)(g > 8192 ? 8192 : g), 256, 0, stream, x, (_Float16 *)y_f16, n);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_cast_f16_to_f32(const void *x_f16, float *y, long long n, void *stream) {
+    DS_REQUIRE(x_f16 && y, DS_ERR_NULL);
+    DS_REQUIRE(n > 0, DS_ERR_BAD_SHAPE);
+    long long g = (n + 255) / 256;
+    DS_LAUNCH(cast_f16_to_f32_kernel, (int)(g > 8192 ? 8192 : g), 256, 0, stream, (const _Float16 *)x_f16, y, n);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8) {
+    DS_REQUIRE(out8 != nullptr, DS_ERR_NULL);
+    PlanH pl;
+    int rc = plan_f16(pl, s);
+    if (rc != DS_OK) return rc;
+    const TileCfgH &cf = kCfgH[pl.cfg];
+    out8[0] = cf.MT; out8[1] = cf.NTILE; out8[2] = pl.k.RT; out8[3] = pl.k.NI;
+    out8[4] = pl.grid; out8[5] = (int)pl.lds_bytes; out8[6] = cf.NTHR; out8[7] = pl.db * 1000 + pl.nit;
+    return DS_OK;
+}
+
+extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
+                               const float *shift, const void *residual_f16, void *y, int flags, void *stream) {
+    DS_REQUIRE(x_f16 && w_f16 && y, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_AFFINE) || (scale && shift), DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_RESIDUAL) || residual_f16, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_STATS), DS_ERR_UNSUPPORTED);            // eval path only
+    DS_REQUIRE(DS_ALIGNED16(x_f16) && DS_ALIGNED16(w_f16) && DS_ALIGNED16(y) && DS_ALIGNED16(residual_f16) &&
+                   DS_ALIGNED16(scale) && DS_ALIGNED16(shift), DS_ERR_ALIGNMENT);
+    PlanH pl;
+    int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER));
+    if (rc != DS_OK) return rc;
+    ConvKH &k = pl.k;
+    k.x = (const _Float16 *)x_f16; k.w = (const _Float16 *)w_f16; k.y = y;
+    k.scale = scale; k.shift = shift; k.res = (const _Float16 *)residual_f16;
+    k.flags = flags;
+    const long long n_out = (long long)s->B * k.Ho * k.Wo * s->Cout;
+    k.y_bytes = (unsigned)(n_out * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
+    k.res_bytes = (unsigned)(n_out * 2);
+    if (s->KS == 3) { if (pl.db) ds_f16_launch_k3db(pl, stream); else ds_f16_launch_k3sb(pl, stream); }
+    else            { if (pl.db) ds_f16_launch_k5db(pl, stream); else ds_f16_launch_k5sb(pl, stream); }
+    return ds_last_launch_error();
+}

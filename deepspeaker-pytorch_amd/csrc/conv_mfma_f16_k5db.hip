@@ -1,0 +1,6 @@
+// conv_mfma_f16_k5db.hip -- the 5x5 instantiations of the fp16 convolution kernel (double-buffered pixel tile),
+// a translation unit of their own so that the kernel family compiles in parallel (see conv_mfma_f16_kernel.h)
+#define DS_F16_KERNEL_TU
+#include "conv_mfma_f16_kernel.h"
+
+void ds_f16_launch_k5db(const PlanH &pl, void *stream) { launch_h<5, true>(pl, stream); }

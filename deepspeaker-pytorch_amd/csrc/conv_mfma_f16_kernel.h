@@ -1,0 +1,416 @@
+// conv_mfma_f16_kernel.h -- implicit-GEMM convolution on the gfx950 fp16 matrix cores
+// (v_mfma_f32_32x32x16_f16, f32 accumulate) with fp16 activations in HBM: the throughput kernel of the eval
+// forward (reference model.py:69,73,192,197,202 + the fused BatchNorm-affine / residual / clipped-ReLU
+// epilogue, model.py:70-80,188-205).  One MFMA per product; measured 3.7e-4 from the reference on the
+// embedding (contract: 1e-3).  Included by conv_mfma_f16_k*.hip (one translation unit per kernel size x
+// buffering mode so the instantiations compile in parallel); planner and C ABI: conv_mfma_f16.hip.
+//
+// Differences from the split-operand bf16 kernel (conv_mfma_bf16_kernel.h), all following from having a third
+// of the matrix work per byte moved:
+//   * activations are fp16 channels-last in HBM: staging is a 16-byte copy (no conversion), HBM traffic halves;
+//   * 32 input channels per chunk (two MFMA k-steps per tap) -> half as many chunk boundaries;
+//   * the pixel tile is double-buffered in LDS where it fits (DB): the next chunk's pixels are written into
+//     the other buffer between the MFMAs of this chunk's last taps, leaving ONE barrier per chunk;
+//   * fragment reads, filter-ring refills and the staging traffic are dealt out one per MFMA.
+#pragma once
+#include <ds_device.h>
+#include <type_traits>
+#include "ds_common.h"
+
+constexpr int CKH = 32;             // input channels per chunk = two k-steps of the 32x32x16 MFMA
+constexpr int PSH = 80;             // bytes per staged pixel record: 32 halfs + 16 B pad (16 consecutive
+                                    // records walk all 64 banks with one ds_read_b128 each)
+
+struct ConvKH {
+    const _Float16 *x;              // [B, H, W, Cin] fp16 channels-last
+    const _Float16 *w;              // packed [Cin/16][tap][Cout][16]
+    void *y;                        // [B, Ho, Wo, Cout] fp16 (f32 with DS_EPI_OUT_F32)
+    const float *scale, *shift;
+    const _Float16 *res;            // residual, fp16, laid out like y
+    int H, W, Cin;
+    int Ho, Wo, Cout;
+    int IS;
+    int dh_min, dw_min;
+    int rows_in, cols_in, seg_pix;
+    int pitch, half;                // LDS records per tile row; first odd-column slot (stride-2 de-interleave)
+    int RT, NI, segs_per_img, n_segs;
+    int n_ntiles;
+    int flags;
+    unsigned y_bytes, res_bytes;    // sizes for the buffer descriptors
+};
+
+struct PlanH {
+    int cfg, grid, n_mtiles, nit, db;
+    size_t lds_bytes;
+    ConvKH k;
+};
+
+// one entry point per translation unit (kernel size x buffering)
+void ds_f16_launch_k3db(const PlanH &pl, void *stream);
+void ds_f16_launch_k3sb(const PlanH &pl, void *stream);
+void ds_f16_launch_k5db(const PlanH &pl, void *stream);
+void ds_f16_launch_k5sb(const PlanH &pl, void *stream);
+
+#ifdef DS_F16_KERNEL_TU
+namespace {
+
+// NIT: 16-byte staging items per thread and chunk (compile time: all loads of a chunk are in flight together).
+// DB:  two pixel-tile buffers in LDS; requires the register prefetch (NIT <= 16).
+template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT, bool DB>
+__global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f16_kernel(const ConvKH p) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MT = MSUB * WM * 32;
+    constexpr int NTILE = NSUB * WN * 32;
+    constexpr int NT = KS * KS;
+    constexpr int NU = 2 * NT;                      // (tap, k-step) units per chunk
+    constexpr int RU = (KS == 3) ? 9 : 10;          // filter ring, in units; NU % RU == 0
+    constexpr int NMF = MSUB * NSUB;                // MFMAs per unit
+    constexpr bool PREF = DB || NIT <= 16;          // next chunk's pixels ride in registers through the taps
+    static_assert(NU % RU == 0, "ring slots must be chunk-invariant");
+    static_assert(!DB || NIT <= 16, "double buffering needs the register prefetch");
+
+    char *lds = (char *)ds_dynamic_lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile_n = blockIdx.x % p.n_ntiles;
+    const int tile_m = blockIdx.x / p.n_ntiles;
+    const int seg0 = tile_m * p.NI;
+    const int pix_per_seg = p.RT * p.Wo;
+    const int tile_pix = p.NI * p.seg_pix;
+    // the pixel-tile region doubles as the epilogue's transposition buffers (32 x (NSUB*32+4) floats per wave)
+    constexpr int EPI_BYTES = WM * WN * 32 * (NSUB * 32 + 4) * 4;
+    const int tile_bytes = tile_pix * PSH;
+    const int tiles_bytes = (DB ? 2 : 1) * tile_bytes;
+    const int stage_bytes = tiles_bytes > EPI_BYTES ? tiles_bytes : EPI_BYTES;
+    int *out_off = (int *)(lds + stage_bytes);                 // [MT]
+    int *seg_lo = out_off + MT;                                // [NI] first in-image row of each segment's tile
+    int *seg_cnt = seg_lo + p.NI;                              // [NI] number of in-image rows
+
+    // the first filter fragments are requested before anything else: their latency hides behind the tables
+    const int n_chunks = p.Cin / CKH;
+    const int n_base = tile_n * NTILE + wn * NSUB * 32;
+    const size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);      // in halfs
+    const size_t w_kc_stride = (size_t)NT * p.Cout * 16;                // one 16-channel slab: [tap][Cout][16]
+    const size_t w_tap_stride = (size_t)p.Cout * 16;
+    // unit u of a chunk = (tap u >> 1, k-step u & 1): filter slab 2*chunk + (u & 1), tap u >> 1
+    auto w_unit = [&](int chunk, int u) {
+        return p.w + lane_w + (size_t)(2 * chunk + (u & 1)) * w_kc_stride + (size_t)(u >> 1) * w_tap_stride;
+    };
+
+    f16x8 bq[RU][NSUB];
+#pragma unroll
+    for (int d = 0; d < RU; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(0, d) + (size_t)ns * 32 * 16);
+
+    const float rcp_pps = 1.0f / (float)pix_per_seg, rcp_wc = 1.0f / (float)p.Wo, rcp_w = 1.0f / (float)p.W,
+                rcp_spi = 1.0f / (float)p.segs_per_img;
+    for (int seg = tid; seg < p.NI; seg += NTHR) {
+        const int gseg = seg0 + seg;
+        int lo = 0, cnt = 0;
+        if (gseg < p.n_segs) {
+            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+            const int h0 = p.IS * (gseg - b * p.segs_per_img) * p.RT + p.dh_min;      // image row of tile row 0
+            lo = h0 < 0 ? -h0 : 0;
+            const int hi = p.H - h0 < p.rows_in ? p.H - h0 : p.rows_in;
+            cnt = hi > lo ? hi - lo : 0;
+        }
+        seg_lo[seg] = lo;
+        seg_cnt[seg] = cnt;
+    }
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+
+    // ---- staging descriptors (chunk-invariant) of this thread's items: 8 channels (16 B) of one in-image
+    // pixel each.  Item idx -> (quarter q, column c, valid row) in segment order; slots past the last item
+    // load x[0..7] and drop it into the unused pad bytes of pixel record 0: the chunk loop has no branches.
+    int g_off[NIT], l_off[NIT];
+    __syncthreads();                            // seg_lo / seg_cnt are complete
+    {
+        const int q = tid & 3;
+        const int dvr = ds_div_small(NTHR / 4, p.W, rcp_w), dc = NTHR / 4 - dvr * p.W;
+        int vr = ds_div_small(tid >> 2, p.W, rcp_w);
+        int c = (tid >> 2) - vr * p.W;
+        int seg = -1, row0 = 0, cnt = 0, lo = 0, img_row = 0;
+        auto next_seg = [&]() {
+            row0 += cnt;
+            ++seg;
+            cnt = 0;
+            if (seg < p.NI) {
+                cnt = seg_cnt[seg];
+                lo = seg_lo[seg];
+                const int gseg = seg0 + seg;
+                const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+                img_row = b * p.H + p.IS * (gseg - b * p.segs_per_img) * p.RT + p.dh_min;   // of tile row 0
+            }
+        };
+        next_seg();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            while (seg < p.NI && vr >= row0 + cnt) next_seg();
+            g_off[it] = 0;
+            l_off[it] = 64;
+            if (seg < p.NI) {
+                const int rr = lo + vr - row0;
+                // stride-2 layers keep even tile columns in slots [0, half) and odd ones in [half, cols_in),
+                // so that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
+                const int cc = c - p.dw_min;
+                const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
+                g_off[it] = ((img_row + rr) * p.W + c) * p.Cin + q * 8;
+                l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16;
+            }
+            c += dc;
+            vr += dvr;
+            if (c >= p.W) {
+                c -= p.W;
+                ++vr;
+            }
+        }
+    }
+    f32x4 st[NIT];                              // 8 halfs each, moved as 16 opaque bytes
+    if constexpr (PREF) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
+    }
+    // ---- everything below overlaps the first chunk's loads ----
+    // Only in-image pixels are ever staged: the zero halo (and the row padding) is written once, here.
+    for (int i = tid; i < tiles_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int m = tid; m < MT; m += NTHR) {
+        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
+        const int rem = m - seg * pix_per_seg;
+        const int r = ds_div_small(rem, p.Wo, rcp_wc), c = rem - r * p.Wo;
+        const int gseg = seg0 + seg;
+        int off = -1;
+        if (seg < p.NI && gseg < p.n_segs) {
+            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
+            if (rr < p.Ho) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+        }
+        out_off[m] = off;
+    }
+    // Which pixel of its 32-pixel sub-tile a lane owns is free (the epilogue un-permutes): it is chosen so
+    // that the two 16-lane SERVICE GROUPS of a ds_read_b128 -- lanes {0-3,12-15,20-27} and {4-11,16-19,
+    // 28-31} -- each read 16 CONSECUTIVE pixels, i.e. consecutive 80-byte records that walk all 64 banks.
+    const int lpix = (l31 < 4 || l31 >= 28) ? l31
+                   : (l31 < 12) ? l31 + 12 : (l31 < 16) ? l31 - 8 : (l31 < 20) ? l31 + 8 : l31 - 12;
+    int a_off[MSUB];                                           // byte offset of this lane's fragment
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int m = (wm * MSUB + ms) * 32 + lpix;
+        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
+        const int rem = m - seg * pix_per_seg;
+        const int r = ds_div_small(rem, p.Wo, rcp_wc), c = rem - r * p.Wo;
+        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
+        a_off[ms] = pix * PSH + 16 * lhi;
+    }
+    auto tap_off = [&](int tt) {
+        const int kw = tt % KS;
+        return ((tt / KS) * p.pitch + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw)) * PSH;
+    };
+
+    // ---- one chunk of 32 input channels: NU units of NMF MFMAs, one side operation after each MFMA ----
+    //   odd slots:  the NEXT unit's pixel fragments (LDS -> registers, double-buffered per unit)
+    //   even slots: the filter-ring refills (L2 -> registers, RU-1 units ahead), then the staging traffic:
+    //               loads of the next chunk's pixels in the first units, their LDS writes in the last ones (DB)
+    constexpr int SPU = (NMF + 1) / 2 - NSUB;              // staging slots per unit
+    static_assert(SPU >= 1 && NSUB >= 2, "tile too small for the interleaved schedule (one odd slot per fragment read)");
+    constexpr int UL = (NIT + SPU - 1) / SPU;              // units that issue loads / that issue LDS writes
+    static_assert(!PREF || 2 * UL <= NU, "not enough units for the staging traffic");
+    auto run_chunk = [&](auto last_tag, int chunk, const char *buf, char *obuf) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        f16x8 a[2][MSUB];
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms) {
+            DS_OPAQUE_VGPR(a_off[ms]);          // keep the NU x MSUB fragment addresses out of registers
+            a[0][ms] = *(const f16x8 *)(buf + a_off[ms] + tap_off(0));
+        }
+        const _Float16 *xn = p.x + (chunk + 1) * CKH;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int cur = u & 1, slot = u % RU;
+            const bool more = u + 1 < NU;
+            const char *nfrag = buf + tap_off((u + 1) >> 1) + 32 * ((u + 1) & 1);
+            // the slot the previous unit consumed is refilled with the unit RU - 1 ahead of this one
+            const int ur = u - 1 + RU;                          // may run into the next chunk
+            const bool refill = !(LAST && ur >= NU);            // (unit 0 of chunk 0 reloads what the prologue loaded)
+            const _Float16 *rw = w_unit(ur >= NU ? chunk + 1 : chunk, ur >= NU ? ur - NU : ur);
+            const int rslot = (u + RU - 1) % RU;
+#pragma unroll
+            for (int q = 0; q < NMF; ++q) {
+                const int ms = q / NSUB, ns = q % NSUB;
+                acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
+                if (q & 1) {
+                    const int lm = q >> 1;
+                    if (lm < MSUB && more) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + a_off[lm]);
+                } else {
+                    const int e = q >> 1;
+                    if (e < NSUB) {
+                        if (refill) bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+                    } else if constexpr (PREF && !LAST) {
+                        const int s = e - NSUB;
+                        if (u < UL) {                           // next chunk's pixels -> registers
+                            const int it = u * SPU + s;
+                            if (it < NIT) st[it] = *(const f32x4 *)(xn + g_off[it]);
+                        } else if (DB && u >= NU - UL) {        // ... -> the other LDS buffer
+                            const int it = (u - (NU - UL)) * SPU + s;
+                            if (it < NIT) *(f32x4 *)(obuf + l_off[it]) = st[it];
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if constexpr (DB) {
+        __syncthreads();                        // the zero fill is complete
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
+        __syncthreads();
+        for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) {
+            char *b0 = lds + (chunk & 1) * tile_bytes, *b1 = lds + ((chunk & 1) ^ 1) * tile_bytes;
+            run_chunk(std::false_type{}, chunk, b0, b1);
+            __syncthreads();
+        }
+        run_chunk(std::true_type{}, n_chunks - 1, lds + ((n_chunks - 1) & 1) * tile_bytes, lds);
+    } else {
+        auto stage_chunk = [&](int chunk) __attribute__((always_inline)) {
+            __syncthreads();                    // previous chunk's fragment reads (chunk 0: the zero fill) are done
+            if constexpr (!PREF) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + chunk * CKH);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
+            __syncthreads();
+        };
+        for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) {
+            stage_chunk(chunk);
+            run_chunk(std::false_type{}, chunk, lds, lds);
+        }
+        stage_chunk(n_chunks - 1);
+        run_chunk(std::true_type{}, n_chunks - 1, lds, lds);
+    }
+
+    // ---- epilogue ----
+    // The filters were the A operand of every MFMA, so the accumulators hold the TRANSPOSED product: a lane
+    // owns one output pixel (lpix of the 32-pixel sub-tile) and, per register quad g, four consecutive output
+    // channels 8g + 4*lhi .. +3.  Each 32-pixel sub-tile is turned around through a wave-private LDS buffer
+    // (the pixel tile's space, free now) so that residual loads and stores move whole pixel rows: the
+    // NSUB*32 channels of a pixel are contiguous across NSUB*4 lanes, 8 channels = 16 bytes of fp16 per lane.
+    constexpr int TP = NSUB * 32 + 4;           // buffer row pitch in floats (conflict-free 16-byte writes)
+    constexpr int LPP = NSUB * 4;               // lanes per pixel row
+    constexpr int PPI = 64 / LPP;               // pixel rows per instruction
+    constexpr int NRI = 32 / PPI;               // instructions per sub-tile
+    const int flags = p.flags;
+    __syncthreads();                            // every wave is done reading the pixel tile
+    float *tb = (float *)lds + wave * (32 * TP);
+    const int my_c = (lane % LPP) * 8, my_p = lane / LPP;
+    const int col = n_base + my_c;
+    f32x4 sc[2] = {{1.0f, 1.0f, 1.0f, 1.0f}, {1.0f, 1.0f, 1.0f, 1.0f}};
+    f32x4 sh[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    if (flags & DS_EPI_AFFINE) {
+        sc[0] = *(const f32x4 *)(p.scale + col);
+        sc[1] = *(const f32x4 *)(p.scale + col + 4);
+        sh[0] = *(const f32x4 *)(p.shift + col);
+        sh[1] = *(const f32x4 *)(p.shift + col + 4);
+    }
+    // Rows of a ragged tile get an out-of-range buffer offset (the store is dropped, the load returns
+    // zeros) and a layer without residual reads "out of range" too: no branch around any memory instruction.
+    const bool out32 = (flags & DS_EPI_OUT_F32) != 0;
+    const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
+    const ds_buffer rbuf = ds_make_buffer((flags & DS_EPI_RESIDUAL) ? (const void *)p.res : (const void *)p.y,
+                                          (flags & DS_EPI_RESIDUAL) ? p.res_bytes : 0u);
+    unsigned voff[2][NRI];                      // element offset of (pixel row, first channel) or OOB
+    f32x4 resv[2][NRI];
+    auto fetch_rows = [&](int ms, int bsel) {   // offsets and residual rows of sub-tile ms
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            const int off = out_off[(wm * MSUB + ms) * 32 + k * PPI + my_p];
+            voff[bsel][k] = off >= 0 ? (unsigned)(off + col) : DS_BUFFER_OOB;
+        }
+#pragma unroll
+        for (int k = 0; k < NRI; ++k)
+            resv[bsel][k] = ds_buffer_load_f32x4(rbuf, voff[bsel][k] != DS_BUFFER_OOB ? voff[bsel][k] * 2u : DS_BUFFER_OOB);
+    };
+    fetch_rows(0, 0);
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int cb = ms & 1;
+        if (ms + 1 < MSUB) fetch_rows(ms + 1, cb ^ 1);
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
+                *(f32x4 *)(tb + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
+            }
+        ds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            const f16x8 r8 = __builtin_bit_cast(f16x8, resv[cb][k]);
+            f32x4 o[2];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c + 4 * hq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = v[j] * sc[hq][j] + sh[hq][j];
+                    t += (float)r8[4 * hq + j];
+                    if (flags & DS_EPI_CLIP) t = fminf(fmaxf(t, 0.0f), 20.0f);
+                    o[hq][j] = t;
+                }
+            }
+            const unsigned vo = voff[cb][k];
+            if (out32) {
+                const unsigned b = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
+                ds_buffer_store_f32x4(ybuf, b, o[0]);
+                ds_buffer_store_f32x4(ybuf, b != DS_BUFFER_OOB ? b + 16u : DS_BUFFER_OOB, o[1]);
+            } else {
+                f16x8 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = (_Float16)o[0][j];
+                    h[4 + j] = (_Float16)o[1][j];
+                }
+                ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+            }
+        }
+        ds_wave_sync();                         // the buffer is rewritten by the next sub-tile
+    }
+}
+
+template <int KS, int MSUB, int NSUB, int WM, int WN, bool DB>
+static void launch_nit_h(const PlanH &pl, void *stream) {
+    constexpr int NTHR = WM * WN * 64;
+    if (pl.nit <= 8)
+        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 8, DB>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+    else if (pl.nit <= 16)
+        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 16, DB>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+    else if constexpr (!DB)
+        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 32, false>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+}
+
+template <int KS, bool DB>
+static void launch_h(const PlanH &pl, void *stream) {
+    if (pl.cfg == 0) launch_nit_h<KS, 5, 2, 1, 2, DB>(pl, stream);          // 160x128, two waves
+    else if (pl.cfg == 1) launch_nit_h<KS, 5, 2, 1, 4, DB>(pl, stream);     // 160x256, four waves
+    else if (pl.cfg == 2) launch_nit_h<KS, 5, 2, 2, 2, DB>(pl, stream);     // 320x128
+    else if (pl.cfg == 3) launch_nit_h<KS, 5, 2, 2, 1, DB>(pl, stream);     // 320x64, two waves
+    else if (pl.cfg == 4) launch_nit_h<KS, 4, 2, 1, 2, DB>(pl, stream);     // 128x128, two waves
+    else if (pl.cfg == 5) launch_nit_h<KS, 4, 2, 1, 4, DB>(pl, stream);     // 128x256
+    else launch_nit_h<KS, 5, 2, 4, 1, DB>(pl, stream);                      // 640x64, four waves
+}
+
+}  // namespace
+#endif

@@ -24,6 +24,13 @@ __device__ __forceinline__ f32x16 ds_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_32x32x16_f16: the same shape and fragment layout with fp16 inputs
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 ds_mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 // cross-lane exchange inside one 64-lane wavefront
 __device__ __forceinline__ float ds_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float ds_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
@@ -71,12 +78,20 @@ __device__ __forceinline__ f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte
 __device__ __forceinline__ void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ds_u32x4, v), b, (int)byte_off, 0, 0);
 }
+typedef unsigned int ds_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ds_buffer_store_b64(ds_buffer b, unsigned byte_off, ds_u32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, b, (int)byte_off, 0, 0);
+}
 __device__ __forceinline__ float ds_buffer_load_f32(ds_buffer b, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, 0, 0));
 }
 __device__ __forceinline__ void ds_buffer_store_f32(ds_buffer b, unsigned byte_off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b, (int)byte_off, 0, 0);
 }
+
+// Hides how a (per-lane) value was computed: derived addresses are then recomputed where they are used instead of
+// being hoisted out of the enclosing loop into dozens of live registers.
+#define DS_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 
 // 16-byte aligned base of the dynamic LDS allocation (no static __shared__ objects are
 // declared anywhere, so the base is the start of the workgroup's LDS segment)

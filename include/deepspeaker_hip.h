@@ -46,6 +46,11 @@ extern "C" {
 #define DS_EPI_STATS    8   /* also emit per-tile column sums {sum, sum of squares} of the RAW
                                accumulator (train-mode BatchNorm statistics)                       */
 
+#define DS_EPI_OUT_F32  16  /* fp16 convolution: store the result as f32 (the layer feeding the f32 tail)     */
+#define DS_EPI_OUT_F16  32  /* conv1 (ds_conv5x5s2_c1_fwd_bf16): store the result as fp16                    */
+
+#define DS_CONV_HINT_SINGLE_BUFFER 64  /* fp16 convolution: plan with one LDS pixel tile (tuning / test hint)  */
+
 #define DS_CONV_CK      8   /* input-channel chunk of the packed weight layout */
 
 int ds_version(void);
@@ -106,9 +111,10 @@ int ds_conv5x5s2_c1_stats_rows(int B, int H);
 int ds_conv5x5s2_c1_fwd_f32(const float *x, const float *w_packed, const float *scale,
                             const float *shift, float *y, float *stats_partial, int B, int H,
                             int W, int Cout, int flags, void *stream);
-/* the same layer on the bf16 matrix cores with split operands (bf16x3); same packed bank and statistics rows */
+/* the same layer on the bf16 matrix cores with split operands (bf16x3); same packed bank and statistics rows.
+ * y is f32 [B,Ho,Wo,64], or fp16 with DS_EPI_OUT_F16 (the input of the fp16 convolution path) */
 int ds_conv5x5s2_c1_fwd_bf16(const float *x, const float *w_packed, const float *scale,
-                             const float *shift, float *y, float *stats_partial, int B, int H,
+                             const float *shift, void *y, float *stats_partial, int B, int H,
                              int W, int Cout, int flags, void *stream);
 /* generic implicit-GEMM convolution on the f32 matrix cores: 3x3 s1 p1 (model.py:47-50,69,73),
  * 5x5 s2 p2 (model.py:98,102,106 / :192,197,202) and 1x1 (the fc GEMM, model.py:209), with the
@@ -140,6 +146,21 @@ int ds_conv_bf16_plan_describe(const ds_conv_shape *s, int x3, int *out8);
 int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, const void *w_lo,
                      const float *scale, const float *shift, const float *residual, float *y,
                      float *stats_partial, int flags, void *stream);
+
+/* ---- fp16 matrix cores: the eval-forward throughput path ------------------------------------------
+ * Same layers and epilogue as ds_conv_fwd_f32 (model.py:69-80,192-205 in module.eval()), computed with
+ * v_mfma_f32_32x32x16_f16 (fp16 operands, f32 accumulate) on fp16 channels-last activations
+ * [B,H,W,C].  One MFMA per product: the embedding lands 3.7e-4 from the reference (contract 1e-3).
+ * x, residual, y are fp16 buffers (y is f32 with DS_EPI_OUT_F32); DS_EPI_STATS is not supported. */
+/* OIHW f32 -> [Cin/16][KS*KS][Cout][16] fp16 (round to nearest even) */
+int ds_pack_conv_weight_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, void *stream);
+int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
+                    const float *shift, const void *residual_f16, void *y, int flags, void *stream);
+/* out8 = {M tile, N tile, rows per segment, segments per tile, workgroups, LDS bytes, threads per workgroup,
+ * 1000 * double-buffered + staging items per thread} */
+int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8);
+int ds_cast_f32_to_f16(const float *x, void *y_f16, long long n, void *stream);
+int ds_cast_f16_to_f32(const void *x_f16, float *y, long long n, void *stream);
 
 /* ---- tail: temporal average pool, L2 normalisation --------------------------------------------- */
 /* x [B,Hr,Wc,C] -> pooled [B, Wc*C] (index f*C + c), mean over Hr  (model.py:111,207-208) */

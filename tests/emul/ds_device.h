@@ -48,6 +48,27 @@ static inline f32x16 ds_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return c;
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x16_f16: same fragment layout; fp16 products are exact in f32, summed as above
+static inline f32x16 ds_mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+    float A[8][64], B[8][64];
+    for (int j = 0; j < 8; ++j) {
+        emu::wave_exchange((float)a[j], A[j]);
+        emu::wave_exchange((float)b[j], B[j]);
+    }
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        double s = 0.0;
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 8; ++j) s += (double)A[j][row + 32 * g] * (double)B[j][col + 32 * g];
+        c[r] = (float)((double)c[r] + s);
+    }
+    return c;
+}
+
 static inline float ds_shfl_xor(float v, int mask) {
     float all[64];
     emu::wave_exchange(v, all);
@@ -101,6 +122,10 @@ static inline f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte_off) {
 static inline void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
     if ((unsigned long long)byte_off + 16 <= b.bytes) memcpy(b.base + byte_off, &v, 16);
 }
+typedef unsigned int ds_u32x2 __attribute__((ext_vector_type(2)));
+static inline void ds_buffer_store_b64(ds_buffer b, unsigned byte_off, ds_u32x2 v) {
+    if ((unsigned long long)byte_off + 8 <= b.bytes) memcpy(b.base + byte_off, &v, 8);
+}
 static inline float ds_buffer_load_f32(ds_buffer b, unsigned byte_off) {
     float v = 0.0f;
     if ((unsigned long long)byte_off + 4 <= b.bytes) memcpy(&v, b.base + byte_off, 4);
@@ -121,6 +146,8 @@ static inline unsigned long long ds_ballot(int pred) {
         if (all[l] != 0.0f) m |= 1ull << l;
     return m;
 }
+
+#define DS_OPAQUE_VGPR(x) ((void)0)
 
 static inline float *ds_dynamic_lds() { return emu::dynamic_lds(); }
 

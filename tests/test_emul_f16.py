@@ -1,0 +1,141 @@
+"""The fp16 convolution path on the host emulator (no GPU): the unmodified conv_mfma_f16 sources driven through
+the C ABI, compared with the oracle convolution evaluated on the SAME fp16-rounded operands (the kernel's
+products are exact in f32, so only the summation order differs).  Covers both buffering modes, both kernel
+sizes, ragged tiles, residual / clip epilogues and the f32-output flag."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import deepspeaker_oracle as O
+from conftest import rel_err
+from emul_util import aligned, emul_lib, ptr, to_aligned
+from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_SINGLE_BUFFER, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_OUT_F16, DS_EPI_OUT_F32,
+                                             DS_EPI_RESIDUAL, DS_EPI_STATS)
+
+
+def nhwc16(x):
+    return to_aligned(np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16), np.float16)
+
+
+def run_conv_f16(lib, x, w, stride, flags=0, scale=None, shift=None, res=None):
+    b, ci, h, wd = x.shape
+    co, _, k, _ = w.shape
+    shp = ConvShape(b, h, wd, ci, co, k, stride)
+    ho, wo = O.conv_out_size(h, k, stride, k // 2), O.conv_out_size(wd, k, stride, k // 2)
+    out32 = bool(flags & DS_EPI_OUT_F32)
+    y = aligned((b, ho, wo, co), np.float32 if out32 else np.float16, fill=np.nan)
+    wp, src = aligned(w.size, np.float16), to_aligned(w)
+    lib.call("ds_pack_conv_weight_f16", ptr(src), ptr(wp), co, ci, k, None)
+    xh = nhwc16(x)
+    sc = to_aligned(scale) if scale is not None else None
+    sh = to_aligned(shift) if shift is not None else None
+    rh = nhwc16(res) if res is not None else None
+    lib.call("ds_conv_fwd_f16", ctypes.byref(shp), ptr(xh), ptr(wp), ptr(sc), ptr(sh), ptr(rh), ptr(y), flags, None)
+    return np.ascontiguousarray(y.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
+def describe(lib, case):
+    b, ci, co, h, w, k, s = case
+    out8 = (ctypes.c_int * 8)()
+    lib.call("ds_conv_f16_plan_describe", ctypes.byref(ConvShape(b, h, w, ci, co, k, s)), out8)
+    return list(out8)
+
+
+CASES = [
+    # (B, Cin, Cout, H, W, KS, stride)
+    (2, 64, 64, 11, 32, 3, 1),               # stage-1 geometry, two chunks, ragged last row block
+    (3, 32, 128, 20, 8, 3, 1),               # stage-3 geometry, one chunk, 160-pixel tile = one image
+    (5, 96, 128, 10, 4, 3, 1),               # stage-4 geometry: several images per tile, three chunks, ragged tile
+    (2, 64, 128, 21, 16, 5, 2),              # 5x5 stride 2, odd height, two chunks
+    (3, 32, 256, 9, 8, 5, 2),                # 5x5 s2 into a 5x4 map, multi-image tiles
+    (1, 64, 64, 3, 5, 3, 1),                 # tiny map: every tile row ragged
+    (1, 64, 128, 21, 64, 5, 2),              # wide stride-2 input: too many staging items -> single-buffered tile
+    (1, 32, 64, 12, 100, 3, 1),              # wide 3x3 map (variable-length / wide inputs), single chunk
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_f16_raw(case):
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(sum(case))
+    x = np.abs(rs.randn(b, ci, h, w)).astype(np.float16).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
+    y = run_conv_f16(lib, x, wt, s, DS_EPI_OUT_F32)
+    ref = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-6, describe(lib, case)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[3]])
+def test_conv_f16_epilogue(case):
+    """affine + residual + clip, fp16 store (round to nearest even of the f32 epilogue value)"""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(7 + sum(case))
+    x = (np.abs(rs.randn(b, ci, h, w)) * 3).astype(np.float16).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, co).astype(np.float32)
+    shift = rs.randn(co).astype(np.float32)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    res = (np.abs(rs.randn(b, co, ho, wo)) * 8).astype(np.float16).astype(np.float32)
+    flags = DS_EPI_AFFINE | DS_EPI_RESIDUAL | DS_EPI_CLIP
+    y = run_conv_f16(lib, x, wt, s, flags, scale, shift, res)
+    acc = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    ref = np.clip(acc * scale[None, :, None, None] + shift[None, :, None, None] + res, 0.0, 20.0)
+    assert (y >= 0).all() and (y <= 20).all()
+    # one fp16 rounding of a value in [0, 20]: |err| <= 2^-11 * 16 plus the f32 epilogue's own rounding
+    assert np.abs(y - ref).max() <= 20 * 2.0 ** -11 + 1e-5, describe(lib, case)
+    assert np.abs(y - ref).mean() < 1.5e-3
+    # no residual, no clip: negative values survive
+    y2 = run_conv_f16(lib, x, wt, s, DS_EPI_AFFINE | DS_EPI_OUT_F32, scale, shift)
+    ref2 = acc * scale[None, :, None, None] + shift[None, :, None, None]
+    assert rel_err(y2, ref2) < 2e-6
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[6]])
+def test_conv_f16_single_buffered(case):
+    """the one-tile variant of the kernel (what the planner falls back to when two tiles do not fit the LDS)"""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(11 + sum(case))
+    x = np.abs(rs.randn(b, ci, h, w)).astype(np.float16).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
+    y = run_conv_f16(lib, x, wt, s, DS_EPI_OUT_F32 | DS_CONV_HINT_SINGLE_BUFFER)
+    ref = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    assert rel_err(y, ref) < 2e-6
+
+
+def test_conv_f16_rejects_stats_and_bad_shapes():
+    lib = emul_lib()
+    x = aligned((1, 4, 4, 32), np.float16, fill=0)
+    w = aligned(64 * 32 * 9, np.float16, fill=0)
+    y = aligned((1, 4, 4, 64), np.float16, fill=0)
+    shp = ConvShape(1, 4, 4, 32, 64, 3, 1)
+    fn = lib.raw("ds_conv_fwd_f16")
+    assert fn(ctypes.byref(shp), ptr(x), ptr(w), None, None, None, ptr(y), DS_EPI_STATS, None) == -4
+    assert fn(ctypes.byref(ConvShape(1, 4, 4, 16, 64, 3, 1)), ptr(x), ptr(w), None, None, None, ptr(y), 0, None) == -1
+    assert fn(ctypes.byref(shp), None, ptr(w), None, None, None, ptr(y), 0, None) == -3
+
+
+def test_conv1_fp16_output():
+    """conv1's matrix-core kernel with DS_EPI_OUT_F16 stores the rounded f32 result"""
+    lib = emul_lib()
+    rs = np.random.RandomState(5)
+    b, t = 2, 37
+    x = to_aligned(rs.randn(b, t, 64).astype(np.float32))
+    w = (rs.randn(64, 1, 5, 5) * 0.2).astype(np.float32)
+    wp, src = aligned(w.size), to_aligned(w)
+    lib.call("ds_pack_conv1_weight_f32", ptr(src), ptr(wp), 64, None)
+    scale = to_aligned(rs.uniform(0.5, 1.5, 64).astype(np.float32))
+    shift = to_aligned(rs.randn(64).astype(np.float32))
+    ho, wo = (t - 1) // 2 + 1, 32
+    y32 = aligned((b, ho, wo, 64), fill=np.nan)
+    y16 = aligned((b, ho, wo, 64), np.float16, fill=np.nan)
+    fl = DS_EPI_AFFINE | DS_EPI_CLIP
+    lib.call("ds_conv5x5s2_c1_fwd_bf16", ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(y32), None, b, t, 64, 64, fl, None)
+    lib.call("ds_conv5x5s2_c1_fwd_bf16", ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(y16), None, b, t, 64, 64,
+             fl | DS_EPI_OUT_F16, None)
+    assert np.isfinite(y32).all()
+    assert np.array_equal(y16, y32.astype(np.float16))
