@@ -15,7 +15,10 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from ._native import (ConvShape, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_RESIDUAL, DS_EPI_STATS, NativeLib)
+from ._native import (ConvShape, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_OUT_F16, DS_EPI_OUT_F32, DS_EPI_RESIDUAL,
+                      DS_EPI_STATS, NativeLib)
+
+PRECISIONS = ("f32", "bf16x3", "bf16", "f16")
 
 STAGE_CHANNELS = (64, 128, 256, 512)        # reference model.py:93-107
 BN_EPS = 1e-5
@@ -51,6 +54,10 @@ class StageWeights:
     l_conv1_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
     l_conv2_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
     conv_dgrad_bf16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None     # 5x5 stride 2: four parity-class banks
+    # fp16 matrix-core banks [Cin/16][tap][Cout][16] (precision "f16")
+    conv_f16: Optional[torch.Tensor] = None
+    l_conv1_f16: Optional[torch.Tensor] = None
+    l_conv2_f16: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -106,8 +113,13 @@ class Engine:
                       self._p(hi), self._p(lo), w.shape[0], w.shape[1], ks, self._stream(w))
         return hi, lo
 
+    def _pack_f16(self, w: torch.Tensor, ks: int):
+        out = torch.empty(w.numel(), dtype=torch.float16, device=w.device)
+        self.lib.call("ds_pack_conv_weight_f16", self._p(w), self._p(out), w.shape[0], w.shape[1], ks, self._stream(w))
+        return out
+
     def pack_weights(self, sd: Dict[str, torch.Tensor], n_stages: int = 4,
-                     with_dgrad: bool = False, with_bf16: bool = False) -> PackedWeights:
+                     with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False) -> PackedWeights:
         """OIHW / [out,in] parameters (reference shapes) -> kernel layouts."""
         lib = self.lib
         stages = []
@@ -130,6 +142,11 @@ class Engine:
                 lib.call("ds_pack_conv_weight_f32", self._p(wl), self._p(pl), co, co, 3, 0, st)
                 packs.append(pl)
             sw = StageWeights(pc, packs[0], packs[1])
+            if with_f16:
+                if i > 1:
+                    sw.conv_f16 = self._pack_f16(w, 5)
+                sw.l_conv1_f16 = self._pack_f16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3)
+                sw.l_conv2_f16 = self._pack_f16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3)
             if with_bf16:
                 if i > 1:
                     sw.conv_bf16 = self._pack_bf16(w, 5)
@@ -230,10 +247,30 @@ class Engine:
                                  2.0 * B * ho * wo * cout * cin * ks * ks, ev0, ev1))
         return (y, stats) if want_stats else y
 
+    def conv_f16(self, x: torch.Tensor, w_f16: torch.Tensor, B: int, H: int, W: int, cin: int, cout: int, ks: int,
+                 stride: int, scale=None, shift=None, residual=None, flags: int = 0):
+        """Forward convolution on the fp16 matrix cores: fp16 channels-last in, fp16 out (f32 with DS_EPI_OUT_F32)."""
+        shp = ConvShape(B, H, W, cin, cout, ks, stride)
+        ho, wo = conv_out(H, ks, stride), conv_out(W, ks, stride)
+        y = torch.empty((B, ho, wo, cout), dtype=torch.float32 if flags & DS_EPI_OUT_F32 else torch.float16,
+                        device=x.device)
+        prof = self.profile is not None and x.is_cuda
+        if prof:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        self.lib.call("ds_conv_fwd_f16", ctypes.byref(shp), self._p(x), self._p(w_f16), self._p(scale), self._p(shift),
+                      self._p(residual), self._p(y), flags, self._stream(x))
+        if prof:
+            ev1.record()
+            self.profile.append((f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}",
+                                 2.0 * B * ho * wo * cout * cin * ks * ks, ev0, ev1))
+        return y
+
     def conv1(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, scale=None, shift=None,
               flags: int = 0, want_stats: bool = False, lowp: bool = False):
         ho, wo = conv_out(H, 5, 2), conv_out(W, 5, 2)
-        y = torch.empty((B, ho, wo, 64), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, ho, wo, 64), dtype=torch.float16 if flags & DS_EPI_OUT_F16 else torch.float32,
+                        device=x.device)
         stats = None
         if want_stats:
             rows = self.lib.raw("ds_conv5x5s2_c1_stats_rows")(B, H)
@@ -311,24 +348,31 @@ class Engine:
         dev = x.device
         lowp = precision != "f32"
         x3 = precision == "bf16x3"
+        h16 = precision == "f16"
         x_slot, e_slot, st_slot = ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_void_p(0)
         calls = []            # (raw function, argument tuple, profile label or None, flops)
         keep = []             # tensors / structs the argument tuples point into
         AC = DS_EPI_AFFINE | DS_EPI_CLIP
 
-        def buf(*shape):
-            t = torch.empty(shape, dtype=torch.float32, device=dev)
+        def buf(*shape, dtype=torch.float32):
+            t = torch.empty(shape, dtype=dtype, device=dev)
             keep.append(t)
             return t
 
-        def conv_call(src_p, w_f32, w_bf16, Bc, h, w, cin, cout, ks, stride, sc, sh, res):
+        def conv_call(src_p, w_f32, w_bf16, Bc, h, w, cin, cout, ks, stride, sc, sh, res, w_f16=None, last=False):
             shp = ConvShape(Bc, h, w, cin, cout, ks, stride)
             keep.append(shp)
             ho, wo = conv_out(h, ks, stride), conv_out(w, ks, stride)
-            y = buf(Bc, ho, wo, cout)
             flags = AC | (DS_EPI_RESIDUAL if res is not None else 0)
             label = f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}"
             flops = 2.0 * Bc * ho * wo * cout * cin * ks * ks
+            if h16:         # fp16 activations between the layers; the last layer hands f32 to the tail
+                y = buf(Bc, ho, wo, cout, dtype=torch.float32 if last else torch.float16)
+                args = (ctypes.byref(shp), src_p, self._p(w_f16), self._p(sc), self._p(sh), self._p(res), self._p(y),
+                        flags | (DS_EPI_OUT_F32 if last else 0), st_slot)
+                calls.append((self.lib.raw("ds_conv_fwd_f16"), args, label, flops))
+                return y, ho, wo
+            y = buf(Bc, ho, wo, cout)
             if lowp:
                 args = (ctypes.byref(shp), src_p, self._p(w_bf16[0]), self._p(w_bf16[1]) if x3 else None,
                         self._p(sc), self._p(sh), self._p(res), self._p(y), None, flags, st_slot)
@@ -346,18 +390,19 @@ class Engine:
             sc, sh = folded[f"model.bn{i}"]
             if i == 1:
                 ho, wo = conv_out(h, 5, 2), conv_out(w, 5, 2)
-                a = buf(B, ho, wo, 64)
+                a = buf(B, ho, wo, 64, dtype=torch.float16 if h16 else torch.float32)
                 calls.append((self.lib.raw("ds_conv5x5s2_c1_fwd_bf16" if precision != "f32" else "ds_conv5x5s2_c1_fwd_f32"),
-                              (x_slot, self._p(sw.conv), self._p(sc), self._p(sh), self._p(a), None, B, h, w, 64, AC,
-                               st_slot), None, 0.0))
+                              (x_slot, self._p(sw.conv), self._p(sc), self._p(sh), self._p(a), None, B, h, w, 64,
+                               AC | (DS_EPI_OUT_F16 if h16 else 0), st_slot), None, 0.0))
                 h, w = ho, wo
             else:
-                a, h, w = conv_call(self._p(a), sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2, sc, sh, None)
+                a, h, w = conv_call(self._p(a), sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2, sc, sh, None, sw.conv_f16)
             cin = c
             sc, sh = folded[f"model.layer{i}.0.bn1"]
-            y, _, _ = conv_call(self._p(a), sw.l_conv1, sw.l_conv1_bf16, B, h, w, c, c, 3, 1, sc, sh, None)
+            y, _, _ = conv_call(self._p(a), sw.l_conv1, sw.l_conv1_bf16, B, h, w, c, c, 3, 1, sc, sh, None, sw.l_conv1_f16)
             sc, sh = folded[f"model.layer{i}.0.bn2"]
-            a, _, _ = conv_call(self._p(y), sw.l_conv2, sw.l_conv2_bf16, B, h, w, c, c, 3, 1, sc, sh, a)
+            a, _, _ = conv_call(self._p(y), sw.l_conv2, sw.l_conv2_bf16, B, h, w, c, c, 3, 1, sc, sh, a, sw.l_conv2_f16,
+                                last=(s == len(pw.stages) - 1))
         k = w * cin
         n_out = pw.fc_bias.numel()
         pooled = buf(B, k)
@@ -377,7 +422,12 @@ class Engine:
         self._check(x, "input")
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError("input must be [B,1,T,F] (reference model.py:185, SURVEY F1)")
-        if precision != "f32" and pw.stages[0].l_conv1_bf16 is None:
+        if precision not in PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}; expected one of {PRECISIONS}")
+        if precision == "f16":
+            if pw.stages[0].l_conv1_f16 is None:
+                raise ValueError("pack_weights(..., with_f16=True) is required for precision 'f16'")
+        elif precision != "f32" and pw.stages[0].l_conv1_bf16 is None:
             raise ValueError("pack_weights(..., with_bf16=True) is required for the bf16 precisions")
         # the plan owns its intermediate activations: forwards in flight on different streams need their own
         stream_id = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
@@ -412,13 +462,18 @@ class Engine:
         the convolution epilogues -- 3 launches per stage, no intermediate normalisation pass.
 
         precision: "f32" exact-f32 MFMA (the parity path); "bf16x3" split-operand bf16 MFMA (f32-class
-        accuracy); "bf16" plain bf16 operands (speed mode).  conv1 runs its split-operand bf16 kernel in both
-        low-precision modes; fc and the tail are f32 in all modes."""
-        if precision not in ("f32", "bf16x3", "bf16"):
-            raise ValueError(f"unknown precision {precision!r}")
+        accuracy); "f16" fp16 operands and fp16 activations in HBM, f32 accumulate (the throughput path, 3.7e-4
+        from the reference); "bf16" plain bf16 operands (3e-3: outside the contract).  conv1 runs its
+        split-operand bf16 kernel in all low-precision modes; fc and the tail are f32 in all modes."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}; expected one of {PRECISIONS}")
         lowp = precision != "f32"
         x3 = precision == "bf16x3"
-        if lowp and pw.stages[0].l_conv1_bf16 is None:
+        h16 = precision == "f16"
+        if h16:
+            if pw.stages[0].l_conv1_f16 is None:
+                raise ValueError("pack_weights(..., with_f16=True) is required for precision 'f16'")
+        elif lowp and pw.stages[0].l_conv1_bf16 is None:
             raise ValueError("pack_weights(..., with_bf16=True) is required for the bf16 precisions")
         self._check(x, "input")
         B, one, T, F = x.shape
@@ -431,7 +486,9 @@ class Engine:
             i, c = s + 1, STAGE_CHANNELS[s]
             sc, sh = folded[f"model.bn{i}"]
             if i == 1:
-                a, _ = self.conv1(a, sw.conv, B, h, w, sc, sh, AC, lowp=lowp)
+                a, _ = self.conv1(a, sw.conv, B, h, w, sc, sh, AC | (DS_EPI_OUT_F16 if h16 else 0), lowp=lowp)
+            elif h16:
+                a = self.conv_f16(a, sw.conv_f16, B, h, w, cin, c, 5, 2, sc, sh, None, AC)
             elif lowp:
                 a = self.conv_bf16(a, sw.conv_bf16, x3, B, h, w, cin, c, 5, 2, sc, sh, None, AC)
             else:
@@ -440,14 +497,19 @@ class Engine:
             if taps is not None:
                 taps[f"stage{i}.a"] = a
             sc, sh = folded[f"model.layer{i}.0.bn1"]
-            if lowp:
+            if h16:
+                y = self.conv_f16(a, sw.l_conv1_f16, B, h, w, c, c, 3, 1, sc, sh, None, AC)
+            elif lowp:
                 y = self.conv_bf16(a, sw.l_conv1_bf16, x3, B, h, w, c, c, 3, 1, sc, sh, None, AC)
             else:
                 y, _ = self.conv(a, sw.l_conv1, B, h, w, c, c, 3, 1, sc, sh, None, AC)
             if taps is not None:
                 taps[f"stage{i}.b"] = y
             sc, sh = folded[f"model.layer{i}.0.bn2"]
-            if lowp:
+            if h16:         # the last layer hands f32 to the (f32) pooling / projection tail
+                last = DS_EPI_OUT_F32 if s == len(pw.stages) - 1 else 0
+                a = self.conv_f16(y, sw.l_conv2_f16, B, h, w, c, c, 3, 1, sc, sh, a, AC | DS_EPI_RESIDUAL | last)
+            elif lowp:
                 a = self.conv_bf16(y, sw.l_conv2_bf16, x3, B, h, w, c, c, 3, 1, sc, sh, a, AC | DS_EPI_RESIDUAL)
             else:
                 a, _ = self.conv(y, sw.l_conv2, B, h, w, c, c, 3, 1, sc, sh, a, AC | DS_EPI_RESIDUAL)

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _native
-from .engine import ALPHA, BNParams, Engine, L2_EPS, STAGE_CHANNELS
+from .engine import ALPHA, BNParams, Engine, L2_EPS, PRECISIONS, STAGE_CHANNELS
 
 _engine: Optional[Engine] = None
 
@@ -285,7 +285,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
         eng = get_engine()
-        prec = "bf16x3" if model.precision == "bf16x3" else "f32"
+        prec = "bf16x3" if model.precision in ("bf16x3", "f16") else "f32"
         pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"))
         e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer, precision=prec)
         ctx.precision = prec
@@ -352,8 +352,11 @@ class DeepSpeakerModel(nn.Module):
         super().__init__()
         # arithmetic of the stage convolutions: "f32" (exact-f32 MFMA), "bf16x3" (split-operand bf16 MFMA,
         # f32-class accuracy; in training: forward, data and filter gradients of the 3x3 / 5x5 layers; the fc
-        # layer, conv1's filter gradient and the BatchNorm / loss passes stay f32) or "bf16"
-        # (eval-only speed mode; training then runs in f32)
+        # layer, conv1's filter gradient and the BatchNorm / loss passes stay f32), "f16" (eval: fp16 operands
+        # and activations, f32 accumulate -- the throughput path; training then runs in bf16x3) or "bf16"
+        # (eval-only speed mode outside the 1e-3 contract; training then runs in f32)
+        if precision not in PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}; expected one of {PRECISIONS}")
         self.precision = precision
         if feature_dim != 64:
             # the reference's feature_dim == 40 branch is dead code that cannot run
@@ -401,12 +404,12 @@ class DeepSpeakerModel(nn.Module):
         sd["model.fc.bias"] = self.model.fc.bias
         return sd
 
-    def _packed(self, with_dgrad: bool = False, with_bf16: bool = False):
+    def _packed(self, with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False):
         sd = self._conv_fc_tensors()
-        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (with_dgrad, with_bf16)
+        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (with_dgrad, with_bf16, with_f16)
         if self._pack_key != key:
             self._pack_cache = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad,
-                                                         with_bf16=with_bf16)
+                                                         with_bf16=with_bf16, with_f16=with_f16)
             self._pack_key = key
         return self._pack_cache
 
@@ -465,9 +468,8 @@ class DeepSpeakerModel(nn.Module):
                     bn.num_batches_tracked += 1
                 self.features = e
         else:
-            lowp = self.precision != "f32"
-            self.features = get_engine().forward_eval_planned(x, self._packed(with_bf16=lowp), self._folded(),
-                                                              precision=self.precision)
+            pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
+            self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=self.precision)
         return self.features
 
     def graphed(self, example: torch.Tensor) -> "GraphedEmbedder":

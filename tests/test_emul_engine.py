@@ -126,14 +126,14 @@ def test_backward_matches_oracle(n_stages, B, T, seed):
         assert err < 5e-5, (k, err)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 3e-2), ("f16", 1e-3)])
 def test_forward_eval_bf16_precisions(precision, tol):
     eng = Engine(emul_lib())
     n_stages, B, T = 4, 2, 32
     sd = O.make_state_dict(seed=9, num_classes=4, n_stages=n_stages)
     x = O.make_input(seed=6, batch=B, frames=T)
     tsd = torch_sd(sd)
-    pw = eng.pack_weights(tsd, n_stages, with_bf16=True)
+    pw = eng.pack_weights(tsd, n_stages, with_bf16=precision != "f16", with_f16=precision == "f16")
     folded = {n: eng.bn_fold(b) for n, b in make_bns(tsd, n_stages).items()}
     e = eng.forward_eval(torch.from_numpy(x), pw, folded, precision=precision)
     ref = O.forward(sd, x, n_stages=n_stages, dtype=np.float64)
@@ -249,7 +249,7 @@ def test_classifier_head_and_cross_entropy(golden):
     assert abs(float(l2) - float(golden["ce_value"])) < 1e-6
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16"])
 def test_planned_eval_forward_equals_unplanned(precision):
     """The cached launch plan must be the same computation as the step-by-step forward, call after call
     (buffers are re-used) and across shapes."""
@@ -257,7 +257,7 @@ def test_planned_eval_forward_equals_unplanned(precision):
     n_stages = 2
     sd = O.make_state_dict(seed=19, num_classes=4, n_stages=n_stages)
     tsd = torch_sd(sd)
-    pw = eng.pack_weights(tsd, n_stages, with_bf16=True)
+    pw = eng.pack_weights(tsd, n_stages, with_bf16=True, with_f16=True)
     folded = {n: eng.bn_fold(b) for n, b in make_bns(tsd, n_stages).items()}
     for seed, (B, T) in enumerate([(2, 24), (3, 17), (2, 24)]):
         x = torch.from_numpy(O.make_input(seed=seed, batch=B, frames=T))
