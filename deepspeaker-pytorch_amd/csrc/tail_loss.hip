@@ -139,6 +139,84 @@ __global__ void __launch_bounds__(256) triplet_filter_kernel(const float *d_p, c
     }
 }
 
+// ---- the whole scalar side of the triplet step in ONE single-workgroup pass over d_p / d_n ------------------
+// (model.py:27-33 and train_triplet.py:253-262): loss = mean hinge, the ordered filter {i : d_n - d_p < margin},
+// mean(d_n - d_p), and -- new -- the ordered list of NEAR TIES |d_n - d_p - margin| < band (at most amb_cap
+// entries; unused slots hold index 0 so that they stay valid gather indices; amb_count is the true count).
+// Fixed summation order, ordered block scans: deterministic.
+__global__ void __launch_bounds__(256) triplet_scan_kernel(const float *d_p, const float *d_n, float margin, float band,
+                                                           float *loss, long long *idx, int *count, float *mean_diff,
+                                                           long long *amb_idx, int *amb_count, int amb_cap, int N) {
+    float *scratch = ds_dynamic_lds();
+    int *iscratch = (int *)(scratch + 8);       // [2][4] wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (amb_idx)
+        for (int i = threadIdx.x; i < amb_cap; i += 256) amb_idx[i] = 0;
+    int base = 0, abase = 0;
+    float dsum = 0.f, hsum = 0.f;
+    for (int i0 = 0; i0 < N; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        float diff = 0.f, hinge = 0.f;
+        int sel = 0, amb = 0;
+        if (i < N) {
+            const float dp = d_p[i], dn = d_n[i];
+            diff = dn - dp;
+            sel = diff < margin;                                   // train_triplet.py:253
+            hinge = fmaxf(margin + dp - dn, 0.0f);                 // model.py:30-31
+            amb = fabsf(diff - margin) < band;
+        }
+        dsum += diff;
+        hsum += hinge;
+        const unsigned long long m = ds_ballot(sel), ma = ds_ballot(amb);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int before = __popcll(m & below), abefore = __popcll(ma & below);
+        if (lane == 0) {
+            iscratch[wave] = __popcll(m);
+            iscratch[4 + wave] = __popcll(ma);
+        }
+        __syncthreads();
+        int woff = 0, awoff = 0;
+        for (int w = 0; w < wave; ++w) {
+            woff += iscratch[w];
+            awoff += iscratch[4 + w];
+        }
+        const int tot = iscratch[0] + iscratch[1] + iscratch[2] + iscratch[3];
+        const int atot = iscratch[4] + iscratch[5] + iscratch[6] + iscratch[7];
+        if (sel) idx[base + woff + before] = i;
+        if (amb && amb_idx && abase + awoff + abefore < amb_cap) amb_idx[abase + awoff + abefore] = i;
+        base += tot;
+        abase += atot;
+        __syncthreads();
+    }
+    const float dtot = block_sum_256(dsum, scratch);
+    const float htot = block_sum_256(hsum, scratch);
+    if (threadIdx.x == 0) {
+        count[0] = base;
+        mean_diff[0] = dtot / (float)N;
+        loss[0] = htot / (float)N;
+        if (amb_count) amb_count[0] = abase;
+    }
+}
+
+// Near-tie refinement: slot s < min(amb_count, cap) holds triplet i = amb_idx[s], whose three utterances were
+// re-embedded at f32-class precision into e_ref rows (s, cap + s, 2 cap + s); its distances are replaced.
+__global__ void __launch_bounds__(256) refine_distances_kernel(const float *e_ref, const long long *amb_idx,
+                                                               const int *amb_count, int cap, float *d_p, float *d_n,
+                                                               int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int live_n = amb_count[0] < cap ? amb_count[0] : cap;
+    const int r = s < cap ? s : 0;
+    const float *a = e_ref + (size_t)r * D, *p = e_ref + (size_t)(cap + r) * D, *n = e_ref + (size_t)(2 * cap + r) * D;
+    const float sp = row_sqdist(a, p, D, lane);
+    const float sn = row_sqdist(a, n, D, lane);
+    if (s < live_n && lane == 0) {
+        const long long i = amb_idx[s];
+        d_p[i] = sqrtf(sp + eps);
+        d_n[i] = sqrtf(sn + eps);
+    }
+}
+
 // ---- backward of the loss side (autograd of model.py:13-18, 27-33) -------------------------------
 // d = sqrt(sum (x1-x2)^2 + eps)  ->  dx1 = gd * (x1-x2)/d, dx2 = -dx1
 __global__ void __launch_bounds__(256) pairwise_distance_bwd_kernel(const float *x1, const float *x2, const float *d,
@@ -487,6 +565,45 @@ extern "C" int ds_triplet_filter_f32(const float *d_p, const float *d_n, float m
     DS_REQUIRE(d_p && d_n && idx && count && mean_diff, DS_ERR_NULL);
     DS_REQUIRE(N > 0, DS_ERR_BAD_SHAPE);
     DS_LAUNCH(triplet_filter_kernel, 1, 256, 64, stream, d_p, d_n, margin, idx, count, mean_diff, N);
+    return ds_last_launch_error();
+}
+
+// The triplet step's loss side in two launches: distances (one wave per row), then ONE scan over the 2N scalars
+// for the loss, the filter, the mean difference and the near-tie list.  Shared by TripletMarginLoss.forward and
+// select_triplets, so the distances are computed once per step.
+extern "C" int ds_triplet_tail_f32(const float *a, const float *p, const float *n, float margin, float band,
+                                   float *d_p, float *d_n, float *loss, long long *idx, int *count, float *mean_diff,
+                                   long long *amb_idx, int *amb_count, int amb_cap, int N, int D, void *stream) {
+    DS_REQUIRE(a && p && n && d_p && d_n && loss && idx && count && mean_diff, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0 && amb_cap >= 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(amb_cap == 0 || (amb_idx && amb_count), DS_ERR_NULL);
+    const float eps = (float)(1e-4 / (double)D);
+    DS_LAUNCH(triplet_dist_kernel, ds_ceil_div(N, 4), 256, 0, stream, a, p, n, d_p, d_n, N, D, eps);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(triplet_scan_kernel, 1, 256, 64, stream, (const float *)d_p, (const float *)d_n, margin,
+              amb_cap > 0 ? band : -1.0f, loss, idx, count, mean_diff, amb_cap > 0 ? amb_idx : (long long *)nullptr,
+              amb_cap > 0 ? amb_count : (int *)nullptr, amb_cap, N);
+    return ds_last_launch_error();
+}
+
+// the scan alone, over distances that already exist (after ds_refine_distances_f32 patched the near ties)
+extern "C" int ds_triplet_scan_f32(const float *d_p, const float *d_n, float margin, float *loss, long long *idx,
+                                   int *count, float *mean_diff, int N, void *stream) {
+    DS_REQUIRE(d_p && d_n && loss && idx && count && mean_diff, DS_ERR_NULL);
+    DS_REQUIRE(N > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(triplet_scan_kernel, 1, 256, 64, stream, d_p, d_n, margin, -1.0f, loss, idx, count, mean_diff,
+              (long long *)nullptr, (int *)nullptr, 0, N);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_refine_distances_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap,
+                                       float *d_p, float *d_n, int D, void *stream) {
+    DS_REQUIRE(e_ref && amb_idx && amb_count && d_p && d_n, DS_ERR_NULL);
+    DS_REQUIRE(cap > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    const float eps = (float)(1e-4 / (double)D);
+    DS_LAUNCH(refine_distances_kernel, ds_ceil_div(cap, 4), 256, 0, stream, e_ref, amb_idx, amb_count, cap, d_p, d_n, D,
+              eps);
     return ds_last_launch_error();
 }
 

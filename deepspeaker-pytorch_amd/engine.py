@@ -435,6 +435,10 @@ class Engine:
         plans = self.__dict__.setdefault("_eval_plans", {})
         plan = plans.get(key)
         if plan is None:
+            # a plan pins its packed filters, folded BatchNorm and activation buffers: drop the plans of this
+            # shape that were built for an older weights generation, and bound the total
+            for k in [k for k in plans if k[:2] == key[:2] and k[4:] == key[4:] and k[2:4] != key[2:4]]:
+                del plans[k]
             if len(plans) > 16:
                 plans.clear()
             plan = plans[key] = self._build_eval_plan(x, pw, folded, precision)
@@ -578,17 +582,42 @@ class Engine:
         self.lib.call("ds_pairwise_distance_f32", self._p(x1), self._p(x2), self._p(out), n, d, self._stream(x1))
         return out
 
-    def triplet_margin(self, a, p, n, margin: float):
+    def triplet_tail(self, a, p, n, margin: float, band: float = 0.0, amb_cap: int = 0) -> dict:
+        """The loss side of one triplet step (model.py:27-33, train_triplet.py:251-262) in two launches:
+        distances, then one scan giving the loss, the ordered filter, mean(d_n - d_p) and (amb_cap > 0) the
+        near-tie list.  The result of the latest call is kept, keyed on the three embedding buffers (held alive,
+        so their addresses cannot be recycled) and their version counters: `TripletMarginLoss.forward` and
+        `select_triplets` on the same embeddings share one computation."""
         for t, nm in ((a, "anchor"), (p, "positive"), (n, "negative")):
             self._check(t, nm)
         assert a.size() == p.size() == n.size()
+        stream_id = torch.cuda.current_stream(a.device).cuda_stream if a.is_cuda else 0
+        key = (a.data_ptr(), a._version, p.data_ptr(), p._version, n.data_ptr(), n._version, tuple(a.shape),
+               float(margin), float(band), int(amb_cap), stream_id)
+        memo = self.__dict__.get("_tail_memo")
+        if memo is not None and memo["key"] == key:
+            return memo
         rows, d = a.shape
-        d_p = torch.empty(rows, dtype=torch.float32, device=a.device)
-        d_n = torch.empty_like(d_p)
-        loss = torch.empty(1, dtype=torch.float32, device=a.device)
-        self.lib.call("ds_triplet_margin_fwd_f32", self._p(a), self._p(p), self._p(n), float(margin),
-                      self._p(d_p), self._p(d_n), self._p(loss), rows, d, self._stream(a))
-        return loss, d_p, d_n
+        dev = a.device
+        out = {"key": key, "hold": (a, p, n),
+               "d_p": torch.empty(rows, dtype=torch.float32, device=dev),
+               "d_n": torch.empty(rows, dtype=torch.float32, device=dev),
+               "loss": torch.empty(1, dtype=torch.float32, device=dev),
+               "idx": torch.empty(rows, dtype=torch.int64, device=dev),
+               "count": torch.empty(1, dtype=torch.int32, device=dev),
+               "mean_diff": torch.empty(1, dtype=torch.float32, device=dev),
+               "amb_idx": torch.empty(amb_cap, dtype=torch.int64, device=dev) if amb_cap > 0 else None,
+               "amb_count": torch.empty(1, dtype=torch.int32, device=dev) if amb_cap > 0 else None}
+        self.lib.call("ds_triplet_tail_f32", self._p(a), self._p(p), self._p(n), float(margin), float(band),
+                      self._p(out["d_p"]), self._p(out["d_n"]), self._p(out["loss"]), self._p(out["idx"]),
+                      self._p(out["count"]), self._p(out["mean_diff"]), self._p(out["amb_idx"]),
+                      self._p(out["amb_count"]), int(amb_cap), rows, d, self._stream(a))
+        self._tail_memo = out
+        return out
+
+    def triplet_margin(self, a, p, n, margin: float):
+        t = self.triplet_tail(a, p, n, margin)
+        return t["loss"], t["d_p"], t["d_n"]
 
     def triplet_filter(self, d_p: torch.Tensor, d_n: torch.Tensor, margin: float):
         """train_triplet.py:251-262 on the device: returns (idx[int64, N] of which the first `count`

@@ -291,6 +291,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
         ctx.precision = prec
         for bn in model._bn_modules():
             bn.num_batches_tracked += 1                             # nn.BatchNorm2d.train() bookkeeping
+        model._stat_updates += 1
         ctx.saved_forward = saved
         ctx.model = model
         ctx.pw = pw
@@ -369,8 +370,9 @@ class DeepSpeakerModel(nn.Module):
         self.model.fc = nn.Linear(c_last * f_bins, self.embedding_size)       # 512*4 (model.py:164)
         self.model.classifier = nn.Linear(self.embedding_size, num_classes)   # model.py:167
         self._reducer = None          # set by enable_data_parallel()
-        self._pack_cache = None
+        self._pack_cache = {}
         self._pack_key = None
+        self._stat_updates = 0        # train-mode forwards so far (invalidates the folded BatchNorm cache)
         self._fold_cache = None
         self._fold_key = None
         self._param_names = [n for n, _ in self.named_parameters() if not n.startswith("model.classifier")]
@@ -405,18 +407,25 @@ class DeepSpeakerModel(nn.Module):
         return sd
 
     def _packed(self, with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False):
+        """Kernel-layout copies of the filters for one set of consumers; one copy per variant is kept until a
+        parameter changes (version counters), so alternating precisions do not re-pack."""
         sd = self._conv_fc_tensors()
-        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (with_dgrad, with_bf16, with_f16)
+        key = tuple((t.data_ptr(), t._version) for t in sd.values())
         if self._pack_key != key:
-            self._pack_cache = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad,
-                                                         with_bf16=with_bf16, with_f16=with_f16)
-            self._pack_key = key
-        return self._pack_cache
+            self._pack_cache, self._pack_key = {}, key
+        variant = (with_dgrad, with_bf16, with_f16)
+        pw = self._pack_cache.get(variant)
+        if pw is None:
+            pw = self._pack_cache[variant] = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad,
+                                                                       with_bf16=with_bf16, with_f16=with_f16)
+        return pw
 
     def _folded(self):
         mods = self._bn_modules()
+        # num_batches_tracked (a host-visible counter bumped by every train-mode forward) stands in for the
+        # running statistics' version: the finalize kernels update those through raw pointers
         key = tuple((t.data_ptr(), t._version) for m in mods
-                    for t in (m.weight, m.bias, m.running_mean, m.running_var))
+                    for t in (m.weight, m.bias, m.running_mean, m.running_var)) + (self._stat_updates,)
         if self._fold_key != key:
             eng = get_engine()
             self._fold_cache = {n: eng.bn_fold(b) for n, b in self._bn_params().items()}
@@ -466,11 +475,20 @@ class DeepSpeakerModel(nn.Module):
                                                   reducer=self._reducer)
                 for bn in self._bn_modules():
                     bn.num_batches_tracked += 1
+                self._stat_updates += 1
                 self.features = e
         else:
             pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
             self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=self.precision)
         return self.features
+
+    def embed_reference(self, x: torch.Tensor) -> torch.Tensor:
+        """Eval-mode embeddings at f32-class precision (split-operand bf16 path) whatever `self.precision` is:
+        what the near-tie refinement of `mining.select_triplets` re-embeds with."""
+        _require_cuda(x, "DeepSpeakerModel.embed_reference")
+        prec = "f32" if self.precision == "f32" else "bf16x3"
+        pw = self._packed(with_bf16=prec == "bf16x3")
+        return get_engine().forward_eval_planned(x.contiguous().float(), pw, self._folded(), precision=prec)
 
     def graphed(self, example: torch.Tensor) -> "GraphedEmbedder":
         """HIP-graph replay of the eval forward for inputs of `example`'s shape (serving: at small batch the

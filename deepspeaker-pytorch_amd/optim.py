@@ -23,10 +23,32 @@ class _FusedBase(torch.optim.Optimizer):
     def _eng(self):
         return self._engine if self._engine is not None else get_engine()
 
-    def _tables(self, group, state_keys: List[str], need_state2: bool, with_step: bool = True):
-        """Device pointer tables + chunk table for the parameters of `group` that have gradients (cached
-        until the set of tensors / their storage changes)."""
-        params = [p for p in group["params"] if p.grad is not None]
+    @staticmethod
+    def _bump_versions(params):
+        """The kernels write parameters through raw pointers; autograd's version counters are what
+        DeepSpeakerModel's packed-filter / folded-BatchNorm caches (and autograd's own saved-tensor checks) watch."""
+        for p in params:
+            torch.autograd.graph.increment_version(p)
+
+    def _partitions(self, group, fresh_key=None):
+        """Parameters with gradients, split into sets that share the per-step scalars: the step count (Adagrad's
+        decayed lr, Adam's bias correction) or, for SGD, whether the momentum buffer exists yet -- a parameter
+        that starts receiving gradients later (the classifier head when the regime switches) must not inherit
+        the others' count, nor reset their buffers."""
+        parts = {}
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            st = self.state[p]
+            k = (fresh_key not in st) if fresh_key is not None else float(st["step"]) if "step" in st else 0.0
+            parts.setdefault(k, []).append(p)
+        return parts
+
+    def _tables(self, group, state_keys: List[str], need_state2: bool, with_step: bool = True, params=None):
+        """Device pointer tables + chunk table for `params` (default: the parameters of `group` that have
+        gradients), cached until the set of tensors / their storage changes."""
+        if params is None:
+            params = [p for p in group["params"] if p.grad is not None]
         if not params:
             return None
         for p in params:
@@ -43,7 +65,8 @@ class _FusedBase(torch.optim.Optimizer):
             states.append(st)
         key = tuple((p.data_ptr(), p.grad.data_ptr()) + tuple(st[k].data_ptr() for k in state_keys)
                     for p, st in zip(params, states))
-        cache = group.get("_ds_cache")
+        caches = group.setdefault("_ds_cache", {})
+        cache = caches.get(len(params))
         if cache is None or cache["key"] != key:
             dev = params[0].device
             chunk = self._eng().lib.raw("ds_optim_chunk_elems")()
@@ -65,7 +88,7 @@ class _FusedBase(torch.optim.Optimizer):
                 "ct": torch.tensor(ct, dtype=torch.int32).to(dev), "ci": torch.tensor(ci, dtype=torch.int32).to(dev),
                 "n_chunks": len(ct),
             }
-            group["_ds_cache"] = cache
+            caches[len(params)] = cache
         return params, states, cache
 
     @staticmethod
@@ -91,16 +114,15 @@ class FusedAdagrad(_FusedBase):
         loss = closure() if closure is not None else None
         eng = self._eng()
         for group in self.param_groups:
-            t = self._tables(group, ["sum"], False)
-            if t is None:
-                continue
-            params, states, c = t
-            for st in states:
-                st["step"] += 1
-            step = float(states[0]["step"])
-            clr = group["lr"] / (1 + (step - 1) * group["lr_decay"])
-            eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
-                         eng._stream(params[0]))
+            for part in self._partitions(group).values():
+                params, states, c = self._tables(group, ["sum"], False, params=part)
+                for st in states:
+                    st["step"] += 1
+                step = float(states[0]["step"])
+                clr = group["lr"] / (1 + (step - 1) * group["lr_decay"])
+                eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
+                             eng._stream(params[0]))
+                self._bump_versions(params)
         return loss
 
 
@@ -115,13 +137,12 @@ class FusedSGD(_FusedBase):
         loss = closure() if closure is not None else None
         eng = self._eng()
         for group in self.param_groups:
-            fresh = any("momentum_buffer" not in self.state[p] for p in group["params"] if p.grad is not None)
-            t = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False, with_step=False)
-            if t is None:
-                continue
-            params, states, c = t
-            eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
-                         group["weight_decay"], int(fresh), eng._stream(params[0]))
+            for fresh, part in self._partitions(group, fresh_key="momentum_buffer").items():
+                params, states, c = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False,
+                                                 with_step=False, params=part)
+                eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
+                             group["weight_decay"], int(fresh), eng._stream(params[0]))
+                self._bump_versions(params)
         return loss
 
 
@@ -136,16 +157,15 @@ class FusedAdam(_FusedBase):
         loss = closure() if closure is not None else None
         eng = self._eng()
         for group in self.param_groups:
-            t = self._tables(group, ["exp_avg", "exp_avg_sq"], True)
-            if t is None:
-                continue
-            params, states, c = t
-            for st in states:
-                st["step"] += 1
-            step = float(states[0]["step"])
-            b1, b2 = group["betas"]
-            eng.lib.call("ds_adam_step_f32", *self._args(eng, c), group["lr"], b1, b2, group["eps"],
-                         group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), eng._stream(params[0]))
+            for part in self._partitions(group).values():
+                params, states, c = self._tables(group, ["exp_avg", "exp_avg_sq"], True, params=part)
+                for st in states:
+                    st["step"] += 1
+                step = float(states[0]["step"])
+                b1, b2 = group["betas"]
+                eng.lib.call("ds_adam_step_f32", *self._args(eng, c), group["lr"], b1, b2, group["eps"],
+                             group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), eng._stream(params[0]))
+                self._bump_versions(params)
         return loss
 
 

@@ -189,6 +189,19 @@ int ds_triplet_margin_fwd_f32(const float *a, const float *p, const float *n, fl
  * d_n[i] - d_p[i] < margin; count[0] = number selected; mean_diff[0] = mean(d_n - d_p). */
 int ds_triplet_filter_f32(const float *d_p, const float *d_n, float margin, long long *idx,
                           int *count, float *mean_diff, int N, void *stream);
+/* The loss side of one triplet step in two launches (distances, then one scan): loss (model.py:27-33), the
+ * ordered filter + mean(d_n - d_p) (train_triplet.py:253-262) and, when amb_cap > 0, the ordered list of near
+ * ties |d_n - d_p - margin| < band (first amb_cap of them; unused slots hold 0; amb_count = true count).  The near
+ * ties are what a reduced-precision forward may decide differently from the reference: the caller re-embeds them
+ * at f32-class precision, patches their distances with ds_refine_distances_f32 (e_ref rows: anchors | positives |
+ * negatives, cap each) and re-runs the scan with ds_triplet_scan_f32. */
+int ds_triplet_tail_f32(const float *a, const float *p, const float *n, float margin, float band, float *d_p,
+                        float *d_n, float *loss, long long *idx, int *count, float *mean_diff, long long *amb_idx,
+                        int *amb_count, int amb_cap, int N, int D, void *stream);
+int ds_triplet_scan_f32(const float *d_p, const float *d_n, float margin, float *loss, long long *idx, int *count,
+                        float *mean_diff, int N, void *stream);
+int ds_refine_distances_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
+                            float *d_n, int D, void *stream);
 
 
 /* ---- backward of the convolution stack (torch autograd of nn.Conv2d / nn.BatchNorm2d under

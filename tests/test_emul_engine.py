@@ -83,6 +83,52 @@ def test_loss_side(golden):
     assert rel_err(eng.pairwise_distance(ta, tp).numpy(), golden["loss_d_p"]) < 1e-6
 
 
+@pytest.mark.parametrize("N,cap", [(1, 4), (5, 2), (256, 8), (700, 8)])
+def test_triplet_tail_scan_and_refinement(N, cap):
+    """ds_triplet_tail_f32 (loss + ordered filter + mean difference + near-tie list in one scan) against the
+    oracle; then the near-tie refinement: patched distances and a re-scan give the selection of the patched set."""
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(100 + N)
+    D = 64
+    a = rs.randn(N, D).astype(np.float32)
+    p = a + rs.randn(N, D).astype(np.float32) * 0.05
+    n = a + rs.randn(N, D).astype(np.float32) * 0.05
+    margin, band = 0.1, 0.02
+    t = eng.triplet_tail(*(torch.from_numpy(v) for v in (a, p, n)), margin, band=band, amb_cap=cap)
+    ref_loss, d_p, d_n = O.triplet_margin_loss(a, p, n, margin)
+    ref_idx, _, md = O.triplet_filter(d_p, d_n, margin)
+    assert rel_err(t["d_p"].numpy(), d_p) < 1e-6 and rel_err(t["d_n"].numpy(), d_n) < 1e-6
+    assert abs(float(t["loss"]) - float(ref_loss)) < 1e-6
+    assert int(t["count"]) == len(ref_idx)
+    np.testing.assert_array_equal(t["idx"].numpy()[:len(ref_idx)], ref_idx)
+    assert abs(float(t["mean_diff"]) - md) < 1e-6
+    amb_ref = np.where(np.abs(t["d_n"].numpy() - t["d_p"].numpy() - np.float32(margin)) < np.float32(band))[0]
+    assert int(t["amb_count"]) == len(amb_ref)
+    k = min(cap, len(amb_ref))
+    np.testing.assert_array_equal(t["amb_idx"].numpy()[:k], amb_ref[:k])
+    assert (t["amb_idx"].numpy()[k:] == 0).all()
+    # same call again: served from the memo (the same buffers come back)
+    assert eng.triplet_tail(*t["hold"], margin, band=band, amb_cap=cap) is t
+    # refinement: "re-embedded" rows for the cap slots (anchors | positives | negatives)
+    e_ref = rs.randn(3 * cap, D).astype(np.float32)
+    dp2, dn2 = t["d_p"].clone(), t["d_n"].clone()
+    eng.lib.call("ds_refine_distances_f32", eng._p(torch.from_numpy(e_ref)), eng._p(t["amb_idx"]), eng._p(t["amb_count"]),
+                 cap, eng._p(dp2), eng._p(dn2), D, None)
+    exp_p, exp_n = t["d_p"].numpy().copy(), t["d_n"].numpy().copy()
+    for s_ in range(k):
+        i = amb_ref[s_]
+        exp_p[i] = O.pairwise_distance(e_ref[s_:s_ + 1], e_ref[cap + s_:cap + s_ + 1])[0]
+        exp_n[i] = O.pairwise_distance(e_ref[s_:s_ + 1], e_ref[2 * cap + s_:2 * cap + s_ + 1])[0]
+    assert rel_err(dp2.numpy(), exp_p) < 1e-6 and rel_err(dn2.numpy(), exp_n) < 1e-6
+    idx, count = torch.empty(N, dtype=torch.int64), torch.empty(1, dtype=torch.int32)
+    md2, loss2 = torch.empty(1), torch.empty(1)
+    eng.lib.call("ds_triplet_scan_f32", eng._p(dp2), eng._p(dn2), margin, eng._p(loss2), eng._p(idx), eng._p(count),
+                 eng._p(md2), N, None)
+    ref_idx2, _, _ = O.triplet_filter(dp2.numpy(), dn2.numpy(), margin)
+    np.testing.assert_array_equal(idx.numpy()[:int(count)], ref_idx2)
+    assert abs(float(loss2) - float(np.maximum(margin + dp2.numpy() - dn2.numpy(), 0).mean())) < 1e-6
+
+
 @pytest.mark.parametrize("N", [1, 5, 256, 700])
 def test_filter_sizes(N):
     eng = Engine(emul_lib())
@@ -162,14 +208,20 @@ def test_fused_optimizers_match_torch(kind):
         ref = torch.optim.Adam(ref_p, lr=0.01, weight_decay=1e-3)
         ours = fo.FusedAdam(our_p, lr=0.01, weight_decay=1e-3)
     ours._engine = eng
-    for it in range(3):
-        for a, b in zip(ref_p, our_p):
+    for it in range(4):
+        for k, (a, b) in enumerate(zip(ref_p, our_p)):
+            if k == 1 and it < 2:       # a parameter that starts receiving gradients later (the classifier head
+                a.grad = b.grad = None  # when the regime switches): its own step count / fresh momentum buffer
+                continue
             g = torch.from_numpy(rs.randn(*a.shape).astype(np.float32))
             a.grad, b.grad = g.clone(), g.clone()
+        versions = [b._version for b in our_p]
         ref.step()
         ours.step()
-        for a, b in zip(ref_p, our_p):
-            assert rel_err(b.detach().numpy(), a.detach().numpy()) < 2e-6, (kind, it)
+        for k, (a, b) in enumerate(zip(ref_p, our_p)):
+            assert rel_err(b.detach().numpy(), a.detach().numpy()) < 2e-6, (kind, it, k)
+            # raw-pointer updates must be visible to version-keyed caches (DeepSpeakerModel._packed / _folded)
+            assert (b._version > versions[k]) == (b.grad is not None), (kind, it, k)
     # state interchange: our state_dict loads into torch's optimizer and vice versa
     sd = ours.state_dict()
     assert set(sd["state"][0].keys()) == set(ref.state_dict()["state"][0].keys())
