@@ -57,7 +57,7 @@ namespace {
 // NIT: 16-byte staging items per thread and chunk (compile time: all loads of a chunk are in flight together).
 // DB:  two pixel-tile buffers in LDS; requires the register prefetch (NIT <= 16).
 template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT, bool DB>
-__global__ void __launch_bounds__(WM * WN * 64) conv_mfma_f16_kernel(const ConvKH p) {
+__global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f16_kernel(const ConvKH p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = MSUB * WM * 32;
     constexpr int NTILE = NSUB * WN * 32;

@@ -17,23 +17,44 @@ from .model import _require_cuda, get_engine
 # a triplet whose |d_n - d_p - margin| is below that can land on the other side of the filter.  Every triplet
 # inside REFINE_BAND is therefore re-embedded through the split-operand bf16 path (f32-class, 5e-6) and decided
 # on those distances; outside the band the fp16 decision is already the reference's.
-REFINE_BAND = 2e-3          # > 3x the largest observed |error| of d_n - d_p
-REFINE_CAP = 8              # near ties refined per call (expected ~1.5 per 256 random-init triplets)
+REFINE_BAND = 1.25e-3       # 2x the largest observed |error| of d_n - d_p (6 sigma)
+REFINE_CAP = 4              # near ties refined per call (expected ~1 per 256 random-init triplets; P(>4) = 0.3 %)
 
 
 class TripletSelection:
     """Result of `select_triplets`.  Everything stays on the device; reading `.indices` / `.n_selected` /
-    `.n_correct` is what synchronises (the reference branches on the count, train_triplet.py:263)."""
+    `.n_correct` is what synchronises (the reference branches on the count, train_triplet.py:263).
 
-    def __init__(self, idx_full, count, d_p, d_n, mean_diff, loss=None, amb_count=None, amb_cap=0):
+    When the fp16 forward's near ties were refined, the refinement ran on a side stream: every accessor first
+    makes the CURRENT stream wait for it (no host synchronisation), so results are ordered like any other tensor."""
+
+    def __init__(self, idx_full, count, d_p, d_n, mean_diff, loss=None, amb_count=None, amb_cap=0, ready=None):
         self._idx_full = idx_full    # int64 [N]; the first `count` entries are valid, ascending
-        self.count = count           # int32 [1] on the device
-        self.d_p = d_p               # [N]  (train_triplet.py:251)
-        self.d_n = d_n               # [N]  (train_triplet.py:252)
-        self.mean_diff = mean_diff   # mean(d_n - d_p), 1-element device tensor (train_triplet.py:259-260)
-        self.loss = loss             # triplet loss on the same distances (train_triplet.py:275), 1-element tensor
-        self.amb_count = amb_count   # near ties found (int32 [1]) when the fp16 forward was refined, else None
+        self._count = count          # int32 [1] on the device
+        self._d_p = d_p              # [N]  (train_triplet.py:251)
+        self._d_n = d_n              # [N]  (train_triplet.py:252)
+        self._mean_diff = mean_diff  # mean(d_n - d_p), 1-element device tensor (train_triplet.py:259-260)
+        self._loss = loss            # triplet loss on the same distances (train_triplet.py:275), 1-element tensor
+        self._amb_count = amb_count  # near ties found (int32 [1]) when the fp16 forward was refined, else None
         self.amb_cap = amb_cap
+        self._ready = ready          # event on the refinement stream, or None
+
+    def wait(self):
+        """Order the current stream after the refinement (idempotent per stream; free when nothing was refined)."""
+        if self._ready is not None:
+            cur = torch.cuda.current_stream(self._idx_full.device)
+            cur.wait_event(self._ready)
+            for t in (self._idx_full, self._count, self._d_p, self._d_n, self._mean_diff, self._loss):
+                if t is not None:
+                    t.record_stream(cur)        # allocated on the side stream, consumed on this one
+        return self
+
+    count = property(lambda self: self.wait()._count)
+    d_p = property(lambda self: self.wait()._d_p)
+    d_n = property(lambda self: self.wait()._d_n)
+    mean_diff = property(lambda self: self.wait()._mean_diff)
+    loss = property(lambda self: self.wait()._loss)
+    amb_count = property(lambda self: self.wait()._amb_count)
 
     @property
     def n_selected(self) -> int:
@@ -42,7 +63,8 @@ class TripletSelection:
     @property
     def indices(self) -> torch.Tensor:
         """int64 [n_selected], ascending -- `np.where(all == 1)[0]` of train_triplet.py:262."""
-        return self._idx_full[:self.n_selected]
+        n = self.n_selected
+        return self._idx_full[:n]
 
     @property
     def n_correct(self) -> int:
@@ -51,15 +73,29 @@ class TripletSelection:
 
     @property
     def refine_overflow(self) -> bool:
-        """True if more near ties were found than `REFINE_CAP` slots could re-embed (synchronises)."""
-        return self.amb_count is not None and int(self.amb_count.item()) > self.amb_cap
+        """True if more near ties were found than the refinement had slots to re-embed (synchronises)."""
+        return self._amb_count is not None and int(self.amb_count.item()) > self.amb_cap
+
+
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tensor, margin: float,
-                    model=None, inputs=None, band: float = REFINE_BAND, cap: int = REFINE_CAP) -> TripletSelection:
+                    model=None, inputs=None, band: float = REFINE_BAND, cap: int = REFINE_CAP,
+                    side_stream: bool = True) -> TripletSelection:
     """train_triplet.py:251-262.  With `model` (a DeepSpeakerModel in eval mode, precision "f16") and `inputs`
     (the three input batches the embeddings came from), near ties are re-embedded at f32-class precision first,
-    which makes the selection the reference's (see REFINE_BAND); no host synchronisation either way."""
+    which makes the selection the reference's (see REFINE_BAND).  No host synchronisation either way.  The
+    re-embedding is a small-batch forward (latency-bound: a few workgroups walking the whole contraction), so by
+    default it runs on a side stream next to whatever the caller enqueues next; `TripletSelection` orders its
+    consumers after it."""
     _require_cuda(out_a, "select_triplets")
     eng = get_engine()
     a, p, n = (t.detach().contiguous() for t in (out_a, out_p, out_n))
@@ -70,22 +106,35 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     if inputs is None or len(inputs) != 3:
         raise ValueError("refinement needs inputs=(data_a, data_p, data_n), the batches behind the embeddings")
     t = eng.triplet_tail(a, p, n, margin, band=band, amb_cap=cap)
-    rows = inputs[0][0].numel()
-    xr = torch.empty((3 * cap,) + tuple(inputs[0].shape[1:]), dtype=torch.float32, device=a.device)
-    st = eng._stream(a)
-    for k, x in enumerate(inputs):
-        _require_cuda(x, "select_triplets(inputs=...)")
-        x = x.contiguous()
-        eng.lib.call("ds_gather_rows_f32", eng._p(x), eng._p(t["amb_idx"]), eng._p(xr[k * cap:(k + 1) * cap]), cap, rows, st)
-    e_ref = model.embed_reference(xr)
-    d_p, d_n = t["d_p"].clone(), t["d_n"].clone()       # the memoised fp16 distances stay what they are
-    eng.lib.call("ds_refine_distances_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
-                 eng._p(d_p), eng._p(d_n), a.shape[1], st)
-    idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
-    mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])
-    eng.lib.call("ds_triplet_scan_f32", eng._p(d_p), eng._p(d_n), float(margin), eng._p(loss), eng._p(idx), eng._p(count),
-                 eng._p(mean_diff), d_p.numel(), st)
-    return TripletSelection(idx, count, d_p, d_n, mean_diff, loss, t["amb_count"], cap)
+    main = torch.cuda.current_stream(a.device)
+    side = _side_stream(a.device) if side_stream else main
+    if side_stream:
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
+        if side_stream:
+            for v in t.values():                    # the memoised main-stream buffers the side stream reads
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(side)
+        rows = inputs[0][0].numel()
+        xr = torch.empty((3 * cap,) + tuple(inputs[0].shape[1:]), dtype=torch.float32, device=a.device)
+        st = eng._stream(a)
+        for k, x in enumerate(inputs):
+            _require_cuda(x, "select_triplets(inputs=...)")
+            x = x.contiguous()
+            if side_stream:
+                x.record_stream(side)               # keep the batch's memory until the side stream has read it
+            eng.lib.call("ds_gather_rows_f32", eng._p(x), eng._p(t["amb_idx"]), eng._p(xr[k * cap:(k + 1) * cap]), cap,
+                         rows, st)
+        e_ref = model.embed_reference(xr)
+        d_p, d_n = t["d_p"].clone(), t["d_n"].clone()       # the memoised fp16 distances stay what they are
+        eng.lib.call("ds_refine_distances_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
+                     eng._p(d_p), eng._p(d_n), a.shape[1], st)
+        idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
+        mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])
+        eng.lib.call("ds_triplet_scan_f32", eng._p(d_p), eng._p(d_n), float(margin), eng._p(loss), eng._p(idx),
+                     eng._p(count), eng._p(mean_diff), d_p.numel(), st)
+        ready = side.record_event() if side_stream else None
+    return TripletSelection(idx, count, d_p, d_n, mean_diff, loss, t["amb_count"], cap, ready)
 
 
 def mine_semihard_negatives(anchors: torch.Tensor, positives: torch.Tensor, anchor_labels: torch.Tensor,

@@ -186,6 +186,40 @@ def main():
     path = os.path.join(HERE, "reference_outputs.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+    make_cfg1()
+
+
+def cfg1_inputs():
+    """BASELINE.json configs[1], exactly as bench.py builds it on rank 0: parameters make_state_dict(seed=0,
+    num_classes=1211), 256 triplets = anchors | positives | negatives in one [768,1,160,64] randn batch of the
+    torch CPU generator seeded 1234."""
+    sd = O.make_state_dict(seed=0, num_classes=1211)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    return sd, torch.randn(768, 1, 160, 64, generator=g)
+
+
+def make_cfg1():
+    """The unmodified reference at the bench configuration: all 768 embeddings, both distance vectors, the
+    triplet loss and the filter's selection (train_triplet.py:251-262 restated on the reference's own distances)."""
+    sd, x = cfg1_inputs()
+    m = build_ref(sd, 1211).eval()
+    with torch.no_grad():
+        e = torch.cat([m(x[i:i + 64]) for i in range(0, 768, 64)])
+        a, p, n = e[:256], e[256:512], e[512:]
+        pd = ref.PairwiseDistance(2)
+        d_p, d_n = pd.forward(a, p), pd.forward(a, n)
+        loss = ref.TripletMarginLoss(0.1).forward(a, p, n)
+    allm = (d_n - d_p < 0.1).numpy().flatten()
+    out = {"cfg1_emb": e.numpy(), "cfg1_d_p": d_p.numpy(), "cfg1_d_n": d_n.numpy(), "cfg1_loss": loss.numpy(),
+           "cfg1_selected": np.where(allm == 1)[0].astype(np.int64),
+           "cfg1_mean_diff": np.array(np.mean((d_n - d_p).numpy().flatten())),
+           "cfg1_input_digest": np.array([float(x.double().sum()), float(x.double().abs().sum()), float(x[767, 0, 159, 63])])}
+    gap = np.abs(d_n.numpy() - d_p.numpy() - 0.1)
+    print("cfg1: selected", len(out["cfg1_selected"]), "of 256; min |d_n - d_p - margin| =", gap.min(),
+          "next", np.sort(gap)[1:4])
+    path = os.path.join(HERE, "reference_cfg1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,153 @@
+"""BASELINE.json configs[1] on a real MI355X against outputs of the UNMODIFIED reference at that configuration
+(tests/golden/reference_cfg1.npz, made by tests/golden/make_golden.py): all 768 embeddings, the triplet loss and
+the filter's selection over the 256 triplets, for every arithmetic the eval forward offers.  Contract
+(north_star): embeddings and loss within 1e-3 relative, identical selection."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import deepspeaker_oracle as O
+from conftest import ROOT, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT = 1e-3
+# measured bars per arithmetic (embeddings, max |diff| / max |ref| over all 768 rows)
+EMB_BAR = {"f32": 2e-5, "bf16x3": 3e-5, "f16": CONTRACT}
+
+
+@pytest.fixture(scope="module")
+def cfg1():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_cfg1.npz"))
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(768, 1, 160, 64, generator=gen)
+    dig = g["cfg1_input_digest"]
+    # the inputs are regenerated, not stored: make sure this torch build draws the same stream
+    assert abs(float(x.double().sum()) - dig[0]) < 1e-6 * max(1.0, abs(dig[0])) and float(x[767, 0, 159, 63]) == dig[2]
+    return g, O.make_state_dict(seed=0, num_classes=1211), x.cuda()
+
+
+def build(sd, precision):
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel
+    m = DeepSpeakerModel(512, 1211, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16"])
+def test_bench_size_vs_reference_golden(cfg1, precision):
+    from deepspeaker_pytorch_amd.mining import select_triplets
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss
+    g, sd, x = cfg1
+    m = build(sd, precision)
+    with torch.no_grad():
+        e = m(x).clone()
+        a, p, n = e[:256], e[256:512], e[512:]
+        loss = TripletMarginLoss(0.1).forward(a, p, n)
+        sel = select_triplets(a, p, n, 0.1, model=m, inputs=(x[:256], x[256:512], x[512:]))
+    ref = g["cfg1_emb"]
+    err = rel_err(e.cpu().numpy(), ref)
+    row = float(((e.cpu().double() - torch.from_numpy(ref).double()).norm(dim=1) / torch.from_numpy(ref).double().norm(dim=1)).max())
+    gap_ref = g["cfg1_d_n"] - g["cfg1_d_p"] - np.float32(0.1)
+    gap = sel.d_n.cpu().numpy() - sel.d_p.cpu().numpy() - np.float32(0.1)
+    loss_rel = abs(float(loss) - float(g["cfg1_loss"])) / float(g["cfg1_loss"])
+    sel_loss_rel = abs(float(sel.loss) - float(g["cfg1_loss"])) / float(g["cfg1_loss"])
+    print(f"\\n[{precision}] embeddings: max|d|/max {err:.3e}, worst row rel-L2 {row:.3e}; loss rel {loss_rel:.3e} "
+          f"(after refinement {sel_loss_rel:.3e}); reference min |d_n-d_p-margin| {np.abs(gap_ref).min():.3e}; "
+          f"max |gap error| {np.abs(gap - gap_ref).max():.3e}; near ties refined: "
+          f"{int(sel.amb_count) if sel.amb_count is not None else 'n/a'}")
+    assert err < EMB_BAR[precision] and row < EMB_BAR[precision]
+    assert loss_rel < CONTRACT and sel_loss_rel < CONTRACT
+    np.testing.assert_array_equal(sel.indices.cpu().numpy(), g["cfg1_selected"])        # identical selection
+    assert abs(float(sel.mean_diff) - float(g["cfg1_mean_diff"])) < 1e-3 * abs(float(g["cfg1_mean_diff"])) + 1e-5
+    if precision == "f16":
+        assert not sel.refine_overflow
+        # the refinement band must cover what fp16 does to the decision variable
+        d_p16, d_n16 = (select_triplets(a, p, n, 0.1).d_p.cpu().numpy(), select_triplets(a, p, n, 0.1).d_n.cpu().numpy())
+        from deepspeaker_pytorch_amd.mining import REFINE_BAND
+        assert np.abs(d_n16 - d_p16 - np.float32(0.1) - gap_ref).max() < 0.75 * REFINE_BAND
+
+
+def test_f16_refinement_decides_planted_near_ties(cfg1):
+    """Force near ties: choose the margin so that triplets sit exactly on the fp16 path's decision boundary; the
+    refined selection must be the selection of the f32-class distances for every triplet inside the band."""
+    from deepspeaker_pytorch_amd.mining import REFINE_BAND, select_triplets
+    g, sd, x = cfg1
+    m16, m3 = build(sd, "f16"), build(sd, "bf16x3")
+    with torch.no_grad():
+        e16, e3 = m16(x).clone(), m3(x).clone()
+    d3 = select_triplets(e3[:256], e3[256:512], e3[512:], 0.1)
+    diff3 = (d3.d_n - d3.d_p).cpu().numpy()
+    order = np.argsort(diff3)
+    flips_seen = 0
+    for k in (40, 100, 128, 200):                   # a margin half-way between two neighbouring triplets
+        margin = float((diff3[order[k]] + diff3[order[k + 1]]) / 2)
+        with torch.no_grad():
+            plain = select_triplets(e16[:256], e16[256:512], e16[512:], margin)
+            fine = select_triplets(e16[:256], e16[256:512], e16[512:], margin, model=m16,
+                                   inputs=(x[:256], x[256:512], x[512:]), cap=32)
+        want = np.where(diff3 < np.float32(margin))[0]
+        got = fine.indices.cpu().numpy()
+        assert not fine.refine_overflow
+        np.testing.assert_array_equal(got, want)
+        flips_seen += int(len(plain.indices) != len(want) or (plain.indices.cpu().numpy() != want).any())
+        assert int(fine.amb_count) >= 2              # the two triplets the margin was placed between
+    print("\\nunrefined fp16 selections that differed from the f32-class one:", flips_seen, "of 4")
+
+
+def test_f16_forward_properties(cfg1):
+    g, sd, x = cfg1
+    m = build(sd, "f16")
+    with torch.no_grad():
+        e1, e2 = m(x).clone(), m(x).clone()
+        part = m(x[256:512].contiguous()).clone()
+        one = m(x[5:6].contiguous()).clone()
+    assert torch.isfinite(e1).all() and torch.equal(e1, e2)                  # bitwise deterministic
+    assert float((e1.double().norm(dim=1) - 10).abs().max()) < 1e-4
+    assert torch.equal(e1[256:512], part) and torch.equal(e1[5:6], one)     # independent of batch composition
+
+
+F16_CASES = [
+    # (B, Cin, Cout, H, W, KS, stride)
+    (2, 64, 64, 11, 32, 3, 1), (3, 32, 128, 20, 8, 3, 1), (5, 96, 128, 10, 4, 3, 1), (2, 64, 128, 21, 16, 5, 2),
+    (3, 32, 256, 9, 8, 5, 2), (1, 64, 64, 3, 5, 3, 1), (1, 64, 128, 21, 64, 5, 2), (1, 32, 64, 12, 100, 3, 1),
+    (48, 64, 64, 80, 32, 3, 1), (48, 64, 128, 80, 32, 5, 2), (32, 128, 128, 40, 16, 3, 1), (32, 128, 256, 40, 16, 5, 2),
+    (32, 256, 256, 20, 8, 3, 1), (33, 256, 512, 20, 8, 5, 2), (67, 512, 512, 10, 4, 3, 1), (3, 512, 512, 50, 4, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("single_buffer", [False, True])
+def test_conv_f16_kernel(case, single_buffer):
+    """ds_conv_fwd_f16 against a float64 convolution of the same fp16-rounded operands: fp16 products are exact
+    in f32, so only the f32 accumulation order separates the two (1e-5 of the largest output)."""
+    from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_SINGLE_BUFFER, DS_EPI_AFFINE, DS_EPI_CLIP,
+                                                 DS_EPI_OUT_F32, DS_EPI_RESIDUAL)
+    from deepspeaker_pytorch_amd.model import get_engine
+    eng = get_engine()
+    b, ci, co, h, w, k, s = case
+    gen = torch.Generator(device="cpu").manual_seed(sum(case))
+    x = torch.randn(b, h, w, ci, generator=gen).abs().half().cuda()
+    wt = (torch.randn(co, ci, k, k, generator=gen) / (ci * k * k) ** 0.5).half().float().cuda()
+    wp = eng._pack_f16(wt, k)
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    hint = DS_CONV_HINT_SINGLE_BUFFER if single_buffer else 0
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    y = torch.full((b, ho, wo, co), float("nan"), device="cuda")
+    eng.lib.call("ds_conv_fwd_f16", ctypes.byref(shp), eng._p(x), eng._p(wp), None, None, None, eng._p(y),
+                 DS_EPI_OUT_F32 | hint, eng._stream(x))
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, s, k // 2).permute(0, 2, 3, 1)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    # full epilogue, fp16 store
+    scale = (torch.rand(co, generator=gen) + 0.5).cuda()
+    shift = torch.randn(co, generator=gen).cuda()
+    res = (torch.randn(b, ho, wo, co, generator=gen).abs() * 6).half().cuda()
+    y16 = torch.full((b, ho, wo, co), float("nan"), dtype=torch.float16, device="cuda")
+    eng.lib.call("ds_conv_fwd_f16", ctypes.byref(shp), eng._p(x), eng._p(wp), eng._p(scale), eng._p(shift), eng._p(res),
+                 eng._p(y16), DS_EPI_AFFINE | DS_EPI_RESIDUAL | DS_EPI_CLIP | hint, eng._stream(x))
+    want = (ref * scale.double() + shift.double() + res.double()).clamp(0.0, 20.0)
+    assert float((y16.double() - want).abs().max()) <= 20 * 2.0 ** -11 + 1e-4
+    assert float(y16.min()) >= 0.0 and float(y16.max()) <= 20.0

@@ -83,3 +83,14 @@ def test_product_package_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "deepspeaker_oracle" not in txt and "torch_restatement" not in txt, f
                 assert "/root/reference" not in txt, f
+
+
+def test_synthetic_state_dict_is_the_oracle_stream():
+    """bench.py takes its parameters from the package helper; the bench-size golden fixture was made from the
+    oracle's generator: the two must be the same arrays."""
+    import deepspeaker_oracle as O
+    from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
+    for seed, ncls, ns in ((0, 1211, 4), (5, 7, 2)):
+        a, b = O.make_state_dict(seed=seed, num_classes=ncls, n_stages=ns), synthetic_state_dict(seed, ncls, ns)
+        assert set(a) == set(b)
+        assert all(np.array_equal(a[k], b[k]) for k in a)

@@ -33,7 +33,7 @@ for prec in ("f32", "bf16x3", "f16"):
             m(x)
         torch.cuda.synchronize()
         by = {}
-        for label, fl, e0, e1 in eng.profile:
+        for label, fl, e0, e1, _ in eng.profile:
             d = by.setdefault(label, [0.0, 0.0])
             d[0] += fl
             d[1] += e0.elapsed_time(e1)
