@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) cast_f16_to_f32_kernel(const _Float16 *x,
 // LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for a candidate row pitch: the two 16-lane
 // service groups of lanes 0..31 each hold 16 consecutive pixels of the M tile (`lpix` in the kernel).
 // Bank slot of a record = (record * PSH / 16) mod 16.
-static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in, int pitch) {
+static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in, int pitch, int PSH) {
     const int pix_per_seg = RT * Wc, seg_pix = rows_in * pitch;
     double total = 0.0;
     int n = 0;
@@ -79,17 +79,17 @@ constexpr size_t kLdsTotal = 160 * 1024;     // per CU
 
 static size_t epi_bytes(const TileCfgH &cf) {
     const int waves = cf.NTHR / 64, nsub = cf.NTILE / (waves / cf.WM) / 32;
-    return (size_t)waves * 32 * (nsub * 32 + 4) * 4;
+    return (size_t)2 * waves * 32 * (nsub * 32 + 4) * 4;
 }
 
 // One wave per SIMD is the design point (the register tile takes most of the 512 VGPRs): a CU holds
 // 256 / NTHR workgroups, each with an equal share of the LDS.
-static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true) {
+static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, bool force_c16 = false) {
     DS_REQUIRE(s != nullptr, DS_ERR_NULL);
     DS_REQUIRE(s->B > 0 && s->H > 0 && s->W > 0 && s->Cin > 0 && s->Cout > 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(s->KS == 3 || s->KS == 5, DS_ERR_UNSUPPORTED);
     DS_REQUIRE(s->stride == 1 || s->stride == 2, DS_ERR_UNSUPPORTED);
-    DS_REQUIRE(s->Cin % CKH == 0 && s->Cout % 64 == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(s->Cin % 32 == 0 && s->Cout % 64 == 0, DS_ERR_BAD_SHAPE);
     const int pad = s->KS / 2;
     const int Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
     const int Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
@@ -99,13 +99,19 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true) {
     DS_REQUIRE((long long)s->B * Ho * Wo * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);   // 32-bit byte offsets
     const int IS = s->stride;
     double best = -1.0;
-    int bc = -1, brt = 0, bni = 0, bdb = 0;
+    int bc = -1, brt = 0, bni = 0, bdb = 0, bck = 32;
     for (int c = 0; c < kNumCfgH; ++c) {
         const TileCfgH &cf = kCfgH[c];
         if (s->Cout % cf.NTILE) continue;
         const int wg_per_cu = 256 / cf.NTHR;
         const size_t lds_cap = kLdsTotal / wg_per_cu - 64;
-        for (int db = allow_db ? 1 : 0; db >= 0; --db) {
+        // (two tiles of 32 channels) > (two tiles of 16 channels: 5x5 stride-2 layers, whose input tile is 4x the
+        // output tile) > (one tile of 32 channels: two barriers and exposed LDS writes per chunk)
+        for (int mode = allow_db ? 0 : 2; mode < 3; ++mode) {
+            const int db = mode < 2, ck = mode == 1 ? 16 : 32;
+            if (mode == 1 && s->KS != 5) continue;
+            if (force_c16 && s->KS == 5 && mode != 1) continue;
+            const int PSH = ds_f16_record_bytes(ck);
             const long long item_cap = (db ? 16 : 32) * cf.NTHR;
             for (int rt = 1; rt <= Ho; ++rt) {
                 if ((long long)rt * Wo > cf.MT) break;
@@ -118,7 +124,7 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true) {
                     const size_t tp = (size_t)n * rows_in * (cols_in + 4);
                     return std::max(tp * PSH * (db ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)n * 8;
                 };
-                auto items_of = [&](int n) { return (long long)n * std::min(rows_in, s->H) * s->W * (CKH / 8); };
+                auto items_of = [&](int n) { return (long long)n * std::min(rows_in, s->H) * s->W * (ck / 8); };
                 while (ni > 1 && (lds_of(ni) > lds_cap || items_of(ni) > item_cap)) --ni;
                 if (lds_of(ni) > lds_cap || items_of(ni) > item_cap) continue;
                 const long long n_mt = ds_ceil_div_ll(n_segs, ni);
@@ -126,10 +132,11 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true) {
                 const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * wg_per_cu;
                 if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
                 else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
-                if (!db) eff *= (s->KS == 3 ? 0.90 : 0.96);      // two barriers and exposed LDS writes per chunk
+                if (mode == 1) eff *= 0.97;
+                if (mode == 2) eff *= (s->KS == 3 ? 0.90 : 0.85);
                 static const int pref[kNumCfgH] = {6, 4, 3, 5, 2, 1, 0};
                 eff += 1e-9 * rt + 1e-6 * pref[c];
-                if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; bdb = db; }
+                if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; bdb = db; bck = ck; }
             }
         }
     }
@@ -148,7 +155,7 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true) {
     int best_pitch = k.cols_in;
     double best_cost = 1e30;
     for (int pt = k.cols_in; pt <= k.cols_in + 4; ++pt) {
-        const double c = frag_read_cost(cf.MT, bni, brt, Wo, IS, k.rows_in, pt);
+        const double c = frag_read_cost(cf.MT, bni, brt, Wo, IS, k.rows_in, pt, ds_f16_record_bytes(bck));
         if (c < best_cost - 1e-9) { best_cost = c; best_pitch = pt; }
     }
     k.pitch = best_pitch;
@@ -156,11 +163,13 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true) {
     k.n_ntiles = s->Cout / cf.NTILE;
     pl.cfg = bc;
     pl.db = bdb;
+    pl.ck = bck;
+    const int PSH = ds_f16_record_bytes(bck);
     pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
     pl.grid = pl.n_mtiles * k.n_ntiles;
     const size_t tp = (size_t)k.NI * k.seg_pix;
     pl.lds_bytes = std::max(tp * PSH * (bdb ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)k.NI * 8 + 16;
-    pl.nit = ds_ceil_div(k.NI * std::min(k.rows_in, s->H) * s->W * (CKH / 8), cf.NTHR);
+    pl.nit = ds_ceil_div(k.NI * std::min(k.rows_in, s->H) * s->W * (bck / 8), cf.NTHR);
     return DS_OK;
 }
 
@@ -199,9 +208,14 @@ extern "C" int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8) {
     if (rc != DS_OK) return rc;
     const TileCfgH &cf = kCfgH[pl.cfg];
     out8[0] = cf.MT; out8[1] = cf.NTILE; out8[2] = pl.k.RT; out8[3] = pl.k.NI;
-    out8[4] = pl.grid; out8[5] = (int)pl.lds_bytes; out8[6] = cf.NTHR; out8[7] = pl.db * 1000 + pl.nit;
+    out8[4] = pl.grid; out8[5] = (int)pl.lds_bytes; out8[6] = cf.NTHR; out8[7] = pl.db * 1000 + (pl.ck == 16 ? 100 : 0) + pl.nit;
     return DS_OK;
 }
+
+#ifdef DS_F16_PROBE
+static long long *g_f16_probe = nullptr;
+extern "C" void ds_f16_set_probe(long long *buf) { g_f16_probe = buf; }
+#endif
 
 extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
                                const float *shift, const void *residual_f16, void *y, int flags, void *stream) {
@@ -212,7 +226,7 @@ extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const 
     DS_REQUIRE(DS_ALIGNED16(x_f16) && DS_ALIGNED16(w_f16) && DS_ALIGNED16(y) && DS_ALIGNED16(residual_f16) &&
                    DS_ALIGNED16(scale) && DS_ALIGNED16(shift), DS_ERR_ALIGNMENT);
     PlanH pl;
-    int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER));
+    int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER), (flags & DS_CONV_HINT_CHUNK16) != 0);
     if (rc != DS_OK) return rc;
     ConvKH &k = pl.k;
     k.x = (const _Float16 *)x_f16; k.w = (const _Float16 *)w_f16; k.y = y;
@@ -221,7 +235,11 @@ extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const 
     const long long n_out = (long long)s->B * k.Ho * k.Wo * s->Cout;
     k.y_bytes = (unsigned)(n_out * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
     k.res_bytes = (unsigned)(n_out * 2);
+#ifdef DS_F16_PROBE
+    k.probe = g_f16_probe;
+#endif
     if (s->KS == 3) { if (pl.db) ds_f16_launch_k3db(pl, stream); else ds_f16_launch_k3sb(pl, stream); }
+    else if (pl.ck == 16) ds_f16_launch_k5c16(pl, stream);
     else            { if (pl.db) ds_f16_launch_k5db(pl, stream); else ds_f16_launch_k5sb(pl, stream); }
     return ds_last_launch_error();
 }

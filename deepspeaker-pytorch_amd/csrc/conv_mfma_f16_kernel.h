@@ -17,9 +17,10 @@
 #include <type_traits>
 #include "ds_common.h"
 
-constexpr int CKH = 32;             // input channels per chunk = two k-steps of the 32x32x16 MFMA
-constexpr int PSH = 80;             // bytes per staged pixel record: 32 halfs + 16 B pad (16 consecutive
-                                    // records walk all 64 banks with one ds_read_b128 each)
+// CK input channels per chunk = CK/16 k-steps of the 32x32x16 MFMA per tap (32, or 16 where two 32-channel tiles
+// do not fit the LDS); a staged pixel record is CK halfs + 16 B pad = 80 / 48 bytes: 16 consecutive records walk
+// all 64 banks with one ds_read_b128 each.
+constexpr int ds_f16_record_bytes(int ck) { return ck * 2 + 16; }
 
 struct ConvKH {
     const _Float16 *x;              // [B, H, W, Cin] fp16 channels-last
@@ -37,10 +38,19 @@ struct ConvKH {
     int n_ntiles;
     int flags;
     unsigned y_bytes, res_bytes;    // sizes for the buffer descriptors
+#ifdef DS_F16_PROBE                 // tools/f16_phase_probe.py builds: s_memtime stamps of the phases of each workgroup
+    long long *probe;
+#endif
 };
 
+#ifdef DS_F16_PROBE
+#define DS_F16_STAMP(i) do { if (p.probe && threadIdx.x == 0) p.probe[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DS_F16_STAMP(i) ((void)0)
+#endif
+
 struct PlanH {
-    int cfg, grid, n_mtiles, nit, db;
+    int cfg, grid, n_mtiles, nit, db, ck;
     size_t lds_bytes;
     ConvKH k;
 };
@@ -50,26 +60,35 @@ void ds_f16_launch_k3db(const PlanH &pl, void *stream);
 void ds_f16_launch_k3sb(const PlanH &pl, void *stream);
 void ds_f16_launch_k5db(const PlanH &pl, void *stream);
 void ds_f16_launch_k5sb(const PlanH &pl, void *stream);
+void ds_f16_launch_k5c16(const PlanH &pl, void *stream);    // 16-channel chunks, double-buffered
 
 #ifdef DS_F16_KERNEL_TU
 namespace {
 
 // NIT: 16-byte staging items per thread and chunk (compile time: all loads of a chunk are in flight together).
 // DB:  two pixel-tile buffers in LDS; requires the register prefetch (NIT <= 16).
-template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT, bool DB>
+template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT, bool DB, int CKH = 32>
 __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f16_kernel(const ConvKH p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = MSUB * WM * 32;
     constexpr int NTILE = NSUB * WN * 32;
     constexpr int NT = KS * KS;
-    constexpr int NU = 2 * NT;                      // (tap, k-step) units per chunk
-    constexpr int RU = (KS == 3) ? 9 : 10;          // filter ring, in units; NU % RU == 0
+    constexpr int KPT = CKH / 16;                   // k-steps per tap
+    constexpr int IPP = CKH / 8;                    // 16-byte staging items per pixel
+    constexpr int PSH = ds_f16_record_bytes(CKH);
+    constexpr int NU = KPT * NT;                    // (tap, k-step) units per chunk
+#ifndef DS_F16_RING_K3
+#define DS_F16_RING_K3 6
+#define DS_F16_RING_K5 5
+#endif
+    constexpr int RU = (KS == 3) ? (KPT == 2 ? DS_F16_RING_K3 : 9) : DS_F16_RING_K5;   // filter ring, in units; NU % RU == 0
     constexpr int NMF = MSUB * NSUB;                // MFMAs per unit
     constexpr bool PREF = DB || NIT <= 16;          // next chunk's pixels ride in registers through the taps
     static_assert(NU % RU == 0, "ring slots must be chunk-invariant");
     static_assert(!DB || NIT <= 16, "double buffering needs the register prefetch");
 
     char *lds = (char *)ds_dynamic_lds();
+    DS_F16_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -78,8 +97,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const int seg0 = tile_m * p.NI;
     const int pix_per_seg = p.RT * p.Wo;
     const int tile_pix = p.NI * p.seg_pix;
-    // the pixel-tile region doubles as the epilogue's transposition buffers (32 x (NSUB*32+4) floats per wave)
-    constexpr int EPI_BYTES = WM * WN * 32 * (NSUB * 32 + 4) * 4;
+    // the pixel-tile region doubles as the epilogue's transposition buffers (two of 32 x (NSUB*32+4) floats per wave)
+    constexpr int EPI_BYTES = 2 * WM * WN * 32 * (NSUB * 32 + 4) * 4;
     const int tile_bytes = tile_pix * PSH;
     const int tiles_bytes = (DB ? 2 : 1) * tile_bytes;
     const int stage_bytes = tiles_bytes > EPI_BYTES ? tiles_bytes : EPI_BYTES;
@@ -93,9 +112,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);      // in halfs
     const size_t w_kc_stride = (size_t)NT * p.Cout * 16;                // one 16-channel slab: [tap][Cout][16]
     const size_t w_tap_stride = (size_t)p.Cout * 16;
-    // unit u of a chunk = (tap u >> 1, k-step u & 1): filter slab 2*chunk + (u & 1), tap u >> 1
+    // unit u of a chunk = (tap u / KPT, k-step u % KPT): filter slab KPT*chunk + u % KPT, tap u / KPT
     auto w_unit = [&](int chunk, int u) {
-        return p.w + lane_w + (size_t)(2 * chunk + (u & 1)) * w_kc_stride + (size_t)(u >> 1) * w_tap_stride;
+        return p.w + lane_w + (size_t)(KPT * chunk + (u % KPT)) * w_kc_stride + (size_t)(u / KPT) * w_tap_stride;
     };
 
     f16x8 bq[RU][NSUB];
@@ -134,10 +153,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     int g_off[NIT], l_off[NIT];
     __syncthreads();                            // seg_lo / seg_cnt are complete
     {
-        const int q = tid & 3;
-        const int dvr = ds_div_small(NTHR / 4, p.W, rcp_w), dc = NTHR / 4 - dvr * p.W;
-        int vr = ds_div_small(tid >> 2, p.W, rcp_w);
-        int c = (tid >> 2) - vr * p.W;
+        const int q = tid % IPP;
+        const int dvr = ds_div_small(NTHR / IPP, p.W, rcp_w), dc = NTHR / IPP - dvr * p.W;
+        int vr = ds_div_small(tid / IPP, p.W, rcp_w);
+        int c = (tid / IPP) - vr * p.W;
         int seg = -1, row0 = 0, cnt = 0, lo = 0, img_row = 0;
         auto next_seg = [&]() {
             row0 += cnt;
@@ -151,26 +170,56 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                 img_row = b * p.H + p.IS * (gseg - b * p.segs_per_img) * p.RT + p.dh_min;   // of tile row 0
             }
         };
-        next_seg();
+        // Tiles whose segments all have the same in-image row window -- a single segment, or one whole image per
+        // segment (every bench layer) -- locate an item with one reciprocal division; only mixed windows walk the table.
+        const bool uniform = p.NI == 1 || p.segs_per_img == 1;
+        if (uniform) {
+            const int h0 = p.IS * (seg0 - ds_div_small(seg0, p.segs_per_img, rcp_spi) * p.segs_per_img) * p.RT + p.dh_min;
+            const int lo_u = h0 < 0 ? -h0 : 0;
+            const int hi_u = p.H - h0 < p.rows_in ? p.H - h0 : p.rows_in;
+            const int cnt_u = hi_u > lo_u ? hi_u - lo_u : 1;
+            const float rcp_cnt = 1.0f / (float)cnt_u;
+            const int b0 = ds_div_small(seg0, p.segs_per_img, rcp_spi);
+            const int img_row0 = b0 * p.H + h0;                                      // tile row 0 of segment 0
+            const int live_segs = p.n_segs - seg0 < p.NI ? p.n_segs - seg0 : p.NI;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            while (seg < p.NI && vr >= row0 + cnt) next_seg();
-            g_off[it] = 0;
-            l_off[it] = 64;
-            if (seg < p.NI) {
-                const int rr = lo + vr - row0;
-                // stride-2 layers keep even tile columns in slots [0, half) and odd ones in [half, cols_in),
-                // so that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
+            for (int it = 0; it < NIT; ++it) {
+                const int sg = ds_div_small(vr, cnt_u, rcp_cnt);
+                const int rr = lo_u + vr - sg * cnt_u;
                 const int cc = c - p.dw_min;
                 const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
-                g_off[it] = ((img_row + rr) * p.W + c) * p.Cin + q * 8;
-                l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16;
+                const bool ok = sg < live_segs;
+                g_off[it] = ok ? ((img_row0 + sg * p.H + rr) * p.W + c) * p.Cin + q * 8 : 0;
+                l_off[it] = ok ? (sg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16 : CKH * 2;
+                c += dc;
+                vr += dvr;
+                if (c >= p.W) {
+                    c -= p.W;
+                    ++vr;
+                }
             }
-            c += dc;
-            vr += dvr;
-            if (c >= p.W) {
-                c -= p.W;
-                ++vr;
+        } else {
+            next_seg();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                while (seg < p.NI && vr >= row0 + cnt) next_seg();
+                g_off[it] = 0;
+                l_off[it] = CKH * 2;                // the pad bytes of pixel record 0
+                if (seg < p.NI) {
+                    const int rr = lo + vr - row0;
+                    // stride-2 layers keep even tile columns in slots [0, half) and odd ones in [half, cols_in),
+                    // so that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
+                    const int cc = c - p.dw_min;
+                    const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
+                    g_off[it] = ((img_row + rr) * p.W + c) * p.Cin + q * 8;
+                    l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16;
+                }
+                c += dc;
+                vr += dvr;
+                if (c >= p.W) {
+                    c -= p.W;
+                    ++vr;
+                }
             }
         }
     }
@@ -237,7 +286,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         for (int u = 0; u < NU; ++u) {
             const int cur = u & 1, slot = u % RU;
             const bool more = u + 1 < NU;
-            const char *nfrag = buf + tap_off((u + 1) >> 1) + 32 * ((u + 1) & 1);
+            const char *nfrag = buf + tap_off((u + 1) / KPT) + 32 * ((u + 1) % KPT);
             // the slot the previous unit consumed is refilled with the unit RU - 1 ahead of this one
             const int ur = u - 1 + RU;                          // may run into the next chunk
             const bool refill = !(LAST && ur >= NU);            // (unit 0 of chunk 0 reloads what the prologue loaded)
@@ -270,6 +319,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         }
     };
 
+    DS_F16_STAMP(1);
     if constexpr (DB) {
         __syncthreads();                        // the zero fill is complete
 #pragma unroll
@@ -311,8 +361,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     constexpr int PPI = 64 / LPP;               // pixel rows per instruction
     constexpr int NRI = 32 / PPI;               // instructions per sub-tile
     const int flags = p.flags;
+    DS_F16_STAMP(2);
     __syncthreads();                            // every wave is done reading the pixel tile
-    float *tb = (float *)lds + wave * (32 * TP);
+    DS_F16_STAMP(3);
+    float *tb = (float *)lds + wave * (2 * 32 * TP);
     const int my_c = (lane % LPP) * 8, my_p = lane / LPP;
     const int col = n_base + my_c;
     f32x4 sc[2] = {{1.0f, 1.0f, 1.0f, 1.0f}, {1.0f, 1.0f, 1.0f, 1.0f}};
@@ -326,6 +378,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     // Rows of a ragged tile get an out-of-range buffer offset (the store is dropped, the load returns
     // zeros) and a layer without residual reads "out of range" too: no branch around any memory instruction.
     const bool out32 = (flags & DS_EPI_OUT_F32) != 0;
+    const float clip_lo = (flags & DS_EPI_CLIP) ? 0.0f : -__builtin_inff();
+    const float clip_hi = (flags & DS_EPI_CLIP) ? 20.0f : __builtin_inff();
     const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
     const ds_buffer rbuf = ds_make_buffer((flags & DS_EPI_RESIDUAL) ? (const void *)p.res : (const void *)p.y,
                                           (flags & DS_EPI_RESIDUAL) ? p.res_bytes : 0u);
@@ -341,11 +395,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         for (int k = 0; k < NRI; ++k)
             resv[bsel][k] = ds_buffer_load_f32x4(rbuf, voff[bsel][k] != DS_BUFFER_OOB ? voff[bsel][k] * 2u : DS_BUFFER_OOB);
     };
-    fetch_rows(0, 0);
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) {
-        const int cb = ms & 1;
-        if (ms + 1 < MSUB) fetch_rows(ms + 1, cb ^ 1);
+    auto put_tile = [&](int ms) {               // accumulators of sub-tile ms -> this wave's buffer ms & 1
+        float *dst = tb + (ms & 1) * (32 * TP);
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
@@ -353,22 +404,37 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
-                *(f32x4 *)(tb + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
+                *(f32x4 *)(dst + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
             }
-        ds_wave_sync();
+    };
+    fetch_rows(0, 0);
+    put_tile(0);
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int cb = ms & 1;
+        ds_wave_sync();                         // sub-tile ms is in its buffer (LDS runs a wave's operations in order)
+        const float *src = tb + cb * (32 * TP);
+        f32x4 tv[NRI][2];
+#pragma unroll
+        for (int k = 0; k < NRI; ++k)
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
+        // the next sub-tile's turn-around and residual rows travel while this one is finished
+        if (ms + 1 < MSUB) {
+            fetch_rows(ms + 1, cb ^ 1);
+            put_tile(ms + 1);
+        }
 #pragma unroll
         for (int k = 0; k < NRI; ++k) {
             const f16x8 r8 = __builtin_bit_cast(f16x8, resv[cb][k]);
             f32x4 o[2];
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
-                const f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c + 4 * hq);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = v[j] * sc[hq][j] + sh[hq][j];
+                    float t = tv[k][hq][j] * sc[hq][j] + sh[hq][j];
                     t += (float)r8[4 * hq + j];
-                    if (flags & DS_EPI_CLIP) t = fminf(fmaxf(t, 0.0f), 20.0f);
-                    o[hq][j] = t;
+                    o[hq][j] = fminf(fmaxf(t, clip_lo), clip_hi);   // (-inf, +inf) without DS_EPI_CLIP: one v_med3
                 }
             }
             const unsigned vo = voff[cb][k];
@@ -386,30 +452,30 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                 ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
             }
         }
-        ds_wave_sync();                         // the buffer is rewritten by the next sub-tile
     }
+    DS_F16_STAMP(4);
 }
 
-template <int KS, int MSUB, int NSUB, int WM, int WN, bool DB>
+template <int KS, int MSUB, int NSUB, int WM, int WN, bool DB, int CK>
 static void launch_nit_h(const PlanH &pl, void *stream) {
     constexpr int NTHR = WM * WN * 64;
     if (pl.nit <= 8)
-        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 8, DB>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 8, DB, CK>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
     else if (pl.nit <= 16)
-        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 16, DB>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 16, DB, CK>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
     else if constexpr (!DB)
-        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 32, false>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 32, false, CK>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
 }
 
-template <int KS, bool DB>
+template <int KS, bool DB, int CK = 32>
 static void launch_h(const PlanH &pl, void *stream) {
-    if (pl.cfg == 0) launch_nit_h<KS, 5, 2, 1, 2, DB>(pl, stream);          // 160x128, two waves
-    else if (pl.cfg == 1) launch_nit_h<KS, 5, 2, 1, 4, DB>(pl, stream);     // 160x256, four waves
-    else if (pl.cfg == 2) launch_nit_h<KS, 5, 2, 2, 2, DB>(pl, stream);     // 320x128
-    else if (pl.cfg == 3) launch_nit_h<KS, 5, 2, 2, 1, DB>(pl, stream);     // 320x64, two waves
-    else if (pl.cfg == 4) launch_nit_h<KS, 4, 2, 1, 2, DB>(pl, stream);     // 128x128, two waves
-    else if (pl.cfg == 5) launch_nit_h<KS, 4, 2, 1, 4, DB>(pl, stream);     // 128x256
-    else launch_nit_h<KS, 5, 2, 4, 1, DB>(pl, stream);                      // 640x64, four waves
+    if (pl.cfg == 0) launch_nit_h<KS, 5, 2, 1, 2, DB, CK>(pl, stream);          // 160x128, two waves
+    else if (pl.cfg == 1) launch_nit_h<KS, 5, 2, 1, 4, DB, CK>(pl, stream);     // 160x256, four waves
+    else if (pl.cfg == 2) launch_nit_h<KS, 5, 2, 2, 2, DB, CK>(pl, stream);     // 320x128
+    else if (pl.cfg == 3) launch_nit_h<KS, 5, 2, 2, 1, DB, CK>(pl, stream);     // 320x64, two waves
+    else if (pl.cfg == 4) launch_nit_h<KS, 4, 2, 1, 2, DB, CK>(pl, stream);     // 128x128, two waves
+    else if (pl.cfg == 5) launch_nit_h<KS, 4, 2, 1, 4, DB, CK>(pl, stream);     // 128x256
+    else launch_nit_h<KS, 5, 2, 4, 1, DB, CK>(pl, stream);                      // 640x64, four waves
 }
 
 }  // namespace

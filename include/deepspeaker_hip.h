@@ -50,6 +50,7 @@ extern "C" {
 #define DS_EPI_OUT_F16  32  /* conv1 (ds_conv5x5s2_c1_fwd_bf16): store the result as fp16                    */
 
 #define DS_CONV_HINT_SINGLE_BUFFER 64  /* fp16 convolution: plan with one LDS pixel tile (tuning / test hint)  */
+#define DS_CONV_HINT_CHUNK16      128  /* fp16 5x5 convolution: plan with 16-channel chunks (tuning / test hint)  */
 
 #define DS_CONV_CK      8   /* input-channel chunk of the packed weight layout */
 
@@ -157,7 +158,7 @@ int ds_pack_conv_weight_f16(const float *w_oihw, void *w_f16, int Cout, int Cin,
 int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
                     const float *shift, const void *residual_f16, void *y, int flags, void *stream);
 /* out8 = {M tile, N tile, rows per segment, segments per tile, workgroups, LDS bytes, threads per workgroup,
- * 1000 * double-buffered + staging items per thread} */
+ * 1000 * double-buffered + 100 * (16-channel chunks) + staging items per thread} */
 int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8);
 int ds_cast_f32_to_f16(const float *x, void *y_f16, long long n, void *stream);
 int ds_cast_f16_to_f32(const void *x_f16, float *y, long long n, void *stream);

@@ -10,7 +10,7 @@ import pytest
 import deepspeaker_oracle as O
 from conftest import rel_err
 from emul_util import aligned, emul_lib, ptr, to_aligned
-from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_SINGLE_BUFFER, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_OUT_F16, DS_EPI_OUT_F32,
+from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_CHUNK16, DS_CONV_HINT_SINGLE_BUFFER, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_OUT_F16, DS_EPI_OUT_F32,
                                              DS_EPI_RESIDUAL, DS_EPI_STATS)
 
 
@@ -52,6 +52,7 @@ CASES = [
     (1, 64, 64, 3, 5, 3, 1),                 # tiny map: every tile row ragged
     (1, 64, 128, 21, 64, 5, 2),              # wide stride-2 input: too many staging items -> single-buffered tile
     (1, 32, 64, 12, 100, 3, 1),              # wide 3x3 map (variable-length / wide inputs), single chunk
+    (2, 32, 128, 100, 4, 3, 1),              # several row blocks of one image per tile: mixed halo windows (table walk)
 ]
 
 
@@ -103,6 +104,19 @@ def test_conv_f16_single_buffered(case):
     x = np.abs(rs.randn(b, ci, h, w)).astype(np.float16).astype(np.float32)
     wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
     y = run_conv_f16(lib, x, wt, s, DS_EPI_OUT_F32 | DS_CONV_HINT_SINGLE_BUFFER)
+    ref = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    assert rel_err(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("case", [CASES[3], CASES[4]])
+def test_conv_f16_chunk16(case):
+    """the 16-channel-chunk variant of the 5x5 kernel (what the planner picks when two 32-channel tiles do not fit)"""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(13 + sum(case))
+    x = np.abs(rs.randn(b, ci, h, w)).astype(np.float16).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
+    y = run_conv_f16(lib, x, wt, s, DS_EPI_OUT_F32 | DS_CONV_HINT_CHUNK16)
     ref = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
     assert rel_err(y, ref) < 2e-6
 

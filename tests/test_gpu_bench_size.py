@@ -116,16 +116,17 @@ F16_CASES = [
     (3, 32, 256, 9, 8, 5, 2), (1, 64, 64, 3, 5, 3, 1), (1, 64, 128, 21, 64, 5, 2), (1, 32, 64, 12, 100, 3, 1),
     (48, 64, 64, 80, 32, 3, 1), (48, 64, 128, 80, 32, 5, 2), (32, 128, 128, 40, 16, 3, 1), (32, 128, 256, 40, 16, 5, 2),
     (32, 256, 256, 20, 8, 3, 1), (33, 256, 512, 20, 8, 5, 2), (67, 512, 512, 10, 4, 3, 1), (3, 512, 512, 50, 4, 3, 1),
+    (2, 32, 128, 100, 4, 3, 1),
 ]
 
 
 @pytest.mark.parametrize("case", F16_CASES)
-@pytest.mark.parametrize("single_buffer", [False, True])
+@pytest.mark.parametrize("single_buffer", [0, 1, 2])
 def test_conv_f16_kernel(case, single_buffer):
     """ds_conv_fwd_f16 against a float64 convolution of the same fp16-rounded operands: fp16 products are exact
     in f32, so only the f32 accumulation order separates the two (1e-5 of the largest output)."""
-    from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_SINGLE_BUFFER, DS_EPI_AFFINE, DS_EPI_CLIP,
-                                                 DS_EPI_OUT_F32, DS_EPI_RESIDUAL)
+    from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_CHUNK16, DS_CONV_HINT_SINGLE_BUFFER,
+                                                 DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_OUT_F32, DS_EPI_RESIDUAL)
     from deepspeaker_pytorch_amd.model import get_engine
     eng = get_engine()
     b, ci, co, h, w, k, s = case
@@ -134,7 +135,9 @@ def test_conv_f16_kernel(case, single_buffer):
     wt = (torch.randn(co, ci, k, k, generator=gen) / (ci * k * k) ** 0.5).half().float().cuda()
     wp = eng._pack_f16(wt, k)
     ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
-    hint = DS_CONV_HINT_SINGLE_BUFFER if single_buffer else 0
+    if single_buffer == 2 and case[5] != 5:
+        pytest.skip("16-channel chunks exist for the 5x5 layers only")
+    hint = (0, DS_CONV_HINT_SINGLE_BUFFER, DS_CONV_HINT_CHUNK16)[single_buffer]
     shp = ConvShape(b, h, w, ci, co, k, s)
     y = torch.full((b, ho, wo, co), float("nan"), device="cuda")
     eng.lib.call("ds_conv_fwd_f16", ctypes.byref(shp), eng._p(x), eng._p(wp), None, None, None, eng._p(y),
