@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     constexpr int KPT = CKH / 16;                   // k-steps per tap
     constexpr int IPP = CKH / 8;                    // 16-byte staging items per pixel
     constexpr int PSH = ds_f16_record_bytes(CKH);
-    constexpr int NU = KPT * NT;                    // (tap, k-step) units per chunk
+    constexpr int NU = KPT * NT;                    // (k-step, tap) units per chunk
 #ifndef DS_F16_RING_K3
 #define DS_F16_RING_K3 6
 #define DS_F16_RING_K5 5
@@ -112,9 +112,11 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);      // in halfs
     const size_t w_kc_stride = (size_t)NT * p.Cout * 16;                // one 16-channel slab: [tap][Cout][16]
     const size_t w_tap_stride = (size_t)p.Cout * 16;
-    // unit u of a chunk = (tap u / KPT, k-step u % KPT): filter slab KPT*chunk + u % KPT, tap u / KPT
+    // unit u of a chunk = (k-step u / NT, tap u % NT): filter slab KPT*chunk + u / NT, tap u % NT.  K-step-major, so
+    // that a pixel's products are accumulated in the same order with 16- and 32-channel chunks (results do not
+    // depend on which the planner picks for a batch size).
     auto w_unit = [&](int chunk, int u) {
-        return p.w + lane_w + (size_t)(KPT * chunk + (u % KPT)) * w_kc_stride + (size_t)(u / KPT) * w_tap_stride;
+        return p.w + lane_w + (size_t)(KPT * chunk + (u / NT)) * w_kc_stride + (size_t)(u % NT) * w_tap_stride;
     };
 
     f16x8 bq[RU][NSUB];
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         for (int u = 0; u < NU; ++u) {
             const int cur = u & 1, slot = u % RU;
             const bool more = u + 1 < NU;
-            const char *nfrag = buf + tap_off((u + 1) / KPT) + 32 * ((u + 1) % KPT);
+            const char *nfrag = buf + tap_off((u + 1) % NT) + 32 * ((u + 1) / NT);
             // the slot the previous unit consumed is refilled with the unit RU - 1 ahead of this one
             const int ur = u - 1 + RU;                          // may run into the next chunk
             const bool refill = !(LAST && ur >= NU);            // (unit 0 of chunk 0 reloads what the prologue loaded)
@@ -383,18 +385,23 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
     const ds_buffer rbuf = ds_make_buffer((flags & DS_EPI_RESIDUAL) ? (const void *)p.res : (const void *)p.y,
                                           (flags & DS_EPI_RESIDUAL) ? p.res_bytes : 0u);
-    unsigned voff[2][NRI];                      // element offset of (pixel row, first channel) or OOB
-    f32x4 resv[2][NRI];
-    auto fetch_rows = [&](int ms, int bsel) {   // offsets and residual rows of sub-tile ms
+    // Every row offset and every residual row of the wave's MSUB sub-tiles is requested BEFORE the first store:
+    // gfx9 retires loads and stores through one in-order counter, so a residual load issued between two stores
+    // could only be waited for together with the store ahead of it (a full write acknowledgement per sub-tile).
+    unsigned voff[MSUB][NRI];                   // element offset of (pixel row, first channel) or OOB
+    f32x4 resv[MSUB][NRI];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
         for (int k = 0; k < NRI; ++k) {
             const int off = out_off[(wm * MSUB + ms) * 32 + k * PPI + my_p];
-            voff[bsel][k] = off >= 0 ? (unsigned)(off + col) : DS_BUFFER_OOB;
+            voff[ms][k] = off >= 0 ? (unsigned)(off + col) : DS_BUFFER_OOB;
         }
 #pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
         for (int k = 0; k < NRI; ++k)
-            resv[bsel][k] = ds_buffer_load_f32x4(rbuf, voff[bsel][k] != DS_BUFFER_OOB ? voff[bsel][k] * 2u : DS_BUFFER_OOB);
-    };
+            resv[ms][k] = ds_buffer_load_f32x4(rbuf, voff[ms][k] != DS_BUFFER_OOB ? voff[ms][k] * 2u : DS_BUFFER_OOB);
     auto put_tile = [&](int ms) {               // accumulators of sub-tile ms -> this wave's buffer ms & 1
         float *dst = tb + (ms & 1) * (32 * TP);
 #pragma unroll
@@ -407,7 +414,6 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                 *(f32x4 *)(dst + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
             }
     };
-    fetch_rows(0, 0);
     put_tile(0);
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
@@ -419,14 +425,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         for (int k = 0; k < NRI; ++k)
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
-        // the next sub-tile's turn-around and residual rows travel while this one is finished
-        if (ms + 1 < MSUB) {
-            fetch_rows(ms + 1, cb ^ 1);
-            put_tile(ms + 1);
-        }
+        if (ms + 1 < MSUB) put_tile(ms + 1);    // the next sub-tile's turn-around travels while this one is finished
 #pragma unroll
         for (int k = 0; k < NRI; ++k) {
-            const f16x8 r8 = __builtin_bit_cast(f16x8, resv[cb][k]);
+            const f16x8 r8 = __builtin_bit_cast(f16x8, resv[ms][k]);
             f32x4 o[2];
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                     o[hq][j] = fminf(fmaxf(t, clip_lo), clip_hi);   // (-inf, +inf) without DS_EPI_CLIP: one v_med3
                 }
             }
-            const unsigned vo = voff[cb][k];
+            const unsigned vo = voff[ms][k];
             if (out32) {
                 const unsigned b = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
                 ds_buffer_store_f32x4(ybuf, b, o[0]);
