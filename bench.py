@@ -227,8 +227,8 @@ def main():
 
     def measure_train(precision, steps, warmup):
         """The training step of the triplet regime (train_triplet.py:215-224): train-mode forwards of a / p / n
-        (three BatchNorm statistic sets, as the reference), triplet loss, backward, gradient all-reduce, fused
-        Adagrad (lr 0.1, lr_decay 1e-4: train_triplet.py:369-383)."""
+        (three BatchNorm statistic sets, as the reference), triplet loss, backward (gradient all-reduce inside),
+        fused Adagrad (lr 0.1, lr_decay 1e-4: train_triplet.py:369-383)."""
         from deepspeaker_pytorch_amd.optim import create_optimizer
         model = load_model(precision).train()
         if multi:
@@ -236,14 +236,15 @@ def main():
         opt = create_optimizer(model, 0.1, "adagrad", lr_decay=1e-4)
 
         def step(slot=0):
-            out_a, out_p, out_n = model(data[0]), model(data[1]), model(data[2])
+            # the three forwards of train_triplet.py:215 in lock-step over one batch (same values, three BatchNorm
+            # statistic sets); under data parallelism: one statistics all-reduce per BatchNorm layer and direction,
+            # gradient buckets all-reduced from inside the backward pass
+            out_a, out_p, out_n = model.forward_triplet(data[0], data[1], data[2])
             loss = loss_fn.forward(out_a, out_p, out_n)
             if multi:
                 loss = loss / world
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            if multi:
-                model.allreduce_gradients()
             opt.step()
             return loss
 

@@ -16,10 +16,60 @@ from ._native import ConvShape
 from .engine import ALPHA, L2_EPS, STAGE_CHANNELS, Engine, PackedWeights, SavedForward
 
 
+def _bn_bwd_group(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
+    """_bn_bwd over a batch made of len(stats) members with their own batch statistics (the three forwards of a
+    triplet step run as one batch, Engine.forward_train_group): the reductions run per member on slices of the
+    batch; with a `reducer` the sums of ALL members travel in one all-reduce.  dgamma / dbeta are summed over the
+    members (the reference accumulates them over its three backward passes)."""
+    G = len(stats)
+    c = z.shape[-1]
+    Bm = z.shape[0] // G
+    dev = z.device
+    n_pix = (z.numel() // c) // G
+    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix)
+    gy, gz = torch.empty_like(z), torch.empty_like(z)
+    gg_all = torch.empty((G, c), dtype=torch.float32, device=dev)
+    gb_all = torch.empty((G, c), dtype=torch.float32, device=dev)
+    st = eng._stream(z)
+
+    def m(t, g):
+        return None if t is None else t[g * Bm:(g + 1) * Bm]
+
+    dp = reducer is not None and reducer.world > 1
+    partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=dev)
+    coef = torch.empty((G, 3 * c), dtype=torch.float32, device=dev)
+    if not dp:
+        for g in range(G):
+            mean, invstd, _ = stats[g]
+            eng.lib.call("ds_bn_bwd_f32", eng._p(m(g1, g)), eng._p(m(g2, g)), eng._p(m(act, g)), eng._p(m(z, g)),
+                         eng._p(mean), eng._p(invstd), eng._p(gamma.detach()), eng._p(m(gy, g)), eng._p(partial[g]),
+                         eng._p(coef[g]), eng._p(gg_all[g]), eng._p(gb_all[g]), eng._p(m(gz, g)), n_pix, c, st)
+    else:
+        sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=dev)
+        for g in range(G):
+            mean, invstd, _ = stats[g]
+            eng.lib.call("ds_bn_bwd_reduce_f32", eng._p(m(g1, g)), eng._p(m(g2, g)), eng._p(m(act, g)), eng._p(m(z, g)),
+                         eng._p(mean), eng._p(invstd), eng._p(m(gy, g)), eng._p(partial[g]), n_pix, c, st)
+            eng.lib.call("ds_partial_sum_f64", eng._p(partial[g]), rows, eng._p(sums[g]), c, st)
+        sums[:, 2 * c] = float(n_pix)
+        reducer.all_reduce_sum_(sums)                               # every member of this layer in ONE collective
+        for g in range(G):
+            mean, invstd, _ = stats[g]
+            eng.lib.call("ds_bn_bwd_apply_f32", eng._p(sums[g]), 0, eng._p(m(gy, g)), eng._p(m(z, g)), eng._p(mean),
+                         eng._p(invstd), eng._p(gamma.detach()), eng._p(coef[g]), eng._p(gg_all[g]), eng._p(gb_all[g]),
+                         eng._p(m(gz, g)), n_pix, c, st)
+    gg, gb = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
+    eng.lib.call("ds_colsum_f32", eng._p(gg_all), eng._p(gg), G, c, st)
+    eng.lib.call("ds_colsum_f32", eng._p(gb_all), eng._p(gb), G, c, st)
+    return gy, gz, gg, gb
+
+
 def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     """(masked upstream gradient gy, gz = dL/d(conv output), dgamma, dbeta).  With a `reducer` the two
     per-channel sums are all-reduced between the reduce and the apply kernel (global-batch BatchNorm);
     dgamma / dbeta then already are the global gradients."""
+    if isinstance(stats, list):
+        return _bn_bwd_group(eng, g1, g2, act, z, stats, gamma, reducer)
     mean, invstd, _ = stats
     c = z.shape[-1]
     n_pix = z.numel() // c
@@ -49,13 +99,14 @@ def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     return gy, gz, gg, gb
 
 
-def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0, x3: bool = False):
+def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0, x3: bool = False, out=None):
+    """filter gradient into `out` (a contiguous view of a gradient bucket) or a fresh tensor"""
     if x3 and shp.KS in (3, 5) and shp.Cin % 64 == 0:      # split-operand bf16 matrix cores
         n_ws = eng.lib.raw("ds_conv_wgrad_bf16_workspace_floats")(ctypes.byref(shp))
         if n_ws <= 0:
             raise RuntimeError(f"ds_conv_wgrad_bf16_workspace_floats failed: {n_ws}")
         ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
-        gw = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        gw = out if out is not None else torch.empty(out_shape, dtype=torch.float32, device=x.device)
         eng.lib.call("ds_conv_wgrad_bf16", ctypes.byref(shp), eng._p(x), eng._p(gz), eng._p(ws), eng._p(gw),
                      eng._stream(x))
         return gw
@@ -63,7 +114,7 @@ def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0, x3: boo
     if n_ws <= 0:
         raise RuntimeError(f"ds_conv_wgrad_workspace_floats failed: {n_ws}")
     ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
-    gw = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+    gw = out if out is not None else torch.empty(out_shape, dtype=torch.float32, device=x.device)
     eng.lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), eng._p(x), eng._p(gz), eng._p(ws), eng._p(gw), fc_f,
                  eng._stream(x))
     return gw
@@ -79,15 +130,58 @@ def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad, w_dgrad_bf16=None):
     return gx
 
 
+class _GradBuckets:
+    """The filter / fc gradients of one backward pass, laid out as one flat buffer per stage (+ one for fc): the
+    gradient kernels write straight into views of their bucket, and under data parallelism each bucket's
+    all-reduce is launched the moment its last gradient kernel has been enqueued -- it then runs over xGMI while
+    the earlier stages' backward kernels execute.  BatchNorm affine gradients come out of the (already global)
+    statistic sums and are not reduced."""
+
+    def __init__(self, shapes: Dict[int, Dict[str, tuple]], device, reducer=None):
+        self.reducer = reducer if (reducer is not None and reducer.world > 1) else None
+        self.views: Dict[str, torch.Tensor] = {}
+        self.flat: Dict[int, torch.Tensor] = {}
+        self.work = []
+        for b, names in shapes.items():
+            n = sum(int(torch.Size(shp).numel()) for shp in names.values())
+            flat = torch.empty(n, dtype=torch.float32, device=device)
+            self.flat[b] = flat
+            off = 0
+            for name, shp in names.items():
+                k = int(torch.Size(shp).numel())
+                self.views[name] = flat[off:off + k].view(shp)
+                off += k
+
+    def done(self, bucket: int):
+        if self.reducer is not None:
+            self.work.append(self.reducer.all_reduce_sum_(self.flat[bucket], async_op=True))
+
+    def finish(self):
+        for h in self.work:
+            h.wait()
+        self.work = []
+
+
 def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
-                   ge: torch.Tensor, reducer=None, precision: str = "f32") -> Dict[str, torch.Tensor]:
+                   ge: torch.Tensor, reducer=None, precision: str = "f32",
+                   reduce_gradients: bool = False) -> Dict[str, torch.Tensor]:
     """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512].
     precision "bf16x3": data and filter gradients of the 3x3 / 5x5 layers run on the bf16 matrix cores with
-    split operands; conv1 and fc stay on the f32 matrix cores."""
+    split operands; conv1 and fc stay on the f32 matrix cores.  `reduce_gradients` (data parallelism): the
+    per-stage gradient buckets are all-reduced over `reducer` as the pass produces them, overlapped with the rest
+    of the pass; the returned gradients are then the global sums."""
     x3 = precision == "bf16x3"
     lib = eng.lib
     grads: Dict[str, torch.Tensor] = {}
     n_stages = len(pw.stages)
+    shapes = {n_stages: {"model.fc.weight": tuple(saved.fc_out.shape[1:]) + (saved.pooled.shape[1],),
+                         "model.fc.bias": (saved.fc_out.shape[1],)}}
+    for s_ in range(n_stages):
+        i_, c_ = s_ + 1, STAGE_CHANNELS[s_]
+        cin_ = 1 if s_ == 0 else STAGE_CHANNELS[s_ - 1]
+        shapes[s_] = {f"model.layer{i_}.0.conv2.weight": (c_, c_, 3, 3), f"model.layer{i_}.0.conv1.weight": (c_, c_, 3, 3),
+                      f"model.conv{i_}.weight": (c_, cin_, 5, 5)}
+    buckets = _GradBuckets(shapes, ge.device, reducer if reduce_gradients else None)
     f = saved.fc_out
     B, n_out = f.shape
     st = eng._stream(f)
@@ -97,12 +191,14 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
     # ---- fc (model.py:209): bias, weight, input ----
     pooled = saved.pooled
     k = pooled.shape[1]
-    gb = torch.empty(n_out, dtype=torch.float32, device=f.device)
+    gb = buckets.views["model.fc.bias"]
     lib.call("ds_colsum_f32", eng._p(gf), eng._p(gb), B, n_out, st)
     grads["model.fc.bias"] = gb
     c_last = STAGE_CHANNELS[n_stages - 1]
     f_bins = k // c_last
-    grads["model.fc.weight"] = _wgrad(eng, ConvShape(1, B, 1, k, n_out, 1, 1), pooled, gf, (n_out, k), f_bins)
+    grads["model.fc.weight"] = _wgrad(eng, ConvShape(1, B, 1, k, n_out, 1, 1), pooled, gf, (n_out, k), f_bins,
+                                      out=buckets.views["model.fc.weight"])
+    buckets.done(n_stages)
     ws = torch.empty(lib.raw("ds_fc_workspace_floats")(B, n_out, k), dtype=torch.float32, device=f.device)
     gpooled = torch.empty((B, k), dtype=torch.float32, device=f.device)
     lib.call("ds_fc_l2norm_fwd_f32", eng._p(gf), eng._p(pw.fc_dgrad), None, eng._p(ws), eng._p(gpooled), None, B,
@@ -124,13 +220,15 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         g_out, gz, gg, gbeta = _bn_bwd(eng, g, None, None if g_is_masked else c_act, saved.raws[name],
                                        saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
-        grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3), x3=x3)
+        grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3), x3=x3,
+                                                         out=buckets.views[f"model.layer{i}.0.conv2.weight"])
         g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad, pw.stages[s].l_conv2_dgrad_bf16 if x3 else None)
         # y = clip(bn1(conv1(r)))                  (model.py:69-71)
         name = f"model.layer{i}.0.bn1"
         _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
-        grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3), x3=x3)
+        grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3), x3=x3,
+                                                         out=buckets.views[f"model.layer{i}.0.conv1.weight"])
         g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad, pw.stages[s].l_conv1_dgrad_bf16 if x3 else None)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv-path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
@@ -139,8 +237,11 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
         shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)
         x_in = saved.x if s == 0 else saved.acts[f"stage{s}.c"]
-        grads[f"model.conv{i}.weight"] = _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5), x3=x3)
+        grads[f"model.conv{i}.weight"] = _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5), x3=x3,
+                                                out=buckets.views[f"model.conv{i}.weight"])
+        buckets.done(s)                         # this stage's three filter gradients are enqueued: reduce them now
         if s > 0:
             g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad, pw.stages[s].conv_dgrad_bf16 if x3 else None)   # unmasked: the next bn2 step masks it
             g_is_masked = False
+    buckets.finish()
     return grads

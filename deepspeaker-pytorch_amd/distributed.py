@@ -5,17 +5,20 @@ BASELINE.json's north_star.  Partitioning: rank r owns rows [r*B_l
 anchor / positive / negative batches.  Exchange steps per iteration:
 
 1. BatchNorm batch statistics -- forward {sum x, sum x^2} and backward {sum dy, sum dy*xhat}: one tiny
-   float64 all-reduce per BatchNorm (engine.bn_finalize / backward._bn_bwd).  With them an N-rank step
-   reproduces the single-process step on the global batch.
+   float64 all-reduce per BatchNorm LAYER and direction, carrying the sums of all three members (anchor /
+   positive / negative forwards run in lock-step, Engine.forward_train_group): 24 per step.  With them an
+   N-rank step reproduces the single-process step on the global batch.
 2. Embeddings (+ speaker labels): RCCL all-gather so every rank sees the global batch for cross-GPU
    semi-hard negative mining; the gather is differentiable (its adjoint is a reduce-scatter), so the
    gradient of a negative mined on another GPU returns to the rank that owns it.
-3. Filter / weight gradients: one flat bucket per stage, all-reduced (sum) asynchronously.  BatchNorm
-   affine gradients need no exchange: they are computed from the already-global sums.
+3. Filter / weight gradients: one flat bucket per stage (+ fc).  The gradient kernels write straight into
+   their bucket and the bucket's all-reduce is launched from inside the backward pass as soon as the stage's
+   last gradient kernel is enqueued (backward._GradBuckets), so it runs over xGMI while the earlier stages'
+   backward kernels execute.  BatchNorm affine gradients need no exchange: they come from global sums.
 
-xGMI is point-to-point (7 links per GPU); the only bandwidth-relevant message is the 46 MB gradient
-all-reduce, issued as 5 bucket-sized collectives so RCCL can spread them over all links while the host
-keeps launching backward kernels of the next stage.
+xGMI is point-to-point (7 links per GPU); the only bandwidth-relevant message is the 46 MB of gradients,
+issued as 5 bucket-sized collectives (stage 4 alone is 26 MB and goes first, with the most backward work
+left to hide behind).
 """
 from __future__ import annotations
 
@@ -36,8 +39,10 @@ class Reducer:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.n_all_reduce = 0           # collectives issued so far (tests assert the per-step count)
 
     def all_reduce_sum_(self, t: torch.Tensor, async_op: bool = False):
+        self.n_all_reduce += 1
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
@@ -127,12 +132,9 @@ def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, redu
     from .backward import backward_train
     lib = eng.lib
     world = reducer.world if reducer is not None else 1
-    outs, saves = [], []
-    for x in (xa, xp, xn):
-        e, saved = eng.forward_train(x, pw, bns, save=True, reducer=reducer)
-        outs.append(e)
-        saves.append(saved)
-    ea, ep, en = outs
+    # the three forwards in lock-step over one batch: one statistics all-reduce per BatchNorm layer
+    (ea, ep, en), saved = eng.forward_train_group([xa, xp, xn], pw, bns, save=True, reducer=reducer)
+    ea, ep, en = ea.contiguous(), ep.contiguous(), en.contiguous()
     n_loc, d = ea.shape
     n_glob = n_loc * world
     st = eng._stream(ea)
@@ -181,14 +183,8 @@ def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, redu
         gn = gcand[2 * n_loc:].contiguous()
     else:
         gn = gn_used
-    grads: Dict[str, torch.Tensor] = {}
-    for saved, g in zip(saves, (ga, gp, gn)):
-        gr = backward_train(eng, bn_weights, pw, saved, g.contiguous(), reducer=reducer)
-        for k, v in gr.items():
-            if k in grads:
-                grads[k].add_(v)
-            else:
-                grads[k] = v
-    if reducer is not None:
-        allreduce_gradients(grads, reducer)
+    # one backward pass over the concatenated batch; its per-stage gradient buckets are all-reduced as they
+    # are produced (backward._GradBuckets), overlapped with the earlier stages' kernels
+    grads = backward_train(eng, bn_weights, pw, saved, torch.cat([ga, gp, gn]).contiguous(), reducer=reducer,
+                           reduce_gradients=reducer is not None)
     return TripletStepResult(loss.reshape(()), grads, (ea, ep, en), mined)

@@ -573,6 +573,139 @@ class Engine:
         e = self.tail(a, pw, saved)
         return e, saved
 
+    # ------------------------------------------------------------------ grouped train-mode forward
+    def _group_aligned(self, shp: ConvShape, members: int, x3: bool) -> bool:
+        """True if one launch over the concatenated batch keeps every M tile inside one member, i.e. the
+        per-tile BatchNorm partial sums can be split by member."""
+        out8 = (ctypes.c_int * 8)()
+        if x3:
+            rc = self.lib.raw("ds_conv_bf16_plan_describe")(ctypes.byref(shp), 1, out8)
+        else:
+            rc = self.lib.raw("ds_conv_plan_describe")(ctypes.byref(shp), out8)
+        if rc != 0:
+            return False
+        rt, ni = out8[2], out8[3]
+        ho = conv_out(shp.H, shp.KS, shp.stride)
+        segs_per_member = (shp.B // members) * ((ho + rt - 1) // rt)
+        return segs_per_member % ni == 0
+
+    def forward_train_group(self, xs: List[torch.Tensor], pw: PackedWeights, bns: Dict[str, BNParams],
+                            save: bool = True, reducer=None, precision: str = "f32"):
+        """The reference's three train-mode forwards of one step -- model(data_a), model(data_p), model(data_n),
+        train_triplet.py:215 -- run in lock-step over ONE concatenated batch: same arithmetic per utterance, one
+        BatchNorm statistic set (and one running-statistics update, in call order) per member, but
+
+          * each layer is one convolution launch over all members wherever its tiles do not straddle members
+            (otherwise one launch per member, into slices of the same buffer),
+          * the backward pass sees one batch: ONE data-gradient and ONE filter-gradient launch per layer, whose
+            contraction over all members' pixels IS the sum the reference gets by accumulating three backward
+            passes into `.grad`,
+          * data-parallel training exchanges the statistics of all members in one all-reduce per BatchNorm
+            layer (24 per step instead of 72).
+
+        Returns ([embeddings per member], SavedForward of the concatenated batch; `stats[name]` is a list with one
+        (mean, invstd, scale) per member)."""
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("training runs in f32 or bf16x3")
+        G = len(xs)
+        for x in xs:
+            self._check(x, "input")
+            if x.shape != xs[0].shape or x.dim() != 4 or x.shape[1] != 1:
+                raise ValueError("members must be equally shaped [B,1,T,F] batches")
+        Bm, _, T, F = xs[0].shape
+        B = G * Bm
+        x = torch.cat(xs)
+        x3 = precision == "bf16x3"
+        if x3 and pw.stages[0].l_conv1_bf16 is None:
+            raise ValueError("pack_weights(..., with_bf16=True) is required for bf16x3")
+        saved = SavedForward(x=x) if save else None
+        dev = x.device
+
+        def member(t, g):
+            return t[g * Bm:(g + 1) * Bm]
+
+        def conv_g(src, w_f32, w_b, hh, ww, ci, co, ks, stride):
+            """raw conv output [B,ho,wo,co] + per-member partial statistics"""
+            shp = ConvShape(B, hh, ww, ci, co, ks, stride)
+            if G == 1 or self._group_aligned(shp, G, x3):
+                if x3:
+                    z, st = self.conv_bf16(src, w_b, True, B, hh, ww, ci, co, ks, stride, want_stats=True)
+                else:
+                    z, st = self.conv(src, w_f32, B, hh, ww, ci, co, ks, stride, want_stats=True)
+                rows = st.shape[0] // G
+                return z, [st[g * rows:(g + 1) * rows] for g in range(G)]
+            ho, wo = conv_out(hh, ks, stride), conv_out(ww, ks, stride)
+            z = torch.empty((B, ho, wo, co), dtype=torch.float32, device=dev)
+            sts = []
+            for g in range(G):
+                if x3:
+                    zg, st = self.conv_bf16(member(src, g), w_b, True, Bm, hh, ww, ci, co, ks, stride, want_stats=True)
+                else:
+                    zg, st = self.conv(member(src, g), w_f32, Bm, hh, ww, ci, co, ks, stride, want_stats=True)
+                member(z, g).copy_(zg)
+                sts.append(st)
+            return z, sts
+
+        def bn_g(z, sts, name, count, residual, flags):
+            """per-member statistics -> normalised (+ residual) + clipped activations of the whole batch"""
+            bn = bns[name]
+            c = bn.weight.numel()
+            per = []
+            if reducer is not None and reducer.world > 1:
+                sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=dev)
+                for g in range(G):
+                    self.lib.call("ds_partial_sum_f64", self._p(sts[g]), sts[g].shape[0], self._p(sums[g]), c,
+                                  self._stream(z))
+                sums[:, 2 * c] = float(count)
+                reducer.all_reduce_sum_(sums)                     # all members of this layer in ONE collective
+                for g in range(G):
+                    mean, invstd, sc, sh = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+                    self.lib.call("ds_bn_stats_from_sums_f32", self._p(sums[g]), 0, self._p(bn.weight.detach()),
+                                  self._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM, self._p(bn.running_mean),
+                                  self._p(bn.running_var), self._p(mean), self._p(invstd), self._p(sc), self._p(sh), c,
+                                  self._stream(z))
+                    per.append((mean, invstd, sc, sh))
+            else:
+                for g in range(G):                                # running statistics update in call order
+                    per.append(self.bn_finalize(sts[g], count, bn))
+            a = torch.empty_like(z)
+            n_pix = member(z, 0).numel() // c
+            for g in range(G):
+                self.lib.call("ds_bn_apply_f32", self._p(member(z, g)), self._p(per[g][2]), self._p(per[g][3]),
+                              self._p(member(residual, g)) if residual is not None else None, self._p(member(a, g)),
+                              n_pix, c, flags, self._stream(z))
+            return a, [(m, i, sc) for (m, i, sc, _) in per]
+
+        h, w, cin = T, F, 1
+        a = x
+        for s, sw in enumerate(pw.stages):
+            i, c = s + 1, STAGE_CHANNELS[s]
+            if i == 1:
+                z, st = self.conv1(a, sw.conv, B, h, w, want_stats=True, lowp=x3)     # its tiles never span images
+                rows = st.shape[0] // G
+                sts = [st[g * rows:(g + 1) * rows] for g in range(G)]
+            else:
+                z, sts = conv_g(a, sw.conv, sw.conv_bf16, h, w, cin, c, 5, 2)
+            h, w, cin = conv_out(h, 5, 2), conv_out(w, 5, 2), c
+            count = Bm * h * w
+            name = f"model.bn{i}"
+            a, stt = bn_g(z, sts, name, count, None, DS_EPI_CLIP)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, stt, a
+            name = f"model.layer{i}.0.bn1"
+            z, sts = conv_g(a, sw.l_conv1, sw.l_conv1_bf16, h, w, c, c, 3, 1)
+            y, stt = bn_g(z, sts, name, count, None, DS_EPI_CLIP)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, stt, y
+            name = f"model.layer{i}.0.bn2"
+            z, sts = conv_g(y, sw.l_conv2, sw.l_conv2_bf16, h, w, c, c, 3, 1)
+            a, stt = bn_g(z, sts, name, count, a, DS_EPI_CLIP | DS_EPI_RESIDUAL)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, stt, a
+                saved.dims.append((h, w))
+        e = self.tail(a, pw, saved)
+        return [member(e, g) for g in range(G)], saved
+
     # ------------------------------------------------------------------ loss side
     def pairwise_distance(self, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
         assert x1.size() == x2.size()                       # reference model.py:14

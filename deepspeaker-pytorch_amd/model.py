@@ -303,9 +303,40 @@ class _ResCNNTrainFn(torch.autograd.Function):
         from .backward import backward_train
         bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
         grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
-                               reducer=ctx.model._reducer, precision=ctx.precision)
+                               reducer=ctx.model._reducer, precision=ctx.precision,
+                               reduce_gradients=ctx.model._reducer is not None)
         ctx.saved_forward = None
         return (None, None) + tuple(grads.get(n) for n in ctx.param_names)
+
+
+class _ResCNNTripletFn(torch.autograd.Function):
+    """The three train-mode forwards of a triplet step (train_triplet.py:215) and their backward as ONE autograd node
+    over the concatenated batch (Engine.forward_train_group)."""
+
+    @staticmethod
+    def forward(ctx, xa, xp, xn, model, *params):
+        eng = get_engine()
+        prec = "bf16x3" if model.precision in ("bf16x3", "f16") else "f32"
+        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"))
+        embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
+                                              precision=prec)
+        for bn in model._bn_modules():
+            bn.num_batches_tracked += 3                             # three statistic updates, as three calls make
+        model._stat_updates += 3
+        ctx.precision, ctx.saved_forward, ctx.model, ctx.pw = prec, saved, model, pw
+        ctx.param_names = model._param_names
+        return tuple(e.clone() for e in embs)
+
+    @staticmethod
+    def backward(ctx, ga, gp, gn):
+        from .backward import backward_train
+        ref = next(g for g in (ga, gp, gn) if g is not None)
+        ge = torch.cat([g if g is not None else torch.zeros_like(ref) for g in (ga, gp, gn)]).contiguous().float()
+        bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
+        grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, reducer=ctx.model._reducer,
+                               precision=ctx.precision, reduce_gradients=ctx.model._reducer is not None)
+        ctx.saved_forward = None
+        return (None, None, None, None) + tuple(grads.get(n) for n in ctx.param_names)
 
 
 class GraphedEmbedder:
@@ -434,21 +465,28 @@ class DeepSpeakerModel(nn.Module):
 
     # ---- data-parallel training (new capability; the reference is single-GPU) ----
     def enable_data_parallel(self, process_group=None):
-        """One process per GPU (torch.distributed backend "nccl" = RCCL).  From now on train-mode forwards
-        and their backward use global-batch BatchNorm statistics (all-reduced over the ranks); call
-        `allreduce_gradients()` after `loss.backward()` and scale the local loss by 1/world_size so that
-        the step equals the single-process step on the concatenated batch."""
+        """One process per GPU (torch.distributed backend "nccl" = RCCL).  From now on train-mode forwards and
+        their backward use global-batch BatchNorm statistics (all-reduced over the ranks -- one collective per
+        BatchNorm layer when the step goes through `forward_triplet`), and the backward pass all-reduces the
+        filter / fc gradients itself, one bucket per stage, launched as soon as the stage's gradient kernels are
+        enqueued (overlapped with the rest of the pass).  Scale the local loss by 1/world_size so that the step
+        equals the single-process step on the concatenated batch; the classifier head (not part of the embedding
+        network's autograd node) is reduced by `allreduce_gradients()`."""
         from .distributed import Reducer
         self._reducer = Reducer(process_group)
         return self._reducer
 
     def allreduce_gradients(self):
-        """Sum the filter / fc gradients over the ranks (BatchNorm affine gradients are already global)."""
-        from .distributed import allreduce_gradients, needs_allreduce
+        """Sum over the ranks what the backward pass has not already reduced: the classifier head's gradients
+        (the embedding network's filter / fc gradients are all-reduced inside its backward; BatchNorm affine
+        gradients come out of global sums)."""
+        from .distributed import allreduce_gradients
         if self._reducer is None:
             raise RuntimeError("call enable_data_parallel() first")
-        grads = {n: p.grad for n, p in self.named_parameters() if p.grad is not None and needs_allreduce(n)}
-        allreduce_gradients(grads, self._reducer)
+        grads = {n: p.grad for n, p in self.named_parameters()
+                 if p.grad is not None and n.startswith("model.classifier")}
+        if grads:
+            allreduce_gradients(grads, self._reducer, n_buckets=1)
 
     # ---- reference surface ----
     def l2_norm(self, input):
@@ -481,6 +519,33 @@ class DeepSpeakerModel(nn.Module):
             pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
             self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=self.precision)
         return self.features
+
+    def forward_triplet(self, data_a, data_p, data_n):
+        """`out_a, out_p, out_n = model(data_a), model(data_p), model(data_n)` (train_triplet.py:215) as one call.
+        Train mode: the three forwards run in lock-step over one concatenated batch with one BatchNorm statistic set
+        per member (same values as three calls, three running-statistics updates in the same order), the backward
+        pass is one pass over that batch, and data-parallel training exchanges one all-reduce per BatchNorm layer.
+        Eval mode: one forward of the concatenated batch."""
+        for t in (data_a, data_p, data_n):
+            _require_cuda(t, "DeepSpeakerModel.forward_triplet")
+            if t.dim() != 4 or t.size(1) != 1 or t.size(3) != 64 or t.shape != data_a.shape:
+                raise ValueError(f"expected three equally shaped [B,1,T,64] batches, got {tuple(t.shape)}")
+        xs = [t.contiguous().float() for t in (data_a, data_p, data_n)]
+        params = [p for n, p in self.named_parameters() if not n.startswith("model.classifier")]
+        if not self.training:
+            e = self.forward(torch.cat(xs))
+            return tuple(e.split(xs[0].shape[0]))
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            outs = _ResCNNTripletFn.apply(xs[0], xs[1], xs[2], self, *params)
+        else:
+            embs, _ = get_engine().forward_train_group(xs, self._packed(), self._bn_params(), save=False,
+                                                       reducer=self._reducer)
+            for bn in self._bn_modules():
+                bn.num_batches_tracked += 3
+            self._stat_updates += 3
+            outs = tuple(embs)
+        self.features = outs[2]
+        return outs
 
     def embed_reference(self, x: torch.Tensor) -> torch.Tensor:
         """Eval-mode embeddings at f32-class precision (split-operand bf16 path) whatever `self.precision` is:

@@ -55,6 +55,8 @@ def _run(rank, world, mine, reducer):
     res = triplet_train_step(eng, pw, bns, {n: b.weight for n, b in bns.items()}, xa, xp, xn, 0.1, reducer,
                              labels=labels, mine=mine)
     out = {"loss": res.loss.numpy()}
+    if reducer is not None:
+        out["n_all_reduce"] = np.array(reducer.n_all_reduce)
     for k, v in res.grads.items():
         out["grad/" + k] = v.numpy()
     for n, b in bns.items():
@@ -103,6 +105,9 @@ def test_two_ranks_reproduce_single_process(tmp_path, mine):
                 np.testing.assert_allclose(got[k], v, rtol=1e-5, atol=1e-6, err_msg=k)
             elif k.startswith("emb_"):
                 np.testing.assert_allclose(got[k], v[r * n_loc:(r + 1) * n_loc], rtol=2e-5, atol=2e-5)
+    # collective-lean: per BatchNorm LAYER one statistics all-reduce forward and one backward (all three members
+    # together), one per gradient bucket (stages + fc), one for the loss -- not one per BatchNorm call
+    assert int(ranks[0]["n_all_reduce"]) == 2 * 3 * N_STAGES + (N_STAGES + 1) + 1
     # both ranks hold identical global gradients
     for k in ranks[0].files:
         if k.startswith("grad/"):

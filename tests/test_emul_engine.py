@@ -340,3 +340,45 @@ def test_training_step_bf16x3_matches_oracle():
     for k, v in ref.items():
         err = np.linalg.norm(grads[k].numpy() - v) / max(np.linalg.norm(v), 1e-30)
         assert err < 3e-4, (k, err)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_grouped_triplet_forward_backward_equals_three_calls(precision):
+    """Engine.forward_train_group + one backward over the concatenated batch == the reference's call pattern
+    (three train-mode forwards, three backward passes accumulated): embeddings and saved statistics bitwise,
+    running statistics bitwise (three sequential momentum updates), gradients to summation-order rounding."""
+    from deepspeaker_pytorch_amd.backward import backward_train
+    eng = Engine(emul_lib())
+    n_stages, B, T = 2, 2, 23
+    sd = O.make_state_dict(seed=23, num_classes=4, n_stages=n_stages)
+    xs = [torch.from_numpy(O.make_input(seed=30 + i, batch=B, frames=T)) for i in range(3)]
+    ges = [torch.from_numpy(np.random.RandomState(40 + i).randn(B, 512).astype(np.float32)) for i in range(3)]
+    x3 = precision == "bf16x3"
+
+    def fresh():
+        tsd = torch_sd(sd)
+        tsd = {k: v.clone() for k, v in tsd.items()}
+        return tsd, eng.pack_weights(tsd, n_stages, with_dgrad=True, with_bf16=x3), make_bns(tsd, n_stages)
+
+    tsd1, pw1, bns1 = fresh()
+    bn_w1 = {n: tsd1[n + ".weight"] for n in bn_names(n_stages)}
+    sep_e, sep_g = [], {}
+    for x, ge in zip(xs, ges):
+        e, saved = eng.forward_train(x, pw1, bns1, precision=precision)
+        sep_e.append(e)
+        for k, v in backward_train(eng, bn_w1, pw1, saved, ge, precision=precision).items():
+            sep_g[k] = sep_g[k] + v if k in sep_g else v
+    tsd2, pw2, bns2 = fresh()
+    bn_w2 = {n: tsd2[n + ".weight"] for n in bn_names(n_stages)}
+    embs, saved = eng.forward_train_group(xs, pw2, bns2, precision=precision)
+    for a, b in zip(sep_e, embs):
+        assert torch.equal(a, b)
+    for n in bn_names(n_stages):
+        assert torch.equal(bns1[n].running_mean, bns2[n].running_mean), n
+        assert torch.equal(bns1[n].running_var, bns2[n].running_var), n
+        assert len(saved.stats[n]) == 3
+    grads = backward_train(eng, bn_w2, pw2, saved, torch.cat(ges), precision=precision)
+    assert set(grads) == set(sep_g)
+    for k, v in sep_g.items():
+        err = float((grads[k] - v).norm() / v.norm().clamp_min(1e-30))
+        assert err < 2e-6, (k, err)

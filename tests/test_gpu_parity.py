@@ -417,7 +417,46 @@ def test_data_parallel_world1_nccl(dev):
         grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
     for n in grads[0]:
         assert rel_err(grads[1][n].cpu().numpy(), grads[0][n].cpu().numpy()) < 1e-5, n
+    # the differentiable all-gather of the mining step and its adjoint, on RCCL's own kernels
+    # (all_gather_into_tensor / reduce_scatter_tensor; gloo in the CPU tests takes a fall-back for the latter)
+    from deepspeaker_pytorch_amd.distributed import AllGatherRows, Reducer
+    r = Reducer()
+    t = torch.randn(6, 512, device="cuda", requires_grad=True)
+    gathered = AllGatherRows.apply(t, r)
+    assert torch.equal(gathered, t.detach())
+    gathered.backward(torch.full_like(gathered, 2.0))
+    assert torch.equal(t.grad, torch.full_like(t, 2.0))
+    assert torch.equal(r.reduce_scatter_rows(t.detach()), t.detach())
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_forward_triplet_equals_three_calls(dev, precision):
+    """model.forward_triplet (one concatenated batch, three BatchNorm statistic sets, one backward pass) against
+    the reference's call pattern model(a), model(p), model(n) + accumulated backward (train_triplet.py:215-224)."""
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=6)).cuda() for i in range(3)]
+    res = []
+    for grouped in (False, True):
+        m = DeepSpeakerModel(512, 16, precision=precision)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        m = m.cuda().train()
+        outs = m.forward_triplet(*xs) if grouped else (m(xs[0]), m(xs[1]), m(xs[2]))
+        loss = TripletMarginLoss(0.1).forward(*outs)
+        loss.backward()
+        res.append((outs, loss, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}))
+    (o0, l0, g0, s0), (o1, l1, g1, s1) = res
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)                                   # same arithmetic per utterance
+    assert float(l0) == float(l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k                        # three sequential running-statistics updates
+    assert int(s1["model.bn1.num_batches_tracked"]) == 3
+    for n in g0:
+        err = float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-30))
+        assert err < 1e-5, (n, err)                                # one contraction over all pixels vs three summed
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
