@@ -593,7 +593,8 @@ class Engine:
                             save: bool = True, reducer=None, precision: str = "f32"):
         """The reference's three train-mode forwards of one step -- model(data_a), model(data_p), model(data_n),
         train_triplet.py:215 -- run in lock-step over ONE concatenated batch: same arithmetic per utterance, one
-        BatchNorm statistic set (and one running-statistics update, in call order) per member, but
+        BatchNorm statistic set (and one running-statistics update, in call order) per member (equal to three
+        calls up to the order in which per-tile partial sums are folded), but
 
           * each layer is one convolution launch over all members wherever its tiles do not straddle members
             (otherwise one launch per member, into slices of the same buffer),

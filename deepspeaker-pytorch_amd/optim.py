@@ -71,8 +71,18 @@ class _FusedBase(torch.optim.Optimizer):
             dev = params[0].device
             chunk = self._eng().lib.raw("ds_optim_chunk_elems")()
 
+            pinned = []                 # staging copies stay alive in the cache until the async uploads have run
+
+            def upload(values, dtype):
+                # Gradients are fresh tensors every step (zero_grad(set_to_none=True)), so these tables are rebuilt
+                # per step: from pinned memory and without blocking -- a pageable .to(device) would make the host
+                # wait for the whole backward pass before it can enqueue anything else.
+                h = torch.tensor(values, dtype=dtype).pin_memory() if dev.type == "cuda" else torch.tensor(values, dtype=dtype)
+                pinned.append(h)
+                return h.to(dev, non_blocking=True)
+
             def ptr_table(ts):
-                return torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(dev)
+                return upload([t.data_ptr() for t in ts], torch.int64)
 
             ct, ci = [], []
             for i, p in enumerate(params):
@@ -84,9 +94,9 @@ class _FusedBase(torch.optim.Optimizer):
                 "params": ptr_table(params), "grads": ptr_table([p.grad for p in params]),
                 "s1": ptr_table([st[state_keys[0]] for st in states]) if state_keys else None,
                 "s2": ptr_table([st[state_keys[1]] for st in states]) if need_state2 else None,
-                "numel": torch.tensor([p.numel() for p in params], dtype=torch.int64).to(dev),
-                "ct": torch.tensor(ct, dtype=torch.int32).to(dev), "ci": torch.tensor(ci, dtype=torch.int32).to(dev),
-                "n_chunks": len(ct),
+                "numel": upload([p.numel() for p in params], torch.int64),
+                "ct": upload(ct, torch.int32), "ci": upload(ci, torch.int32),
+                "n_chunks": len(ct), "pinned": pinned,
             }
             caches[len(params)] = cache
         return params, states, cache

