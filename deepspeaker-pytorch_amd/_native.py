@@ -88,6 +88,7 @@ _SIGNATURES = {
     "ds_scatter_add_rows_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_mine_workspace_floats": (c_longlong, [c_int, c_int]),
     "ds_mine_semihard_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_fc_ce_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_cross_entropy_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_cross_entropy_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_group_mean_f32": (c_int, [_P, _P, c_int, c_int, _P]),

@@ -80,6 +80,46 @@ __global__ void __launch_bounds__(256) fc_reduce_l2norm_kernel(const float *part
         for (int k = lane; k < N; k += 64) e[(size_t)r * N + k] = (f[(size_t)r * N + k] / nrm) * alpha;
 }
 
+// The softmax head's epilogue (model.py:220-223 + train_triplet.py:281-285): one wave per row reduces the split-K
+// partials (+ bias) into the logits AND takes the row maximum, the log-sum-exp over the n_cls real classes and
+// the row's loss = lse - logit[label] in the same pass -- the logits are not read back by a second kernel.
+__global__ void __launch_bounds__(256) fc_reduce_ce_kernel(const float *partial, const float *bias, float *logits,
+                                                           const long long *labels, float *row_loss, float *lse,
+                                                           int B, int N, int n_cls, int S) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = row < B ? row : B - 1;
+    float mx = -3.0e38f;
+    for (int k = lane; k < N; k += 64) {
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += partial[((size_t)s * B + r) * N + k];
+        if (bias) v += bias[k];
+        if (row < B) logits[(size_t)r * N + k] = v;
+        if (k < n_cls) mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, ds_shfl_xor(mx, m));
+    float se = 0.f;
+    if (row < B)                                        // a lane re-reads only the columns it wrote itself
+        for (int k = lane; k < n_cls; k += 64) se += expf(logits[(size_t)r * N + k] - mx);
+    se = fc_wave_sum(se);
+    const float l = mx + logf(se);
+    if (row < B && lane == 0) {
+        lse[row] = l;
+        row_loss[row] = l - logits[(size_t)r * N + labels[row]];
+    }
+}
+
+__global__ void __launch_bounds__(256) fc_mean_kernel(const float *x, float *out, int n) {
+    float *scratch = ds_dynamic_lds();
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    acc = fc_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (float)n;
+}
+
 static int fc_splits(int K) {
     const int chunks = K / CK;
     for (int s = 8; s > 1; s >>= 1)
@@ -107,5 +147,25 @@ extern "C" int ds_fc_l2norm_fwd_f32(const float *pooled, const float *w_packed, 
     if (rc) return rc;
     DS_LAUNCH(fc_reduce_l2norm_kernel, ds_ceil_div(B, 4), 256, 0, stream, (const float *)workspace, bias, f, e, B, N,
               S, alpha, eps);
+    return ds_last_launch_error();
+}
+
+// classifier GEMM + cross-entropy in one call: logits [M, N] (N = n_cls padded to 128; pad columns carry zero
+// weights), per-row loss and log-sum-exp (kept for the backward pass), loss = mean row loss
+extern "C" int ds_fc_ce_fwd_f32(const float *x, const float *w_packed, const float *bias, float *workspace,
+                                float *logits, const long long *labels, float *row_loss, float *lse, float *loss,
+                                int M, int K, int N, int n_cls, void *stream) {
+    DS_REQUIRE(x && w_packed && workspace && logits && labels && row_loss && lse && loss, DS_ERR_NULL);
+    DS_REQUIRE(M > 0 && K > 0 && N > 0 && K % (4 * CK) == 0 && N % 128 == 0 && n_cls > 0 && n_cls <= N, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(w_packed), DS_ERR_ALIGNMENT);
+    const int S = fc_splits(K), n_tiles = N / 128, m_tiles = ds_ceil_div(M, 32);
+    DS_LAUNCH(fc_splitk_kernel, m_tiles * n_tiles * S, 256, 0, stream, x, w_packed, workspace, M, K, N, S, n_tiles);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(fc_reduce_ce_kernel, ds_ceil_div(M, 4), 256, 0, stream, (const float *)workspace, bias, logits, labels,
+              row_loss, lse, M, N, n_cls, S);
+    rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(fc_mean_kernel, 1, 256, 64, stream, (const float *)row_loss, loss, M);
     return ds_last_launch_error();
 }

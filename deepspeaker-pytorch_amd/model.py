@@ -122,58 +122,102 @@ def _pad128(n: int) -> int:
     return (n + 127) // 128 * 128
 
 
+class HeadPack:
+    """Kernel-layout copies of the classifier (model.py:167): rows zero-padded to a multiple of 128, packed for the
+    forward GEMM and, transposed, for the data gradient.  Built once per parameter version (DeepSpeakerModel._head)."""
+
+    def __init__(self, eng, weight, bias):
+        n, k = weight.shape
+        self.n, self.k, self.npad = n, k, _pad128(n)
+        dev = weight.device
+        self.wpad = torch.zeros((self.npad, k), dtype=torch.float32, device=dev)
+        self.wpad[:n].copy_(weight.detach())
+        self.bpad = torch.zeros(self.npad, dtype=torch.float32, device=dev)
+        self.bpad[:n].copy_(bias.detach())
+        st = eng._stream(weight)
+        self.wp = torch.empty(self.npad * k, dtype=torch.float32, device=dev)
+        eng.lib.call("ds_pack_fc_weight_f32", eng._p(self.wpad), eng._p(self.wp), self.npad, k, 1, st)
+        self.wd = torch.empty(self.npad * k, dtype=torch.float32, device=dev)
+        eng.lib.call("ds_pack_fc_weight_dgrad_f32", eng._p(self.wpad), eng._p(self.wd), self.npad, k, 1, st)
+
+
+def _head_backward(eng, pack: HeadPack, x, gp):
+    """(dx, dW, db) of logits = x W^T + b given the padded logits gradient gp [M, Np]"""
+    from ._native import ConvShape
+    import ctypes
+    m, k = x.shape
+    st = eng._stream(x)
+    ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(m, pack.npad, k), dtype=torch.float32, device=x.device)
+    gx = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    eng.lib.call("ds_fc_l2norm_fwd_f32", eng._p(gp), eng._p(pack.wd), None, eng._p(ws), eng._p(gx), None, m, pack.npad, k,
+                 1.0, 0.0, st)                                      # dx = g Wpad
+    shp = ConvShape(1, m, 1, k, pack.npad, 1, 1)                    # dW = g^T x: a 1x1 "convolution" over the M rows
+    ws2 = torch.empty(eng.lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp)), dtype=torch.float32,
+                      device=x.device)
+    gw = torch.empty((pack.npad, k), dtype=torch.float32, device=x.device)
+    eng.lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), eng._p(x), eng._p(gp), eng._p(ws2), eng._p(gw), 0, st)
+    gb = torch.empty(pack.npad, dtype=torch.float32, device=x.device)
+    eng.lib.call("ds_colsum_f32", eng._p(gp), eng._p(gb), m, pack.npad, st)
+    return gx, gw[:pack.n], gb[:pack.n]
+
+
 class _LinearHeadFn(torch.autograd.Function):
-    """y = x W^T + b on the f32 matrix cores (split-K GEMM of fc_mfma_f32.hip); W is zero-padded to a
-    multiple of 128 rows, the returned logits are the [M, n_cls] view of the padded [M, Np] buffer."""
+    """y = x W^T + b on the f32 matrix cores (split-K GEMM of fc_mfma_f32.hip); the returned logits are the
+    [M, n_cls] view of the padded [M, Np] buffer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eng):
-        import ctypes
+    def forward(ctx, x, weight, bias, eng, pack):
         x = x.contiguous()
         m, k = x.shape
-        n = weight.shape[0]
-        npad = _pad128(n)
-        wpad = torch.zeros((npad, k), dtype=torch.float32, device=x.device)
-        wpad[:n].copy_(weight.detach())
-        bpad = torch.zeros(npad, dtype=torch.float32, device=x.device)
-        bpad[:n].copy_(bias.detach())
-        wp = torch.empty(npad * k, dtype=torch.float32, device=x.device)
-        eng.lib.call("ds_pack_fc_weight_f32", eng._p(wpad), eng._p(wp), npad, k, 1, eng._stream(x))
-        ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(m, k, npad), dtype=torch.float32, device=x.device)
-        out = torch.empty((m, npad), dtype=torch.float32, device=x.device)
-        eng.lib.call("ds_fc_l2norm_fwd_f32", eng._p(x), eng._p(wp), eng._p(bpad), eng._p(ws), eng._p(out), None, m, k,
-                     npad, 1.0, 0.0, eng._stream(x))
-        ctx.save_for_backward(x, wpad)
-        ctx.eng, ctx.n = eng, n
-        return out[:, :n]
+        ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(m, k, pack.npad), dtype=torch.float32, device=x.device)
+        out = torch.empty((m, pack.npad), dtype=torch.float32, device=x.device)
+        eng.lib.call("ds_fc_l2norm_fwd_f32", eng._p(x), eng._p(pack.wp), eng._p(pack.bpad), eng._p(ws), eng._p(out), None,
+                     m, k, pack.npad, 1.0, 0.0, eng._stream(x))
+        ctx.save_for_backward(x)
+        ctx.eng, ctx.pack = eng, pack
+        return out[:, :pack.n]
 
     @staticmethod
     def backward(ctx, g):
-        from ._native import ConvShape
-        import ctypes
-        x, wpad = ctx.saved_tensors
-        eng, n = ctx.eng, ctx.n
+        (x,) = ctx.saved_tensors
+        pack = ctx.pack
+        gp = torch.zeros((x.shape[0], pack.npad), dtype=torch.float32, device=x.device)
+        gp[:, :pack.n].copy_(g)
+        gx, gw, gb = _head_backward(ctx.eng, pack, x, gp)
+        return gx, gw, gb, None, None
+
+
+class _HeadCrossEntropyFn(torch.autograd.Function):
+    """loss = CrossEntropy(x W^T + b, labels) (model.py:220-223 + train_triplet.py:281-285) with the row maximum,
+    log-sum-exp and per-row loss taken in the GEMM's reduction epilogue (ds_fc_ce_fwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, labels, eng, pack):
+        x = x.contiguous()
         m, k = x.shape
-        npad = wpad.shape[0]
-        gp = torch.zeros((m, npad), dtype=torch.float32, device=x.device)
-        gp[:, :n].copy_(g)
-        st = eng._stream(x)
-        # dx = g Wpad
-        wd = torch.empty(npad * k, dtype=torch.float32, device=x.device)
-        eng.lib.call("ds_pack_fc_weight_dgrad_f32", eng._p(wpad), eng._p(wd), npad, k, 1, st)
-        ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(m, npad, k), dtype=torch.float32, device=x.device)
-        gx = torch.empty((m, k), dtype=torch.float32, device=x.device)
-        eng.lib.call("ds_fc_l2norm_fwd_f32", eng._p(gp), eng._p(wd), None, eng._p(ws), eng._p(gx), None, m, npad, k,
-                     1.0, 0.0, st)
-        # dW = g^T x (1x1 "convolution" over the M rows), db = column sums
-        shp = ConvShape(1, m, 1, k, npad, 1, 1)
-        ws2 = torch.empty(eng.lib.raw("ds_conv_wgrad_workspace_floats")(ctypes.byref(shp)), dtype=torch.float32,
-                          device=x.device)
-        gw = torch.empty((npad, k), dtype=torch.float32, device=x.device)
-        eng.lib.call("ds_conv_wgrad_f32", ctypes.byref(shp), eng._p(x), eng._p(gp), eng._p(ws2), eng._p(gw), 0, st)
-        gb = torch.empty(npad, dtype=torch.float32, device=x.device)
-        eng.lib.call("ds_colsum_f32", eng._p(gp), eng._p(gb), m, npad, st)
-        return gx, gw[:n], gb[:n], None
+        labels = labels.to(torch.int64).contiguous()
+        dev = x.device
+        ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(m, k, pack.npad), dtype=torch.float32, device=dev)
+        logits = torch.empty((m, pack.npad), dtype=torch.float32, device=dev)
+        row_loss, lse = torch.empty(m, dtype=torch.float32, device=dev), torch.empty(m, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        eng.lib.call("ds_fc_ce_fwd_f32", eng._p(x), eng._p(pack.wp), eng._p(pack.bpad), eng._p(ws), eng._p(logits),
+                     eng._p(labels), eng._p(row_loss), eng._p(lse), eng._p(loss), m, k, pack.npad, pack.n, eng._stream(x))
+        ctx.save_for_backward(x, logits, labels, lse)
+        ctx.eng, ctx.pack = eng, pack
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        x, logits, labels, lse = ctx.saved_tensors
+        eng, pack = ctx.eng, ctx.pack
+        m = x.shape[0]
+        gp = torch.zeros((m, pack.npad), dtype=torch.float32, device=x.device)      # pad columns stay zero
+        gl = gl.reshape(1).contiguous().float()
+        eng.lib.call("ds_cross_entropy_bwd_f32", eng._p(logits), eng._p(labels), eng._p(lse), eng._p(gl), eng._p(gp), m,
+                     pack.n, pack.npad, pack.npad, eng._stream(x))
+        gx, gw, gb = _head_backward(eng, pack, x, gp)
+        return gx, gw, gb, None, None, None
 
 
 class _CrossEntropyFn(torch.autograd.Function):
@@ -560,7 +604,28 @@ class DeepSpeakerModel(nn.Module):
         17 launches of a forward are launch-bound).  New capability; the reference has no counterpart."""
         return GraphedEmbedder(self, example)
 
+    def _head(self) -> HeadPack:
+        w, b = self.model.classifier.weight, self.model.classifier.bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if getattr(self, "_head_key", None) != key:
+            self._head_cache, self._head_key = HeadPack(get_engine(), w, b), key
+        return self._head_cache
+
+    def classify(self, embeddings):
+        """logits = classifier(embeddings) for embeddings that already exist: the softmax pre-training regime
+        (train_triplet.py:277-279) re-runs the whole network three times through `forward_classifier` to classify
+        the very rows `model(data_a)` etc. produced a moment earlier; `classify(out_a[idx])` re-uses them."""
+        _require_cuda(embeddings, "DeepSpeakerModel.classify")
+        return _LinearHeadFn.apply(embeddings, self.model.classifier.weight, self.model.classifier.bias, get_engine(),
+                                   self._head())
+
+    def classifier_loss(self, embeddings, labels):
+        """CrossEntropyLoss(classifier(embeddings), labels) (train_triplet.py:281-285, mean reduction) as one fused
+        GEMM + log-softmax + NLL; gradients flow to the classifier and into `embeddings`."""
+        _require_cuda(embeddings, "DeepSpeakerModel.classifier_loss")
+        return _HeadCrossEntropyFn.apply(embeddings, self.model.classifier.weight, self.model.classifier.bias, labels,
+                                         get_engine(), self._head())
+
     def forward_classifier(self, x):
         """reference model.py:220-223: logits = classifier(embedding x10), on the f32 matrix cores."""
-        features = self.forward(x)
-        return _LinearHeadFn.apply(features, self.model.classifier.weight, self.model.classifier.bias, get_engine())
+        return self.classify(self.forward(x))

@@ -281,6 +281,13 @@ int ds_avgpool_time_bwd_f32(const float *gpooled, const float *out, float *gx, i
                             int C, void *stream);
 
 
+/* Softmax pre-training head in one call (model.py:220-223 + train_triplet.py:281-285): logits = x W^T + b on the
+ * f32 matrix cores with row max / log-sum-exp / per-row loss taken in the split-K reduction's epilogue, then the
+ * mean.  N = n_cls padded to a multiple of 128 (zero filter rows); logits is [M, N]. */
+int ds_fc_ce_fwd_f32(const float *x, const float *w_packed, const float *bias, float *workspace, float *logits,
+                     const long long *labels, float *row_loss, float *lse, float *loss, int M, int K, int N,
+                     int n_cls, void *stream);
+
 /* ---- softmax cross-entropy of the classifier logits (nn.CrossEntropyLoss, mean reduction;
  *      train_triplet.py:281-287).  logits [M, ld] with n_cls valid columns; lse[M] and row_loss[M] are
  *      outputs of the forward that the backward re-uses; dlogits [M, ld_out], columns >= n_cls zeroed. -- */

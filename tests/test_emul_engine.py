@@ -277,7 +277,7 @@ def test_feature_store_crops():
 
 def test_classifier_head_and_cross_entropy(golden):
     """forward_classifier's GEMM + the CE of train_triplet.py:277-287, forward and backward, vs torch on CPU."""
-    from deepspeaker_pytorch_amd.model import _CrossEntropyFn, _LinearHeadFn
+    from deepspeaker_pytorch_amd.model import HeadPack, _CrossEntropyFn, _HeadCrossEntropyFn, _LinearHeadFn
     eng = Engine(emul_lib())
     rs = np.random.RandomState(12)
     M, K, N = 12, 512, 21
@@ -285,9 +285,17 @@ def test_classifier_head_and_cross_entropy(golden):
     w = torch.from_numpy((rs.randn(N, K) * 0.05).astype(np.float32)).requires_grad_(True)
     b = torch.from_numpy(rs.randn(N).astype(np.float32)).requires_grad_(True)
     labels = torch.from_numpy(rs.randint(0, N, M).astype(np.int64))
-    logits = _LinearHeadFn.apply(x, w, b, eng)
+    pack = HeadPack(eng, w, b)
+    # the fused GEMM + log-softmax + NLL (row max / lse in the reduction epilogue) must equal the two-step form
+    xf, wf, bf = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    fused = _HeadCrossEntropyFn.apply(xf, wf, bf, labels, eng, pack)
+    fused.backward()
+    logits = _LinearHeadFn.apply(x, w, b, eng, pack)
     loss = _CrossEntropyFn.apply(logits, labels, eng)
     loss.backward()
+    assert abs(float(fused) - float(loss)) < 1e-6
+    for a, r in ((xf, x), (wf, w), (bf, b)):
+        assert rel_err(a.grad.numpy(), r.grad.numpy()) < 1e-6
     xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
     lr = torch.nn.functional.linear(xr, wr, br)
     ref = torch.nn.CrossEntropyLoss()(lr, labels)

@@ -118,3 +118,68 @@ def test_graph_replay_matches_eager():
         assert torch.equal(g(x), ref)
         x2 = torch.from_numpy(O.make_input(seed=12, batch=4)).cuda()
         assert torch.equal(g(x2), m(x2))
+
+
+def test_softmax_regime_reuses_embeddings():
+    """the pre-training regime of train_triplet.py:277-287 without the three extra network forwards.
+    In eval-BatchNorm terms `classify(out[idx])` must equal `forward_classifier(data[idx])` (rows are independent),
+    the fused `classifier_loss` must equal CrossEntropyLoss over those logits, gradients reach the classifier and the
+    embeddings, and the step is shorter by about three forwards."""
+    import time
+    from deepspeaker_pytorch_amd.mining import select_triplets
+    from deepspeaker_pytorch_amd.model import CrossEntropyLoss, DeepSpeakerModel
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    m = DeepSpeakerModel(512, 16, precision="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m = m.cuda().eval()
+    B = 64
+    data = [torch.from_numpy(O.make_input(seed=60 + i, batch=B)).cuda() for i in range(3)]
+    rs = np.random.RandomState(9)
+    label_p, label_n = (torch.from_numpy(rs.randint(0, 16, B).astype(np.int64)).cuda() for _ in range(2))
+
+    def reference_style():
+        with torch.no_grad():
+            outs = [m(x) for x in data]                                        # train_triplet.py:215
+            idx = select_triplets(*outs, margin=0.1).indices                   # :251-262
+        cls = [m.forward_classifier(x[idx]) for x in data]                     # :277-279 (three more forwards)
+        labels = torch.cat([label_p[idx], label_p[idx], label_n[idx]])         # :283-284
+        return CrossEntropyLoss().forward(torch.cat(cls), labels), idx
+
+    def reuse_style():
+        with torch.no_grad():
+            outs = [m(x) for x in data]
+            idx = select_triplets(*outs, margin=0.1).indices
+        emb = torch.cat([o[idx] for o in outs]).requires_grad_(True)
+        labels = torch.cat([label_p[idx], label_p[idx], label_n[idx]])
+        return m.classifier_loss(emb, labels), emb, labels
+
+    l_ref, idx = reference_style()
+    l_new, emb, labels = reuse_style()
+    assert idx.numel() > 0
+    assert abs(float(l_ref) - float(l_new)) < 1e-5 * max(1.0, abs(float(l_ref)))
+    logits = m.classify(emb.detach())
+    assert abs(float(CrossEntropyLoss().forward(logits, labels)) - float(l_new)) < 1e-6
+    m.zero_grad()
+    l_new.backward()
+    gw = m.model.classifier.weight.grad.clone()
+    ref_w = m.model.classifier.weight.detach().clone().requires_grad_(True)
+    ref_b = m.model.classifier.bias.detach().clone().requires_grad_(True)
+    ref_e = emb.detach().clone().requires_grad_(True)
+    torch.nn.functional.cross_entropy(torch.nn.functional.linear(ref_e, ref_w, ref_b), labels).backward()
+    assert rel_err(gw.cpu().numpy(), ref_w.grad.cpu().numpy()) < 1e-5
+    assert rel_err(emb.grad.cpu().numpy(), ref_e.grad.cpu().numpy()) < 1e-5
+    # the packed classifier copies are built once per parameter version
+    assert m._head() is m._head()
+
+    def timeit(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    t_ref, t_new = timeit(reference_style), timeit(reuse_style)
+    print(f"\nsoftmax regime step (B = {B}, eval BatchNorm): three extra forwards {t_ref:.2f} ms, re-used embeddings {t_new:.2f} ms")
+    assert t_new < t_ref
