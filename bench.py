@@ -317,6 +317,10 @@ def main():
                 secondary[prec] = (e2, p2, k2)
         kt = max(3, args.steps // 4)
         et, _ = measure_train("bf16x3", kt, 2)
+        # BASELINE configs[4]: variable-length inference (100-800 frames) + enrolment scoring, same arithmetic
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import varlen_bench
+        varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=2048, dev=dev)
 
     if rank == 0:
         value = emb_per_step * args.steps / elapsed
@@ -346,6 +350,7 @@ def main():
                                  "frac_of_bf16_peak": round(emb_per_step * kt / et * 3 * FWD_FLOPS_PER_EMB / 1e12 / 2500.0, 4),
                                  "what": "train-mode forward of a/p/n (three BatchNorm statistic sets) + triplet loss + "
                                          "backward + fused Adagrad (train_triplet.py:215-224); ~3x the forward FLOPs"}
+            out["varlen"] = varlen
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out))

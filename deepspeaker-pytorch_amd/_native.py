@@ -92,6 +92,9 @@ _SIGNATURES = {
     "ds_cross_entropy_fwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_cross_entropy_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_group_mean_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ds_mask_rows": (c_int, [_P, _P, c_int, c_int, c_longlong, _P]),
+    "ds_avgpool_time_masked_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_segment_mean_f32": (c_int, [_P, _P, _P, c_int, _P]),
     "ds_roc_sweep_f32": (c_int, [_P, _P, c_int, c_float, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
     "ds_assemble_crops_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_optim_chunk_elems": (c_int, []),

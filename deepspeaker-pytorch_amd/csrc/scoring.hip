@@ -19,6 +19,50 @@ __global__ void __launch_bounds__(256) group_mean_kernel(const float *x, float *
     }
 }
 
+// out[i] = mean of x[off[i] .. off[i+1]) -- enrolment sets of different sizes (off is a prefix-sum table)
+__global__ void __launch_bounds__(256) segment_mean_kernel(const float *x, const long long *off, float *out, int n_seg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_seg) {
+        const long long a = off[i], b = off[i + 1];
+        float s = 0.f;
+        for (long long j = a; j < b; ++j) s += x[j];
+        out[i] = b > a ? s / (float)(b - a) : 0.f;
+    }
+}
+
+// ---- variable-length batches (BASELINE configs[4]) ------------------------------------------------------------
+// Utterances of different lengths share one zero-padded batch.  A convolution of the padded batch equals the
+// convolution of each utterance alone IF the rows past an utterance's own extent are zero at every layer -- they
+// then act exactly like that utterance's zero padding (same products, same accumulation order: bit-identical).
+// BatchNorm's shift and the clip make them non-zero again after every layer, so they are re-zeroed here: image b
+// keeps rows [0, lens[b]) of its [H][row_bytes] slab.  Work is proportional to the padding only.
+__global__ void __launch_bounds__(256) mask_rows_kernel(char *x, const int *lens, int H, long long row_bytes) {
+    const int b = blockIdx.x >> 3, part = blockIdx.x & 7;       // eight workgroups per image
+    const int len = lens[b] < H ? (lens[b] > 0 ? lens[b] : 0) : H;
+    const long long n16 = ((long long)(H - len) * row_bytes) >> 4;
+    f32x4 *dst = (f32x4 *)(x + ((long long)b * H + len) * row_bytes);
+    for (long long i = (long long)part * 256 + threadIdx.x; i < n16; i += 8 * 256) dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// temporal mean over the utterance's own rows: pooled[b] = sum_{h < lens[b]} x[b,h] / lens[b]  (model.py:207 applied
+// to the unpadded utterance).  Rows past lens[b] are never read.
+__global__ void __launch_bounds__(256) avgpool_time_masked_kernel(const float *x, const int *lens, float *pooled, int B,
+                                                                  int Hr, int row_elems) {
+    const int vec_per_row = row_elems >> 2;
+    const long long n = (long long)B * vec_per_row;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / vec_per_row), v = (int)(i - (long long)b * vec_per_row);
+        const int len = lens[b] < Hr ? (lens[b] > 1 ? lens[b] : 1) : Hr;
+        const f32x4 *src = (const f32x4 *)(x + (size_t)b * Hr * row_elems) + v;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < len; ++h) s += src[(size_t)h * vec_per_row];
+        const float hr = (float)len;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = s[j] / hr;
+        ((f32x4 *)(pooled + (size_t)b * row_elems))[v] = s;
+    }
+}
+
 // one thread per threshold; distances / labels are streamed through LDS 1024 at a time
 __global__ void __launch_bounds__(256) roc_sweep_kernel(const float *dist, const int *issame, int N, float t0, float dt,
                                                         int n_thr, int *tp, int *fp) {
@@ -133,5 +177,32 @@ extern "C" int ds_assemble_crops_f32(const float *features, const long long *row
     DS_REQUIRE(B > 0 && T > 0 && F > 0 && (F % 4) == 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(features) && DS_ALIGNED16(out), DS_ERR_ALIGNMENT);
     DS_LAUNCH(assemble_crops_kernel, B, 256, 0, stream, features, row_start, row_end, out, T, F);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_segment_mean_f32(const float *x, const long long *offsets, float *out, int n_seg, void *stream) {
+    DS_REQUIRE(x && offsets && out, DS_ERR_NULL);
+    DS_REQUIRE(n_seg > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(segment_mean_kernel, ds_ceil_div(n_seg, 256), 256, 0, stream, x, offsets, out, n_seg);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_mask_rows(void *x, const int *lens, int B, int H, long long row_bytes, void *stream) {
+    DS_REQUIRE(x && lens, DS_ERR_NULL);
+    DS_REQUIRE(B > 0 && H > 0 && row_bytes > 0 && (row_bytes % 16) == 0 && B < (1 << 27), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(x), DS_ERR_ALIGNMENT);
+    DS_LAUNCH(mask_rows_kernel, 8 * B, 256, 0, stream, (char *)x, lens, H, row_bytes);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_avgpool_time_masked_f32(const float *x, const int *lens, float *pooled, int B, int Hr, int Wc, int C,
+                                          void *stream) {
+    DS_REQUIRE(x && lens && pooled, DS_ERR_NULL);
+    DS_REQUIRE(B > 0 && Hr > 0 && Wc > 0 && C > 0 && (C % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(pooled), DS_ERR_ALIGNMENT);
+    const long long n = (long long)B * (Wc * C / 4);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    DS_LAUNCH(avgpool_time_masked_kernel, grid, 256, 0, stream, x, lens, pooled, B, Hr, Wc * C);
     return ds_last_launch_error();
 }

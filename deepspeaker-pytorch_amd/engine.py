@@ -338,7 +338,7 @@ class Engine:
         return e
 
     # ------------------------------------------------------------------ cached launch plan (eval)
-    def _build_eval_plan(self, x, pw: PackedWeights, folded, precision: str):
+    def _build_eval_plan(self, x, pw: PackedWeights, folded, precision: str, masked: bool = False):
         """Everything that does not change between two eval forwards of the same shape -- tile plans are
         recomputed inside the library anyway, but the Python side of a launch (shape structs, pointer
         objects, activation buffers, the stream handle lookup) costs more than the launch itself at
@@ -353,6 +353,15 @@ class Engine:
         calls = []            # (raw function, argument tuple, profile label or None, flops)
         keep = []             # tensors / structs the argument tuples point into
         AC = DS_EPI_AFFINE | DS_EPI_CLIP
+        # variable-length batch: per stage the number of rows each utterance really has; after every layer the rows
+        # past it are re-zeroed (ds_mask_rows) so that they keep acting as that utterance's zero padding
+        lens_dev = torch.zeros((len(pw.stages), B), dtype=torch.int32, device=dev) if masked else None
+
+        def mask_call(t, stage, hh):
+            if masked:
+                row_bytes = t.shape[2] * t.shape[3] * t.element_size()
+                calls.append((self.lib.raw("ds_mask_rows"), (self._p(t), self._p(lens_dev[stage]), B, hh, row_bytes, st_slot),
+                              None, 0.0))
 
         def buf(*shape, dtype=torch.float32):
             t = torch.empty(shape, dtype=dtype, device=dev)
@@ -397,16 +406,24 @@ class Engine:
                 h, w = ho, wo
             else:
                 a, h, w = conv_call(self._p(a), sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2, sc, sh, None, sw.conv_f16)
+            mask_call(a, s, h)
             cin = c
             sc, sh = folded[f"model.layer{i}.0.bn1"]
             y, _, _ = conv_call(self._p(a), sw.l_conv1, sw.l_conv1_bf16, B, h, w, c, c, 3, 1, sc, sh, None, sw.l_conv1_f16)
+            mask_call(y, s, h)
             sc, sh = folded[f"model.layer{i}.0.bn2"]
             a, _, _ = conv_call(self._p(y), sw.l_conv2, sw.l_conv2_bf16, B, h, w, c, c, 3, 1, sc, sh, a, sw.l_conv2_f16,
                                 last=(s == len(pw.stages) - 1))
+            if s < len(pw.stages) - 1:          # (the masked pool below never reads the last stage's padding rows)
+                mask_call(a, s, h)
         k = w * cin
         n_out = pw.fc_bias.numel()
         pooled = buf(B, k)
-        calls.append((self.lib.raw("ds_avgpool_time_f32"), (self._p(a), self._p(pooled), B, h, w, cin, st_slot), None, 0.0))
+        if masked:
+            calls.append((self.lib.raw("ds_avgpool_time_masked_f32"),
+                          (self._p(a), self._p(lens_dev[len(pw.stages) - 1]), self._p(pooled), B, h, w, cin, st_slot), None, 0.0))
+        else:
+            calls.append((self.lib.raw("ds_avgpool_time_f32"), (self._p(a), self._p(pooled), B, h, w, cin, st_slot), None, 0.0))
         ws_floats = self.lib.raw("ds_fc_workspace_floats")(B, k, n_out)
         if ws_floats <= 0:
             raise RuntimeError(f"ds_fc_workspace_floats({B},{k},{n_out}) failed: {ws_floats}")
@@ -415,10 +432,16 @@ class Engine:
                       (self._p(pooled), self._p(pw.fc), self._p(pw.fc_bias.detach()), self._p(ws), self._p(f), e_slot, B,
                        k, n_out, ALPHA, L2_EPS, st_slot), None, 0.0))
         keep += [pw, folded]
-        return {"calls": calls, "keep": keep, "x": x_slot, "e": e_slot, "st": st_slot, "n_out": n_out}
+        return {"calls": calls, "keep": keep, "x": x_slot, "e": e_slot, "st": st_slot, "n_out": n_out, "lens": lens_dev}
 
-    def forward_eval_planned(self, x: torch.Tensor, pw: PackedWeights, folded, precision: str = "f32") -> torch.Tensor:
-        """forward_eval through a launch plan cached per (shape, weights version, precision, device)."""
+    def forward_eval_planned(self, x: torch.Tensor, pw: PackedWeights, folded, precision: str = "f32",
+                             lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """forward_eval through a launch plan cached per (shape, weights version, precision, device).
+
+        `lengths` (int tensor [B], on the host): x is a zero-padded batch of utterances of these lengths (frames);
+        every kept row of every layer -- and hence the embedding -- is then bit-identical to the forward of the
+        utterance alone (rows past an utterance's extent are re-zeroed after each layer, the temporal mean runs
+        over its own rows)."""
         self._check(x, "input")
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError("input must be [B,1,T,F] (reference model.py:185, SURVEY F1)")
@@ -431,7 +454,7 @@ class Engine:
             raise ValueError("pack_weights(..., with_bf16=True) is required for the bf16 precisions")
         # the plan owns its intermediate activations: forwards in flight on different streams need their own
         stream_id = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
-        key = (tuple(x.shape), precision, id(pw), id(folded), x.device, stream_id)
+        key = (tuple(x.shape), precision, id(pw), id(folded), x.device, stream_id, lengths is not None)
         plans = self.__dict__.setdefault("_eval_plans", {})
         plan = plans.get(key)
         if plan is None:
@@ -441,7 +464,20 @@ class Engine:
                 del plans[k]
             if len(plans) > 16:
                 plans.clear()
-            plan = plans[key] = self._build_eval_plan(x, pw, folded, precision)
+            plan = plans[key] = self._build_eval_plan(x, pw, folded, precision, masked=lengths is not None)
+        if lengths is not None:
+            ln = lengths.to(torch.int64).cpu()
+            if ln.numel() != x.shape[0] or int(ln.min()) < 1 or int(ln.max()) > x.shape[2]:
+                raise ValueError("lengths must hold one frame count in [1, T] per utterance of the padded batch")
+            per_stage = []
+            for _ in range(len(pw.stages)):
+                ln = (ln - 1) // 2 + 1                  # rows after a 5x5 stride-2 pad-2 layer
+                per_stage.append(ln)
+            host = torch.stack(per_stage).to(torch.int32)
+            if x.is_cuda:
+                host = host.pin_memory()
+            plan["lens"].copy_(host, non_blocking=True)
+            plan["lens_host"] = host                    # keeps the pinned staging copy alive until the next call
         e = torch.empty((x.shape[0], plan["n_out"]), dtype=torch.float32, device=x.device)
         plan["x"].value, plan["e"].value = x.data_ptr(), e.data_ptr()
         plan["st"].value = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else None

@@ -32,6 +32,28 @@ def trial_scores(emb_a: torch.Tensor, emb_p: torch.Tensor, crops: int) -> torch.
     return out
 
 
+def enrolment_scores(test_emb: torch.Tensor, enrol_emb: torch.Tensor, enrol_sizes) -> torch.Tensor:
+    """Score of each trial against its claimed speaker's enrolment set -- sets of different sizes, utterances of
+    different lengths (BASELINE configs[4]).  Trial i compares test_emb[i] with the `enrol_sizes[i]` consecutive rows of
+    `enrol_emb` that make up its speaker's set and takes the MEAN of the distances, the reference's length
+    normalisation (train_triplet.py:348-350 averages a trial's crop-pair distances).  Returns [n_trials]."""
+    eng = _eng()
+    sizes = np.asarray(enrol_sizes, np.int64)
+    if sizes.ndim != 1 or len(sizes) != test_emb.shape[0] or (sizes < 1).any() or int(sizes.sum()) != enrol_emb.shape[0]:
+        raise ValueError("enrol_sizes must give one set size >= 1 per trial, summing to the rows of enrol_emb")
+    dev = test_emb.device
+    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(dev)
+    owner = torch.from_numpy(np.repeat(np.arange(len(sizes)), sizes).astype(np.int64)).to(dev)
+    n, d = enrol_emb.shape
+    expanded = torch.empty((n, d), dtype=torch.float32, device=dev)
+    eng.lib.call("ds_gather_rows_f32", eng._p(test_emb.contiguous()), eng._p(owner), eng._p(expanded), n, d,
+                 eng._stream(expanded))
+    dist = eng.pairwise_distance(expanded, enrol_emb.contiguous())
+    out = torch.empty(len(sizes), dtype=torch.float32, device=dev)
+    eng.lib.call("ds_segment_mean_f32", eng._p(dist), eng._p(offsets), eng._p(out), len(sizes), eng._stream(dist))
+    return out
+
+
 @dataclass
 class Verification:
     tpr: float

@@ -297,6 +297,18 @@ int ds_cross_entropy_bwd_f32(const float *logits, const long long *labels, const
                              const float *grad_loss, float *dlogits, int M, int n_cls, int ld, int ld_out,
                              void *stream);
 
+/* ---- variable-length batches (BASELINE configs[4]; the temporal mean pool of model.py:207 accepts any T) --------
+ * Utterances of different lengths share one zero-padded batch [B,1,Tmax,64].  ds_mask_rows re-zeroes, after every
+ * layer, the rows past each utterance's own extent (lens[b] rows of the [H][row_bytes] slab of image b are kept):
+ * those zeros then act exactly like the utterance's own zero padding, so every kept row is bit-identical to the
+ * forward of the utterance alone.  ds_avgpool_time_masked_f32 averages over the utterance's own rows. */
+int ds_mask_rows(void *x, const int *lens, int B, int H, long long row_bytes, void *stream);
+int ds_avgpool_time_masked_f32(const float *x, const int *lens, float *pooled, int B, int Hr, int Wc, int C,
+                               void *stream);
+/* out[i] = mean of x[offsets[i] .. offsets[i+1]): enrolment sets of different sizes (train_triplet.py:350 takes the
+ * mean of a trial's distances) */
+int ds_segment_mean_f32(const float *x, const long long *offsets, float *out, int n_seg, void *stream);
+
 /* ---- verification scoring on the device --------------------------------------
  * ds_group_mean_f32: score of a trial = mean over G crop-pair distances (train_triplet.py:347-350).
  * ds_roc_sweep_f32: the threshold sweep of eval_metrics.py:5-50 (predict = dist < thr; tp/fp per

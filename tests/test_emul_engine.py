@@ -390,3 +390,51 @@ def test_grouped_triplet_forward_backward_equals_three_calls(precision):
     for k, v in sep_g.items():
         err = float((grads[k] - v).norm() / v.norm().clamp_min(1e-30))
         assert err < 2e-6, (k, err)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_masked_variable_length_batch_is_bit_identical_to_single_forwards(precision):
+    """BASELINE configs[4]: utterances of different lengths in one zero-padded batch (rows past each utterance's
+    extent re-zeroed after every layer, temporal mean over its own rows) == each utterance's own forward, bitwise."""
+    eng = Engine(emul_lib())
+    n_stages = 2
+    sd = O.make_state_dict(seed=29, num_classes=4, n_stages=n_stages)
+    tsd = torch_sd(sd)
+    pw = eng.pack_weights(tsd, n_stages, with_f16=True)
+    folded = {n: eng.bn_fold(b) for n, b in make_bns(tsd, n_stages).items()}
+    lens = [7, 16, 11, 1]
+    T = 16
+    rs = np.random.RandomState(4)
+    x = torch.zeros(len(lens), 1, T, 64)
+    for i, t in enumerate(lens):
+        x[i, 0, :t] = torch.from_numpy(rs.randn(t, 64).astype(np.float32))
+    e = eng.forward_eval_planned(x, pw, folded, precision=precision, lengths=torch.tensor(lens))
+    e2 = eng.forward_eval_planned(x, pw, folded, precision=precision, lengths=torch.tensor(lens))      # plan re-use
+    assert torch.equal(e, e2)
+    for i, t in enumerate(lens):
+        alone = eng.forward_eval(x[i:i + 1, :, :t].contiguous(), pw, folded, precision=precision)
+        assert torch.equal(e[i:i + 1], alone), (precision, t)
+    # without the masks the padding leaks: the unmasked padded forward differs for the short utterances
+    plain = eng.forward_eval_planned(x, pw, folded, precision=precision)
+    assert not torch.equal(plain[0], e[0]) and torch.equal(plain[1], e[1])
+    with pytest.raises(ValueError):
+        eng.forward_eval_planned(x, pw, folded, precision=precision, lengths=torch.tensor([7, 17, 11, 1]))
+
+
+def test_enrolment_scores_over_sets_of_different_sizes():
+    from deepspeaker_pytorch_amd import scoring
+    scoring._engine_override = Engine(emul_lib())
+    try:
+        rs = np.random.RandomState(8)
+        sizes = [3, 1, 5, 2]
+        test = rs.randn(len(sizes), 64).astype(np.float32)
+        enrol = rs.randn(sum(sizes), 64).astype(np.float32)
+        got = scoring.enrolment_scores(torch.from_numpy(test), torch.from_numpy(enrol), sizes).numpy()
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        for i in range(len(sizes)):
+            d = O.pairwise_distance(np.repeat(test[i:i + 1], sizes[i], 0), enrol[off[i]:off[i + 1]])
+            assert abs(got[i] - d.mean()) < 1e-5
+        with pytest.raises(ValueError):
+            scoring.enrolment_scores(torch.from_numpy(test), torch.from_numpy(enrol), [3, 1, 5, 3])
+    finally:
+        scoring._engine_override = None

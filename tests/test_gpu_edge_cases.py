@@ -202,3 +202,31 @@ def test_classifier_head_gradients_vs_reference(golden):
         dg = grad_digest(getattr(m.model, name).weight.grad.cpu().numpy())
         ref = golden[key]
         assert np.abs(dg - ref).max() <= 5e-2 * np.abs(ref).max(), name     # (one clip mask may flip: see test_gpu_parity)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_variable_length_batches_vs_reference(golden, precision):
+    """BASELINE configs[4] through the path the tool uses (DeepSpeakerModel.embed_variable_length): utterances of 100,
+    137 (not a multiple of anything), 237, 402 and 800 frames mixed into zero-padded batches must reproduce the
+    reference's embedding of each utterance alone, and -- bitwise -- the model's own single-utterance forward."""
+    from deepspeaker_pytorch_amd import scoring
+    sd = O.make_state_dict(seed=11, num_classes=16)
+    m = build(sd, precision).eval()
+    utts, refs = [], []
+    for T in (402, 100, 800, 137, 237):
+        x = O.make_input(seed=100 + T, batch=2, frames=T)
+        for b in range(2):
+            utts.append(torch.from_numpy(x[b, 0]).cuda())
+            refs.append(golden[f"full_eval_T{T}_emb"][b])
+    with torch.no_grad():
+        e = m.embed_variable_length(utts, max_batch=4)
+        assert rel_err(e.cpu().numpy(), np.stack(refs)) < TOL[precision]
+        for i in (1, 6, 4):
+            alone = m(utts[i].reshape(1, 1, -1, 64))
+            assert torch.equal(e[i:i + 1], alone)
+        # enrolment: the mean of the distances to a speaker's utterances (train_triplet.py:348-350)
+        sc = scoring.enrolment_scores(e[:2], e[2:], [5, 3])
+    en = e[2:].cpu().numpy()
+    want = [O.pairwise_distance(np.repeat(e[0:1].cpu().numpy(), 5, 0), en[:5]).mean(),
+            O.pairwise_distance(np.repeat(e[1:2].cpu().numpy(), 3, 0), en[5:]).mean()]
+    assert np.abs(sc.cpu().numpy() - np.array(want)).max() < 1e-4
