@@ -594,7 +594,8 @@ class DeepSpeakerModel(nn.Module):
     def embed_variable_length(self, utterances, max_batch: int = 128, pad_to: int = 16):
         """Eval-mode embeddings of utterances of DIFFERENT lengths (BASELINE configs[4]: 100-800 frames; the
         temporal mean pool of model.py:207 accepts any T).  `utterances`: a sequence of [T_i, 64]
-        (or [1, T_i, 64]) float tensors on the device.  They are sorted by length, packed `max_batch` at a time into
+        (or [1, T_i, 64]) float tensors on the device, or a `data.FeatureStore` (the resident corpus: batches are
+        then one gather kernel each).  They are sorted by length, packed `max_batch` at a time into
         zero-padded batches whose length is the longest member's rounded up to `pad_to` frames (so launch plans are
         re-used), and run through the masked forward: each embedding is bit-identical to the utterance's own
         forward -- padding never leaks (Engine.forward_eval_planned(lengths=...)).  Returns [N, embedding_size] in
@@ -604,16 +605,21 @@ class DeepSpeakerModel(nn.Module):
         n = len(utterances)
         if n == 0:
             raise ValueError("no utterances")
+        store = utterances if hasattr(utterances, "crops") else None      # a data.FeatureStore: one gather per batch
         feats = []
-        for u in utterances:
-            _require_cuda(u, "DeepSpeakerModel.embed_variable_length")
-            u = u.reshape(-1, u.shape[-1])
-            if u.shape[1] != 64 or u.shape[0] < 1:
-                raise ValueError(f"expected [T, 64] utterances, got {tuple(u.shape)}")
-            feats.append(u)
-        lens = torch.tensor([u.shape[0] for u in feats], dtype=torch.int64)
+        if store is None:
+            for u in utterances:
+                _require_cuda(u, "DeepSpeakerModel.embed_variable_length")
+                u = u.reshape(-1, u.shape[-1])
+                if u.shape[1] != 64 or u.shape[0] < 1:
+                    raise ValueError(f"expected [T, 64] utterances, got {tuple(u.shape)}")
+                feats.append(u)
+            lens = torch.tensor([u.shape[0] for u in feats], dtype=torch.int64)
+            dev = feats[0].device
+        else:
+            lens = torch.tensor([store.length(i) for i in range(n)], dtype=torch.int64)
+            dev = store.features.device
         order = torch.argsort(lens, stable=True)
-        dev = feats[0].device
         out = torch.empty((n, self.embedding_size), dtype=torch.float32, device=dev)
         pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
         eng = get_engine()
@@ -621,9 +627,12 @@ class DeepSpeakerModel(nn.Module):
             idx = order[i:i + max_batch]
             ln = lens[idx]
             t_pad = int(-(-int(ln.max()) // pad_to) * pad_to)
-            x = torch.zeros((len(idx), 1, t_pad, 64), dtype=torch.float32, device=dev)
-            for r, j in enumerate(idx.tolist()):
-                x[r, 0, :feats[j].shape[0]].copy_(feats[j])
+            if store is not None:       # whole utterances from the resident corpus, zero-padded by the gather kernel
+                x = store.crops(idx.numpy(), [0] * len(idx), t_pad)
+            else:
+                x = torch.zeros((len(idx), 1, t_pad, 64), dtype=torch.float32, device=dev)
+                for r, j in enumerate(idx.tolist()):
+                    x[r, 0, :feats[j].shape[0]].copy_(feats[j])
             e = eng.forward_eval_planned(x, pw, self._folded(), precision=self.precision, lengths=ln)
             out[idx.to(dev)] = e
         return out

@@ -224,6 +224,9 @@ def test_variable_length_batches_vs_reference(golden, precision):
         for i in (1, 6, 4):
             alone = m(utts[i].reshape(1, 1, -1, 64))
             assert torch.equal(e[i:i + 1], alone)
+        # the same utterances from a device-resident corpus (one gather kernel per batch)
+        from deepspeaker_pytorch_amd.data import FeatureStore
+        assert torch.equal(m.embed_variable_length(FeatureStore([u.cpu().numpy() for u in utts]), max_batch=4), e)
         # enrolment: the mean of the distances to a speaker's utterances (train_triplet.py:348-350)
         sc = scoring.enrolment_scores(e[:2], e[2:], [5, 3])
     en = e[2:].cpu().numpy()
