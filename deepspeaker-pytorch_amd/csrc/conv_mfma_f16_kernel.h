@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_WAVES_PER_SIMD(OCC) conv_mfma
         }
     }
     DS_F16_STAMP(6);
+    DS_F16_STAMP(6);
     f32x4 st[NIT];                              // 8 halfs each, moved as 16 opaque bytes
     if constexpr (PREF) {
 #pragma unroll
@@ -256,6 +257,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_WAVES_PER_SIMD(OCC) conv_mfma
         }
         out_off[m] = off;
     }
+    DS_F16_STAMP(7);
     DS_F16_STAMP(7);
     // Which pixel of its 32-pixel sub-tile a lane owns is free (the epilogue un-permutes): it is chosen so
     // that the two 16-lane SERVICE GROUPS of a ds_read_b128 -- lanes {0-3,12-15,20-27} and {4-11,16-19,
