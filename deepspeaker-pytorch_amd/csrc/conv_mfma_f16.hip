@@ -4,7 +4,6 @@
 // channels-last in HBM, products run on v_mfma_f32_32x32x16_f16 with f32 accumulation.
 #include <ds_device.h>
 #include <algorithm>
-#include <cstdlib>
 #include "ds_common.h"
 
 #include "conv_mfma_f16_kernel.h"
@@ -65,26 +64,17 @@ static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in
     return n ? total / n : 1.0;
 }
 
-struct TileCfgH { int MT, NTILE, WM, NTHR, occ; };
-constexpr int kNumCfgH = 9;
+struct TileCfgH { int MT, NTILE, WM, NTHR; };
+constexpr int kNumCfgH = 7;
 constexpr TileCfgH kCfgH[kNumCfgH] = {
-    {160, 128, 1, 128, 1},     // <KS,5,2,1,2>: two waves, 160x64 register tile each
-    {160, 256, 1, 256, 1},     // <KS,5,2,1,4>
-    {320, 128, 2, 256, 1},     // <KS,5,2,2,2>
-    {320, 64, 2, 128, 1},      // <KS,5,2,2,1>: the 2-wave shape for 64-channel layers
-    {128, 128, 1, 128, 1},     // <KS,4,2,1,2>: 128x64 register tiles where 160-row tiles quantise badly
-    {128, 256, 1, 256, 1},     // <KS,4,2,1,4>
-    {640, 64, 4, 256, 1},      // <KS,5,2,4,1>: four waves on a 64-channel layer
-    // two waves per SIMD (four 2-wave workgroups per CU, 40 KiB of LDS each): the shallow contractions
-    {256, 64, 2, 128, 2},      // <KS,4,2,2,1,..,OCC=2>
-    {128, 128, 1, 128, 2},     // <KS,4,2,1,2,..,OCC=2>
+    {160, 128, 1, 128},     // <KS,5,2,1,2>: two waves, 160x64 register tile each
+    {160, 256, 1, 256},     // <KS,5,2,1,4>
+    {320, 128, 2, 256},     // <KS,5,2,2,2>
+    {320, 64, 2, 128},      // <KS,5,2,2,1>: the 2-wave shape for 64-channel layers
+    {128, 128, 1, 128},     // <KS,4,2,1,2>: 128x64 register tiles where 160-row tiles quantise badly
+    {128, 256, 1, 256},     // <KS,4,2,1,4>
+    {640, 64, 4, 256},      // <KS,5,2,4,1>: four waves on a 64-channel layer
 };
-// contraction depth (KS*KS*Cin) up to which a workgroup's fixed prologue + epilogue outweigh its MFMA stream enough
-// for the two-waves-per-SIMD shapes to win (measured: stages 1-2); DS_F16_OCC2_MAXK overrides it for experiments
-static int occ2_max_k() {
-    static const int v = [] { const char *e = getenv("DS_F16_OCC2_MAXK"); return e ? atoi(e) : 1600; }();
-    return v;
-}
 constexpr size_t kLdsTotal = 160 * 1024;     // per CU
 
 static size_t epi_bytes(const TileCfgH &cf) {
@@ -110,24 +100,19 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
     const int IS = s->stride;
     double best = -1.0;
     int bc = -1, brt = 0, bni = 0, bdb = 0, bck = 32;
-    const bool shallow = s->KS * s->KS * s->Cin <= occ2_max_k();
-    auto search = [&](int occ) {
     for (int c = 0; c < kNumCfgH; ++c) {
         const TileCfgH &cf = kCfgH[c];
         if (s->Cout % cf.NTILE) continue;
-        if (cf.occ != occ) continue;
-        const int wg_per_cu = cf.occ * 256 / cf.NTHR;
+        const int wg_per_cu = 256 / cf.NTHR;
         const size_t lds_cap = kLdsTotal / wg_per_cu - 64;
         // (two tiles of 32 channels) > (two tiles of 16 channels: 5x5 stride-2 layers, whose input tile is 4x the
-        // output tile) > (one tile of 32 channels: two barriers and exposed LDS writes per chunk) > (one of 16)
-        for (int mode = allow_db ? 0 : 2; mode < 4; ++mode) {
-            const int db = mode < 2, ck = (mode & 1) ? 16 : 32;
-            if ((mode & 1) && s->KS != 5) continue;
-            if (mode == 3 && cf.occ != 2) continue;
-            if (db && cf.occ == 2) continue;
-            if (force_c16 && s->KS == 5 && !(mode & 1)) continue;
+        // output tile) > (one tile of 32 channels: two barriers and exposed LDS writes per chunk)
+        for (int mode = allow_db ? 0 : 2; mode < 3; ++mode) {
+            const int db = mode < 2, ck = mode == 1 ? 16 : 32;
+            if (mode == 1 && s->KS != 5) continue;
+            if (force_c16 && s->KS == 5 && mode != 1) continue;
             const int PSH = ds_f16_record_bytes(ck);
-            const long long item_cap = ((db || cf.occ == 2) ? 16 : 32) * cf.NTHR;
+            const long long item_cap = (db ? 16 : 32) * cf.NTHR;
             for (int rt = 1; rt <= Ho; ++rt) {
                 if ((long long)rt * Wo > cf.MT) break;
                 const int segs_per_img = ds_ceil_div(Ho, rt);
@@ -147,17 +132,14 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
                 const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * wg_per_cu;
                 if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
                 else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
-                if (mode & 1) eff *= 0.97;
-                if (!db && cf.occ == 1) eff *= (s->KS == 3 ? 0.90 : 0.85);
-                static const int pref[kNumCfgH] = {6, 4, 3, 5, 2, 1, 0, 8, 7};
+                if (mode == 1) eff *= 0.97;
+                if (mode == 2) eff *= (s->KS == 3 ? 0.90 : 0.85);
+                static const int pref[kNumCfgH] = {6, 4, 3, 5, 2, 1, 0};
                 eff += 1e-9 * rt + 1e-6 * pref[c];
                 if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; bdb = db; bck = ck; }
             }
         }
     }
-    };
-    search(shallow ? 2 : 1);
-    if (bc < 0 && shallow) search(1);            // no two-waves-per-SIMD shape fits (very wide maps)
     if (bc < 0) return DS_ERR_UNSUPPORTED;
     const TileCfgH &cf = kCfgH[bc];
     ConvKH &k = pl.k;
@@ -256,8 +238,7 @@ extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const 
 #ifdef DS_F16_PROBE
     k.probe = g_f16_probe;
 #endif
-    if (kCfgH[pl.cfg].occ == 2) { if (s->KS == 3) ds_f16_launch_k3o2(pl, stream); else ds_f16_launch_k5o2(pl, stream); }
-    else if (s->KS == 3) { if (pl.db) ds_f16_launch_k3db(pl, stream); else ds_f16_launch_k3sb(pl, stream); }
+    if (s->KS == 3) { if (pl.db) ds_f16_launch_k3db(pl, stream); else ds_f16_launch_k3sb(pl, stream); }
     else if (pl.ck == 16) ds_f16_launch_k5c16(pl, stream);
     else            { if (pl.db) ds_f16_launch_k5db(pl, stream); else ds_f16_launch_k5sb(pl, stream); }
     return ds_last_launch_error();

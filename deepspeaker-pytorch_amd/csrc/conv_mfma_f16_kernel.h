@@ -61,21 +61,14 @@ void ds_f16_launch_k3sb(const PlanH &pl, void *stream);
 void ds_f16_launch_k5db(const PlanH &pl, void *stream);
 void ds_f16_launch_k5sb(const PlanH &pl, void *stream);
 void ds_f16_launch_k5c16(const PlanH &pl, void *stream);    // 16-channel chunks, double-buffered
-void ds_f16_launch_k3o2(const PlanH &pl, void *stream);     // two waves per SIMD (shallow contractions)
-void ds_f16_launch_k5o2(const PlanH &pl, void *stream);
 
 #ifdef DS_F16_KERNEL_TU
 namespace {
 
 // NIT: 16-byte staging items per thread and chunk (compile time: all loads of a chunk are in flight together).
 // DB:  two pixel-tile buffers in LDS; requires the register prefetch (NIT <= 16).
-// OCC: wavefronts per SIMD the kernel is built for.  1: the register tile takes most of the 512-entry file and the
-//      wave hides its own latencies (prefetch through registers, deep filter ring).  2: a 128x64 tile in half the
-//      file, no register prefetch, a short ring -- for layers whose contraction is so shallow (K <= 1600: stages 1-2)
-//      that a workgroup spends more time in its prologue and epilogue than in the MFMA stream: the second wave of
-//      the SIMD runs its MFMA stream meanwhile.
-template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT, bool DB, int CKH = 32, int OCC = 1>
-__global__ void __launch_bounds__(WM * WN * 64) DS_WAVES_PER_SIMD(OCC) conv_mfma_f16_kernel(const ConvKH p) {
+template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT, bool DB, int CKH = 32>
+__global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f16_kernel(const ConvKH p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = MSUB * WM * 32;
     constexpr int NTILE = NSUB * WN * 32;
@@ -88,10 +81,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_WAVES_PER_SIMD(OCC) conv_mfma
 #define DS_F16_RING_K3 6
 #define DS_F16_RING_K5 5
 #endif
-    constexpr int RU = (KS == 3) ? (OCC == 2 ? 3 : KPT == 2 ? DS_F16_RING_K3 : 9) : DS_F16_RING_K5;   // filter ring, in units; NU % RU == 0
+    constexpr int RU = (KS == 3) ? (KPT == 2 ? DS_F16_RING_K3 : 9) : DS_F16_RING_K5;   // filter ring, in units; NU % RU == 0
     constexpr int NMF = MSUB * NSUB;                // MFMAs per unit
-    constexpr bool PREF = OCC == 1 && (DB || NIT <= 16);    // next chunk's pixels ride in registers through the taps
-    static_assert(OCC == 1 || (!DB && MSUB * NSUB <= 8), "two waves per SIMD: 128 accumulator registers, one pixel tile");
+    constexpr bool PREF = DB || NIT <= 16;          // next chunk's pixels ride in registers through the taps
     static_assert(NU % RU == 0, "ring slots must be chunk-invariant");
     static_assert(!DB || NIT <= 16, "double buffering needs the register prefetch");
 
@@ -161,7 +153,6 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_WAVES_PER_SIMD(OCC) conv_mfma
     // pixel each.  Item idx -> (quarter q, column c, valid row) in segment order; slots past the last item
     // load x[0..7] and drop it into the unused pad bytes of pixel record 0: the chunk loop has no branches.
     int g_off[NIT], l_off[NIT];
-    DS_F16_STAMP(5);
     __syncthreads();                            // seg_lo / seg_cnt are complete
     {
         const int q = tid % IPP;
@@ -480,16 +471,6 @@ static void launch_nit_h(const PlanH &pl, void *stream) {
         DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 16, DB, CK>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
     else if constexpr (!DB)
         DS_LAUNCH_BIG_LDS((conv_mfma_f16_kernel<KS, MSUB, NSUB, WM, WN, 32, false, CK>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
-}
-
-// two waves per SIMD: 128x64 register tiles, two-wave workgroups, four workgroups per CU (the planner keeps the
-// staging at <= 16 items per thread for these shapes)
-template <int KS, int CK>
-static void launch_occ2_h(const PlanH &pl, void *stream) {
-    if (pl.cfg == 7)                // 256x64
-        DS_LAUNCH((conv_mfma_f16_kernel<KS, 4, 2, 2, 1, 16, false, CK, 2>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
-    else                            // 128x128
-        DS_LAUNCH((conv_mfma_f16_kernel<KS, 4, 2, 1, 2, 16, false, CK, 2>), pl.grid, 128, pl.lds_bytes, stream, pl.k);
 }
 
 template <int KS, bool DB, int CK = 32>

@@ -96,7 +96,6 @@ __device__ __forceinline__ void ds_buffer_store_f32(ds_buffer b, unsigned byte_o
 // Kernels built around a register tile that takes most of the 512-entry file run one wavefront per SIMD by design;
 // saying so lets the register allocator use the whole file instead of aiming at a higher occupancy.
 #define DS_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
-#define DS_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 // 16-byte aligned base of the dynamic LDS allocation (no static __shared__ objects are
 // declared anywhere, so the base is the start of the workgroup's LDS segment)

@@ -149,7 +149,6 @@ static inline unsigned long long ds_ballot(int pred) {
 
 #define DS_OPAQUE_VGPR(x) ((void)0)
 #define DS_ONE_WAVE_PER_SIMD
-#define DS_WAVES_PER_SIMD(n)
 
 static inline float *ds_dynamic_lds() { return emu::dynamic_lds(); }
 
