@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     // pixel each.  Item idx -> (quarter q, column c, valid row) in segment order; slots past the last item
     // load x[0..7] and drop it into the unused pad bytes of pixel record 0: the chunk loop has no branches.
     int g_off[NIT], l_off[NIT];
+    DS_F16_STAMP(5);
     __syncthreads();                            // seg_lo / seg_cnt are complete
     {
         const int q = tid % IPP;
@@ -226,7 +227,6 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         }
     }
     DS_F16_STAMP(6);
-    DS_F16_STAMP(6);
     f32x4 st[NIT];                              // 8 halfs each, moved as 16 opaque bytes
     if constexpr (PREF) {
 #pragma unroll
@@ -248,7 +248,6 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         }
         out_off[m] = off;
     }
-    DS_F16_STAMP(7);
     DS_F16_STAMP(7);
     // Which pixel of its 32-pixel sub-tile a lane owns is free (the epilogue un-permutes): it is chosen so
     // that the two 16-lane SERVICE GROUPS of a ds_read_b128 -- lanes {0-3,12-15,20-27} and {4-11,16-19,

@@ -61,7 +61,6 @@ for (h, w, ci, co, k, s_, res) in LAYERS:
     ph = np.diff(t[:, :5], axis=1)
     med = np.median(ph, axis=0)
     fine = [np.median(t[:, 5] - t[:, 0]), np.median(t[:, 6] - t[:, 5]), np.median(t[:, 7] - t[:, 6]), np.median(t[:, 1] - t[:, 7])]
-    fine = [np.median(t[:, 5] - t[:, 0]), np.median(t[:, 6] - t[:, 5]), np.median(t[:, 7] - t[:, 6]), np.median(t[:, 1] - t[:, 7])]
     span = (t[:, 4].max() - t[:, 0].min())
     print(f"conv{k}x{k}s{s_} {ci}->{co} {ho}x{wo}: {e0.elapsed_time(e1) * 1e3:6.0f} us, {n} wgs, tile {out8[0]}x{out8[1]} db/nit {out8[7]}; "
           f"ticks(10ns) prologue {med[0]:.0f} | mfma stream {med[1]:.0f} | barrier {med[2]:.0f} | epilogue {med[3]:.0f} | "
