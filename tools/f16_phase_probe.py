@@ -64,4 +64,6 @@ for (h, w, ci, co, k, s_, res) in LAYERS:
     span = (t[:, 4].max() - t[:, 0].min())
     print(f"conv{k}x{k}s{s_} {ci}->{co} {ho}x{wo}: {e0.elapsed_time(e1) * 1e3:6.0f} us, {n} wgs, tile {out8[0]}x{out8[1]} db/nit {out8[7]}; "
           f"ticks(10ns) prologue {med[0]:.0f} | mfma stream {med[1]:.0f} | barrier {med[2]:.0f} | epilogue {med[3]:.0f} | "
-          f"wg total {np.median(t[:, 4] - t[:, 0]):.0f}; launch span {span:.0f}")
+          f"wg total {np.median(t[:, 4] - t[:, 0]):.0f}")
+    print(f"      prologue = ring preload + segment table {fine[0]:.0f} / barrier + descriptors {fine[1]:.0f} / "
+          f"load issue + zero fill + row table {fine[2]:.0f} / fragment offsets {fine[3]:.0f}")
