@@ -8,7 +8,8 @@ SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJD)/%.o,$(SRCS))
 HDRS  := $(wildcard $(CSRC)/*.h) include/deepspeaker_hip.h
 LIB   := $(PKG)/libdeepspeaker_hip.so
-FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude -Wall -Wno-unused-function -Wno-pass-failed
+EXTRA ?=
+FLAGS := $(EXTRA) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$(CSRC) -Iinclude -Wall -Wno-unused-function -Wno-pass-failed
 
 all: $(LIB)
 

@@ -82,6 +82,9 @@ typedef unsigned int ds_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ds_buffer_store_b64(ds_buffer b, unsigned byte_off, ds_u32x2 v) {
     __builtin_amdgcn_raw_buffer_store_b64(v, b, (int)byte_off, 0, 0);
 }
+__device__ __forceinline__ ds_u32x2 ds_buffer_load_b64(ds_buffer b, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(b, (int)byte_off, 0, 0);
+}
 __device__ __forceinline__ float ds_buffer_load_f32(ds_buffer b, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, 0, 0));
 }

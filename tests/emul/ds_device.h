@@ -126,6 +126,11 @@ typedef unsigned int ds_u32x2 __attribute__((ext_vector_type(2)));
 static inline void ds_buffer_store_b64(ds_buffer b, unsigned byte_off, ds_u32x2 v) {
     if ((unsigned long long)byte_off + 8 <= b.bytes) memcpy(b.base + byte_off, &v, 8);
 }
+static inline ds_u32x2 ds_buffer_load_b64(ds_buffer b, unsigned byte_off) {
+    ds_u32x2 v = {0u, 0u};
+    if ((unsigned long long)byte_off + 8 <= b.bytes) memcpy(&v, b.base + byte_off, 8);
+    return v;
+}
 static inline float ds_buffer_load_f32(ds_buffer b, unsigned byte_off) {
     float v = 0.0f;
     if ((unsigned long long)byte_off + 4 <= b.bytes) memcpy(&v, b.base + byte_off, 4);
