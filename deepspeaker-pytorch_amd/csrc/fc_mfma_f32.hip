@@ -68,8 +68,12 @@ __global__ void __launch_bounds__(256) fc_reduce_l2norm_kernel(const float *part
     const int r = row < B ? row : B - 1;
     float ss = 0.f;
     for (int k = lane; k < N; k += 64) {
+        float pv[8];                            // S <= 8 (fc_splits): all partials of a column in flight together
+#pragma unroll
+        for (int s = 0; s < 8; ++s) pv[s] = s < S ? partial[((size_t)s * B + r) * N + k] : 0.f;
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += partial[((size_t)s * B + r) * N + k];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v += pv[s];         // fixed order: s = 0 .. S-1 (+ zeros)
         if (bias) v += bias[k];
         if (row < B) f[(size_t)r * N + k] = v;
         ss += v * v;
@@ -91,8 +95,12 @@ __global__ void __launch_bounds__(256) fc_reduce_ce_kernel(const float *partial,
     const int r = row < B ? row : B - 1;
     float mx = -3.0e38f;
     for (int k = lane; k < N; k += 64) {
+        float pv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) pv[s] = s < S ? partial[((size_t)s * B + r) * N + k] : 0.f;
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += partial[((size_t)s * B + r) * N + k];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v += pv[s];
         if (bias) v += bias[k];
         if (row < B) logits[(size_t)r * N + k] = v;
         if (k < n_cls) mx = fmaxf(mx, v);

@@ -426,9 +426,12 @@ __global__ void __launch_bounds__(256) mine_merge_kernel(const float *partial, l
 // dst[i,:] = src[idx[i],:]  (idx < 0 -> zeros)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const float *src, const long long *idx, float *dst, int N,
                                                           int D) {
-    const int i = blockIdx.x;
+    // long rows (whole utterances: 10240 floats) are split over several workgroups: blockIdx = row * parts + part
+    const int parts = gridDim.x / N;
+    const int i = blockIdx.x / parts, part = blockIdx.x - i * parts;
     const long long j = idx[i];
-    for (int k = threadIdx.x; k < D; k += 256) dst[(size_t)i * D + k] = j >= 0 ? src[(size_t)j * D + k] : 0.0f;
+    for (int k = part * 256 + threadIdx.x; k < D; k += parts * 256)
+        dst[(size_t)i * D + k] = j >= 0 ? src[(size_t)j * D + k] : 0.0f;
 }
 
 // dst[j,:] (+)= sum over {i : idx[i] == j} of g[i,:], i ascending (deterministic; one workgroup per dst row)
@@ -448,7 +451,8 @@ __global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float *g, c
 extern "C" int ds_gather_rows_f32(const float *src, const long long *idx, float *dst, int N, int D, void *stream) {
     DS_REQUIRE(src && idx && dst, DS_ERR_NULL);
     DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
-    DS_LAUNCH(gather_rows_kernel, N, 256, 0, stream, src, idx, dst, N, D);
+    const int parts = D >= 4096 ? 8 : 1;
+    DS_LAUNCH(gather_rows_kernel, N * parts, 256, 0, stream, src, idx, dst, N, D);
     return ds_last_launch_error();
 }
 
