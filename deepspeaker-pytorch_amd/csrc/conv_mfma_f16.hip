@@ -38,6 +38,43 @@ __global__ void __launch_bounds__(256) cast_f16_to_f32_kernel(const _Float16 *x,
         y[i] = (float)x[i];
 }
 
+// split-K second pass: y = epilogue(sum_s partial[s]) -- fixed summation order; 8 channels per thread
+__global__ void __launch_bounds__(256) conv_f16_splitk_reduce_kernel(const float *partial, int S, unsigned stride,
+                                                                     const float *scale, const float *shift,
+                                                                     const _Float16 *res, void *y, long long n8, int Cout,
+                                                                     int flags) {
+    const float clip_lo = (flags & DS_EPI_CLIP) ? 0.0f : -__builtin_inff();
+    const float clip_hi = (flags & DS_EPI_CLIP) ? 20.0f : __builtin_inff();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const long long e = i * 8;
+        const int c = (int)(e % Cout);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            a0 += *(const f32x4 *)(partial + (size_t)s * stride + e);
+            a1 += *(const f32x4 *)(partial + (size_t)s * stride + e + 4);
+        }
+        f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (flags & DS_EPI_RESIDUAL) r = *(const f16x8 *)(res + e);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = j < 4 ? a0[j] : a1[j - 4];
+            if (flags & DS_EPI_AFFINE) t = t * scale[c + j] + shift[c + j];
+            t += (float)r[j];
+            o[j] = fminf(fmaxf(t, clip_lo), clip_hi);
+        }
+        if (flags & DS_EPI_OUT_F32) {
+            *(f32x4 *)((float *)y + e) = f32x4{o[0], o[1], o[2], o[3]};
+            *(f32x4 *)((float *)y + e + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        } else {
+            f16x8 h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (_Float16)o[j];
+            *(f16x8 *)((_Float16 *)y + e) = h;
+        }
+    }
+}
+
 // LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for a candidate row pitch: the two 16-lane
 // service groups of lanes 0..31 each hold 16 consecutive pixels of the M tile (`lpix` in the kernel).
 // Bank slot of a record = (record * PSH / 16) mod 16.
@@ -217,14 +254,31 @@ static long long *g_f16_probe = nullptr;
 extern "C" void ds_f16_set_probe(long long *buf) { g_f16_probe = buf; }
 #endif
 
-extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
-                               const float *shift, const void *residual_f16, void *y, int flags, void *stream) {
+// How many ways a small launch splits its contraction: enough workgroups for two per CU, at least one chunk each
+static int splitk_ways(const PlanH &pl, const ds_conv_shape *s) {
+    const int n_chunks = s->Cin / pl.ck;
+    int ways = 1;
+    while (ways * 2 <= 8 && ways * 2 <= n_chunks && (long long)pl.grid * ways * 2 <= 512) ways *= 2;
+    return ways;
+}
+
+extern "C" long long ds_conv_f16_splitk_workspace_bytes(const ds_conv_shape *s) {
+    PlanH pl;
+    int rc = plan_f16(pl, s);
+    if (rc != DS_OK) return rc;
+    const int ways = splitk_ways(pl, s);
+    return ways > 1 ? (long long)ways * s->B * pl.k.Ho * pl.k.Wo * s->Cout * 4 : 0;
+}
+
+static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
+                        const float *shift, const void *residual_f16, void *y, int flags, void *workspace,
+                        long long ws_bytes, void *stream) {
     DS_REQUIRE(x_f16 && w_f16 && y, DS_ERR_NULL);
     DS_REQUIRE(!(flags & DS_EPI_AFFINE) || (scale && shift), DS_ERR_NULL);
     DS_REQUIRE(!(flags & DS_EPI_RESIDUAL) || residual_f16, DS_ERR_NULL);
     DS_REQUIRE(!(flags & DS_EPI_STATS), DS_ERR_UNSUPPORTED);            // eval path only
     DS_REQUIRE(DS_ALIGNED16(x_f16) && DS_ALIGNED16(w_f16) && DS_ALIGNED16(y) && DS_ALIGNED16(residual_f16) &&
-                   DS_ALIGNED16(scale) && DS_ALIGNED16(shift), DS_ERR_ALIGNMENT);
+                   DS_ALIGNED16(scale) && DS_ALIGNED16(shift) && DS_ALIGNED16(workspace), DS_ERR_ALIGNMENT);
     PlanH pl;
     int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER), (flags & DS_CONV_HINT_CHUNK16) != 0);
     if (rc != DS_OK) return rc;
@@ -235,11 +289,41 @@ extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const 
     const long long n_out = (long long)s->B * k.Ho * k.Wo * s->Cout;
     k.y_bytes = (unsigned)(n_out * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
     k.res_bytes = (unsigned)(n_out * 2);
+    const int n_chunks = s->Cin / pl.ck;
+    int ways = workspace ? splitk_ways(pl, s) : 1;
+    if (ways > 1 && ws_bytes < (long long)ways * n_out * 4) ways = 1;
+    k.tiles = pl.grid;
+    k.chunks_per_split = ds_ceil_div(n_chunks, ways);
+    k.n_splits = ds_ceil_div(n_chunks, k.chunks_per_split);
+    k.partial = (float *)workspace;
+    k.partial_elems = (unsigned)n_out;
+    pl.grid *= k.n_splits;
 #ifdef DS_F16_PROBE
     k.probe = g_f16_probe;
 #endif
     if (s->KS == 3) { if (pl.db) ds_f16_launch_k3db(pl, stream); else ds_f16_launch_k3sb(pl, stream); }
     else if (pl.ck == 16) ds_f16_launch_k5c16(pl, stream);
     else            { if (pl.db) ds_f16_launch_k5db(pl, stream); else ds_f16_launch_k5sb(pl, stream); }
+    rc = ds_last_launch_error();
+    if (rc || k.n_splits == 1) return rc;
+    const long long n8 = n_out / 8;
+    long long g = (n8 + 255) / 256;
+    DS_LAUNCH(conv_f16_splitk_reduce_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, (const float *)workspace,
+              k.n_splits, k.partial_elems, scale, shift, (const _Float16 *)residual_f16, y, n8, s->Cout, flags);
     return ds_last_launch_error();
+}
+
+extern "C" int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
+                               const float *shift, const void *residual_f16, void *y, int flags, void *stream) {
+    return conv_fwd_f16(s, x_f16, w_f16, scale, shift, residual_f16, y, flags, nullptr, 0, stream);
+}
+
+// The same convolution for SMALL launches (serving latency): when the tile grid cannot fill the GPU, the contraction
+// is split over up to 8 workgroups per tile (raw f32 partial sums in `workspace`, ds_conv_f16_splitk_workspace_bytes)
+// and a second kernel folds them in fixed order and applies the epilogue.  Large launches take the one-pass path.
+// Results differ from the one-pass path by the f32 summation order only.
+extern "C" int ds_conv_fwd_f16_splitk(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
+                                      const float *shift, const void *residual_f16, void *y, int flags, void *workspace,
+                                      long long ws_bytes, void *stream) {
+    return conv_fwd_f16(s, x_f16, w_f16, scale, shift, residual_f16, y, flags, workspace, ws_bytes, stream);
 }

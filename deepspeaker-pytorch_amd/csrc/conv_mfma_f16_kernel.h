@@ -38,6 +38,11 @@ struct ConvKH {
     int n_ntiles;
     int flags;
     unsigned y_bytes, res_bytes;    // sizes for the buffer descriptors
+    // split-K (small launches: serving latency): workgroup blockIdx = split * tiles + tile contracts the input-channel
+    // chunks [split * chunks_per_split, ...) and stores its raw f32 accumulators into partial + split * partial_elems
+    int tiles, n_splits, chunks_per_split;
+    float *partial;
+    unsigned partial_elems;
 #ifdef DS_F16_PROBE                 // tools/f16_phase_probe.py builds: s_memtime stamps of the phases of each workgroup
     long long *probe;
 #endif
@@ -92,8 +97,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int tile_n = blockIdx.x % p.n_ntiles;
-    const int tile_m = blockIdx.x / p.n_ntiles;
+    const int split = (int)blockIdx.x / p.tiles, tile = (int)blockIdx.x - split * p.tiles;
+    const int tile_n = tile % p.n_ntiles;
+    const int tile_m = tile / p.n_ntiles;
     const int seg0 = tile_m * p.NI;
     const int pix_per_seg = p.RT * p.Wo;
     const int tile_pix = p.NI * p.seg_pix;
@@ -107,7 +113,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     int *seg_cnt = seg_lo + p.NI;                              // [NI] number of in-image rows
 
     // the first filter fragments are requested before anything else: their latency hides behind the tables
-    const int n_chunks = p.Cin / CKH;
+    const int c0 = split * p.chunks_per_split;                  // this workgroup's chunk range [c0, c0 + n_chunks)
+    const int n_chunks = (p.Cin / CKH - c0) < p.chunks_per_split ? (p.Cin / CKH - c0) : p.chunks_per_split;
     const int n_base = tile_n * NTILE + wn * NSUB * 32;
     const size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);      // in halfs
     const size_t w_kc_stride = (size_t)NT * p.Cout * 16;                // one 16-channel slab: [tap][Cout][16]
@@ -123,7 +130,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
 #pragma unroll
     for (int d = 0; d < RU; ++d)
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(0, d) + (size_t)ns * 32 * 16);
+        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(c0, d) + (size_t)ns * 32 * 16);
 
     const float rcp_pps = 1.0f / (float)pix_per_seg, rcp_wc = 1.0f / (float)p.Wo, rcp_w = 1.0f / (float)p.W,
                 rcp_spi = 1.0f / (float)p.segs_per_img;
@@ -230,7 +237,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     f32x4 st[NIT];                              // 8 halfs each, moved as 16 opaque bytes
     if constexpr (PREF) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
+        for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + c0 * CKH);
     }
     // ---- everything below overlaps the first chunk's loads ----
     // Only in-image pixels are ever staged: the zero halo (and the row padding) is written once, here.
@@ -330,12 +337,12 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
 #pragma unroll
         for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
         __syncthreads();
-        for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) {
-            char *b0 = lds + (chunk & 1) * tile_bytes, *b1 = lds + ((chunk & 1) ^ 1) * tile_bytes;
-            run_chunk(std::false_type{}, chunk, b0, b1);
+        for (int i = 0; i + 1 < n_chunks; ++i) {
+            char *b0 = lds + (i & 1) * tile_bytes, *b1 = lds + ((i & 1) ^ 1) * tile_bytes;
+            run_chunk(std::false_type{}, c0 + i, b0, b1);
             __syncthreads();
         }
-        run_chunk(std::true_type{}, n_chunks - 1, lds + ((n_chunks - 1) & 1) * tile_bytes, lds);
+        run_chunk(std::true_type{}, c0 + n_chunks - 1, lds + ((n_chunks - 1) & 1) * tile_bytes, lds);
     } else {
         auto stage_chunk = [&](int chunk) __attribute__((always_inline)) {
             __syncthreads();                    // previous chunk's fragment reads (chunk 0: the zero fill) are done
@@ -347,12 +354,12 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
             __syncthreads();
         };
-        for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) {
-            stage_chunk(chunk);
-            run_chunk(std::false_type{}, chunk, lds, lds);
+        for (int i = 0; i + 1 < n_chunks; ++i) {
+            stage_chunk(c0 + i);
+            run_chunk(std::false_type{}, c0 + i, lds, lds);
         }
-        stage_chunk(n_chunks - 1);
-        run_chunk(std::true_type{}, n_chunks - 1, lds, lds);
+        stage_chunk(c0 + n_chunks - 1);
+        run_chunk(std::true_type{}, c0 + n_chunks - 1, lds, lds);
     }
 
     // ---- epilogue ----
@@ -365,7 +372,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     constexpr int LPP = NSUB * 4;               // lanes per pixel row
     constexpr int PPI = 64 / LPP;               // pixel rows per instruction
     constexpr int NRI = 32 / PPI;               // instructions per sub-tile
-    const int flags = p.flags;
+    // a split-K workgroup stores raw f32 accumulators; the reduction kernel applies the epilogue
+    const int flags = p.n_splits > 1 ? DS_EPI_OUT_F32 : p.flags;
     DS_F16_STAMP(2);
     __syncthreads();                            // every wave is done reading the pixel tile
     DS_F16_STAMP(3);
@@ -385,7 +393,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const bool out32 = (flags & DS_EPI_OUT_F32) != 0;
     const float clip_lo = (flags & DS_EPI_CLIP) ? 0.0f : -__builtin_inff();
     const float clip_hi = (flags & DS_EPI_CLIP) ? 20.0f : __builtin_inff();
-    const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
+    const ds_buffer ybuf = p.n_splits > 1 ? ds_make_buffer(p.partial + (size_t)split * p.partial_elems, p.partial_elems * 4u)
+                                          : ds_make_buffer(p.y, p.y_bytes);
     const ds_buffer rbuf = ds_make_buffer((flags & DS_EPI_RESIDUAL) ? (const void *)p.res : (const void *)p.y,
                                           (flags & DS_EPI_RESIDUAL) ? p.res_bytes : 0u);
     // Every row offset and every residual row of the wave's MSUB sub-tiles is requested BEFORE the first store:

@@ -338,7 +338,8 @@ class Engine:
         return e
 
     # ------------------------------------------------------------------ cached launch plan (eval)
-    def _build_eval_plan(self, x, pw: PackedWeights, folded, precision: str, masked: bool = False):
+    def _build_eval_plan(self, x, pw: PackedWeights, folded, precision: str, masked: bool = False,
+                         low_latency: bool = False):
         """Everything that does not change between two eval forwards of the same shape -- tile plans are
         recomputed inside the library anyway, but the Python side of a launch (shape structs, pointer
         objects, activation buffers, the stream handle lookup) costs more than the launch itself at
@@ -377,6 +378,13 @@ class Engine:
             flops = 2.0 * Bc * ho * wo * cout * cin * ks * ks
             if h16:         # fp16 activations between the layers; the last layer hands f32 to the tail
                 y = buf(Bc, ho, wo, cout, dtype=torch.float32 if last else torch.float16)
+                ws_bytes = self.lib.raw("ds_conv_f16_splitk_workspace_bytes")(ctypes.byref(shp)) if low_latency else 0
+                if ws_bytes > 0:        # a launch too small to fill the GPU: contraction split over workgroups
+                    ws = buf(ws_bytes // 4)
+                    args = (ctypes.byref(shp), src_p, self._p(w_f16), self._p(sc), self._p(sh), self._p(res), self._p(y),
+                            flags | (DS_EPI_OUT_F32 if last else 0), self._p(ws), ws_bytes, st_slot)
+                    calls.append((self.lib.raw("ds_conv_fwd_f16_splitk"), args, label, flops))
+                    return y, ho, wo
                 args = (ctypes.byref(shp), src_p, self._p(w_f16), self._p(sc), self._p(sh), self._p(res), self._p(y),
                         flags | (DS_EPI_OUT_F32 if last else 0), st_slot)
                 calls.append((self.lib.raw("ds_conv_fwd_f16"), args, label, flops))
@@ -435,13 +443,17 @@ class Engine:
         return {"calls": calls, "keep": keep, "x": x_slot, "e": e_slot, "st": st_slot, "n_out": n_out, "lens": lens_dev}
 
     def forward_eval_planned(self, x: torch.Tensor, pw: PackedWeights, folded, precision: str = "f32",
-                             lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             lengths: Optional[torch.Tensor] = None, low_latency: bool = False) -> torch.Tensor:
         """forward_eval through a launch plan cached per (shape, weights version, precision, device).
 
         `lengths` (int tensor [B], on the host): x is a zero-padded batch of utterances of these lengths (frames);
         every kept row of every layer -- and hence the embedding -- is then bit-identical to the forward of the
         utterance alone (rows past an utterance's extent are re-zeroed after each layer, the temporal mean runs
-        over its own rows)."""
+        over its own rows).
+
+        `low_latency` (fp16 path): launches too small to fill the GPU split their contraction over several
+        workgroups per tile (serving one or a few utterances); results then differ from the one-pass path by the f32
+        summation order."""
         self._check(x, "input")
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError("input must be [B,1,T,F] (reference model.py:185, SURVEY F1)")
@@ -454,7 +466,7 @@ class Engine:
             raise ValueError("pack_weights(..., with_bf16=True) is required for the bf16 precisions")
         # the plan owns its intermediate activations: forwards in flight on different streams need their own
         stream_id = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
-        key = (tuple(x.shape), precision, id(pw), id(folded), x.device, stream_id, lengths is not None)
+        key = (tuple(x.shape), precision, id(pw), id(folded), x.device, stream_id, lengths is not None, low_latency)
         plans = self.__dict__.setdefault("_eval_plans", {})
         plan = plans.get(key)
         if plan is None:
@@ -464,7 +476,8 @@ class Engine:
                 del plans[k]
             if len(plans) > 16:
                 plans.clear()
-            plan = plans[key] = self._build_eval_plan(x, pw, folded, precision, masked=lengths is not None)
+            plan = plans[key] = self._build_eval_plan(x, pw, folded, precision, masked=lengths is not None,
+                                                      low_latency=low_latency and precision == "f16")
         if lengths is not None:
             ln = lengths.to(torch.int64).cpu()
             if ln.numel() != x.shape[0] or int(ln.min()) < 1 or int(ln.max()) > x.shape[2]:

@@ -424,8 +424,13 @@ class DeepSpeakerModel(nn.Module):
     `.forward_classifier(x)`; `.l2_norm(t)`.  `state_dict()` has the reference's 76 keys.
     """
 
-    def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4, precision: str = "f32"):
+    def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4, precision: str = "f32",
+                 low_latency: bool = False):
         super().__init__()
+        # serving: eval forwards of a few utterances (fp16 path) split each layer's contraction over several
+        # workgroups instead of letting a handful of workgroups walk it alone (results then depend on the batch
+        # size in the last bits: the f32 summation order changes)
+        self.low_latency = low_latency
         # arithmetic of the stage convolutions: "f32" (exact-f32 MFMA), "bf16x3" (split-operand bf16 MFMA,
         # f32-class accuracy; in training: forward, data and filter gradients of the 3x3 / 5x5 layers; the fc
         # layer, conv1's filter gradient and the BatchNorm / loss passes stay f32), "f16" (eval: fp16 operands
@@ -561,7 +566,8 @@ class DeepSpeakerModel(nn.Module):
                 self.features = e
         else:
             pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
-            self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=self.precision)
+            self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=self.precision,
+                                                              low_latency=self.low_latency)
         return self.features
 
     def forward_triplet(self, data_a, data_p, data_n):

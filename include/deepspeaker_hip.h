@@ -157,6 +157,14 @@ int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, c
 int ds_pack_conv_weight_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, void *stream);
 int ds_conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
                     const float *shift, const void *residual_f16, void *y, int flags, void *stream);
+/* The same for SMALL launches (serving latency, reference model.py:185-218 on one or a few utterances): when the tile
+ * grid cannot fill the GPU the contraction is split over up to 8 workgroups per tile (raw f32 partial sums in
+ * `workspace`) and a second kernel folds them in fixed order and applies the epilogue.  Differs from
+ * ds_conv_fwd_f16 by the f32 summation order only; large launches take the one-pass path. */
+long long ds_conv_f16_splitk_workspace_bytes(const ds_conv_shape *s);
+int ds_conv_fwd_f16_splitk(const ds_conv_shape *s, const void *x_f16, const void *w_f16, const float *scale,
+                           const float *shift, const void *residual_f16, void *y, int flags, void *workspace,
+                           long long ws_bytes, void *stream);
 /* out8 = {M tile, N tile, rows per segment, segments per tile, workgroups, LDS bytes, threads per workgroup,
  * 1000 * double-buffered + 100 * (16-channel chunks) + staging items per thread} */
 int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8);

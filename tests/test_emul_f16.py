@@ -121,6 +121,42 @@ def test_conv_f16_chunk16(case):
     assert rel_err(y, ref) < 2e-6
 
 
+@pytest.mark.parametrize("case", [CASES[2], CASES[3], (1, 128, 64, 5, 8, 3, 1)])
+def test_conv_f16_split_k(case):
+    """small launches: contraction split over workgroups + fixed-order reduction with the epilogue"""
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(17 + sum(case))
+    x = np.abs(rs.randn(b, ci, h, w)).astype(np.float16).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, co).astype(np.float32)
+    shift = rs.randn(co).astype(np.float32)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    res = (np.abs(rs.randn(b, co, ho, wo)) * 8).astype(np.float16).astype(np.float32)
+    shp = ConvShape(b, h, w, ci, co, k, s)
+    ws_bytes = lib.raw("ds_conv_f16_splitk_workspace_bytes")(ctypes.byref(shp))
+    assert ws_bytes > 0, "these launches are tiny: the contraction must be split"
+    ws = aligned(ws_bytes // 4, fill=np.nan)
+    wp, src = aligned(wt.size, np.float16), to_aligned(wt)
+    lib.call("ds_pack_conv_weight_f16", ptr(src), ptr(wp), co, ci, k, None)
+    xh, rh, sc, sh = nhwc16(x), nhwc16(res), to_aligned(scale), to_aligned(shift)
+    acc = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    y32 = aligned((b, ho, wo, co), fill=np.nan)
+    lib.call("ds_conv_fwd_f16_splitk", ctypes.byref(shp), ptr(xh), ptr(wp), None, None, None, ptr(y32), DS_EPI_OUT_F32,
+             ptr(ws), ws_bytes, None)
+    assert rel_err(y32.transpose(0, 3, 1, 2), acc) < 2e-6
+    y16 = aligned((b, ho, wo, co), np.float16, fill=np.nan)
+    lib.call("ds_conv_fwd_f16_splitk", ctypes.byref(shp), ptr(xh), ptr(wp), ptr(sc), ptr(sh), ptr(rh), ptr(y16),
+             DS_EPI_AFFINE | DS_EPI_RESIDUAL | DS_EPI_CLIP, ptr(ws), ws_bytes, None)
+    ref = np.clip(acc * scale[None, :, None, None] + shift[None, :, None, None] + res, 0.0, 20.0)
+    assert np.abs(y16.astype(np.float32).transpose(0, 3, 1, 2) - ref).max() <= 20 * 2.0 ** -11 + 1e-5
+    # without a workspace the same entry point takes the one-pass path
+    y1 = aligned((b, ho, wo, co), fill=np.nan)
+    lib.call("ds_conv_fwd_f16_splitk", ctypes.byref(shp), ptr(xh), ptr(wp), None, None, None, ptr(y1), DS_EPI_OUT_F32,
+             None, 0, None)
+    assert rel_err(y1, y32) < 2e-6
+
+
 def test_conv_f16_rejects_stats_and_bad_shapes():
     lib = emul_lib()
     x = aligned((1, 4, 4, 32), np.float16, fill=0)

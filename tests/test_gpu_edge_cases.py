@@ -233,3 +233,22 @@ def test_variable_length_batches_vs_reference(golden, precision):
     want = [O.pairwise_distance(np.repeat(e[0:1].cpu().numpy(), 5, 0), en[:5]).mean(),
             O.pairwise_distance(np.repeat(e[1:2].cpu().numpy(), 3, 0), en[5:]).mean()]
     assert np.abs(sc.cpu().numpy() - np.array(want)).max() < 1e-4
+
+
+def test_low_latency_split_k_forward(golden):
+    """DeepSpeakerModel(low_latency=True): small fp16 launches split their contraction over workgroups.  Same result
+    as the one-pass path up to the f32 summation order, inside the contract against the reference, deterministic."""
+    sd = O.make_state_dict(seed=11, num_classes=16)
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel
+    x = torch.from_numpy(O.make_input(seed=12, batch=6)).cuda()
+    outs = {}
+    for low in (False, True):
+        m = DeepSpeakerModel(512, 16, precision="f16", low_latency=low)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        m = m.cuda().eval()
+        with torch.no_grad():
+            outs[low] = (m(x).clone(), m(x[:1].contiguous()).clone(), m(x).clone())
+    assert torch.equal(outs[True][0], outs[True][2])
+    assert rel_err(outs[True][0].cpu().numpy(), outs[False][0].cpu().numpy()) < 2e-5
+    assert rel_err(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy()) < 2e-5
+    assert rel_err(outs[True][0].cpu().numpy(), golden["full_eval_emb"]) < TOL["f16"]
