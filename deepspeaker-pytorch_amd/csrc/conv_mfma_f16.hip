@@ -258,7 +258,8 @@ extern "C" void ds_f16_set_probe(long long *buf) { g_f16_probe = buf; }
 static int splitk_ways(const PlanH &pl, const ds_conv_shape *s) {
     const int n_chunks = s->Cin / pl.ck;
     int ways = 1;
-    while (ways * 2 <= 8 && ways * 2 <= n_chunks && (long long)pl.grid * ways * 2 <= 512) ways *= 2;
+    if (pl.grid > 48) return 1;                  // (measured: from ~64 workgroups on, the partial-sum traffic costs more than it saves)
+    while (ways * 2 <= 8 && ways * 2 <= n_chunks && (long long)pl.grid * ways * 2 <= 256) ways *= 2;
     return ways;
 }
 
