@@ -194,7 +194,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             const int live_segs = p.n_segs - seg0 < p.NI ? p.n_segs - seg0 : p.NI;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int sg = ds_div_small(vr, cnt_u, rcp_cnt);
+                int sg;
+                if (p.NI == 1) sg = vr >= cnt_u ? 1 : 0;       // (uniform branch: a single segment needs no division)
+                else sg = ds_div_small(vr, cnt_u, rcp_cnt);
                 const int rr = lo_u + vr - sg * cnt_u;
                 const int cc = c - p.dw_min;
                 const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
@@ -242,18 +244,30 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     // ---- everything below overlaps the first chunk's loads ----
     // Only in-image pixels are ever staged: the zero halo (and the row padding) is written once, here.
     for (int i = tid; i < tiles_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int m = tid; m < MT; m += NTHR) {
-        const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
-        const int rem = m - seg * pix_per_seg;
-        const int r = ds_div_small(rem, p.Wo, rcp_wc), c = rem - r * p.Wo;
-        const int gseg = seg0 + seg;
-        int off = -1;
-        if (seg < p.NI && gseg < p.n_segs) {
-            const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
-            const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
-            if (rr < p.Ho) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+    // Output pixel of tile row m.  A tile that is one block of rows of one image, or a run of whole images (every
+    // bench layer), covers CONSECUTIVE pixels of y: pixel lin_base + m for m < lin_valid, no table.
+    const bool linear = p.NI == 1 || p.RT == p.Ho;
+    int lin_base = 0, lin_valid = 0;
+    if (linear) {
+        const int b = ds_div_small(seg0, p.segs_per_img, rcp_spi);
+        const int r0 = (seg0 - b * p.segs_per_img) * p.RT;
+        lin_base = (b * p.Ho + r0) * p.Wo;
+        const int live = p.n_segs - seg0 < p.NI ? p.n_segs - seg0 : p.NI;
+        lin_valid = p.NI == 1 ? (p.Ho - r0 < p.RT ? p.Ho - r0 : p.RT) * p.Wo : live * pix_per_seg;
+    } else {
+        for (int m = tid; m < MT; m += NTHR) {
+            const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
+            const int rem = m - seg * pix_per_seg;
+            const int r = ds_div_small(rem, p.Wo, rcp_wc), c = rem - r * p.Wo;
+            const int gseg = seg0 + seg;
+            int off = -1;
+            if (seg < p.NI && gseg < p.n_segs) {
+                const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
+                const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
+                if (rr < p.Ho) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+            }
+            out_off[m] = off;
         }
-        out_off[m] = off;
     }
     DS_F16_STAMP(7);
     // Which pixel of its 32-pixel sub-tile a lane owns is free (the epilogue un-permutes): it is chosen so
@@ -406,7 +420,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
         for (int k = 0; k < NRI; ++k) {
-            const int off = out_off[(wm * MSUB + ms) * 32 + k * PPI + my_p];
+            const int m = (wm * MSUB + ms) * 32 + k * PPI + my_p;
+            int off;
+            if (linear) off = m < lin_valid ? (lin_base + m) * p.Cout : -1;
+            else off = out_off[m];
             voff[ms][k] = off >= 0 ? (unsigned)(off + col) : DS_BUFFER_OOB;
         }
 #pragma unroll
