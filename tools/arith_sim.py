@@ -4,7 +4,7 @@ else in f32 -- embedding error, error of d_n - d_p and flipped filter decisions 
 the choice of the fp16 arithmetic was made on before the kernel existed.  python tools/arith_sim.py"""
 import os, sys, time, numpy as np, torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, 'os.path.join(ROOT, "oracle")')
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import deepspeaker_oracle as O
 torch.set_num_threads(8)
 sd_np = O.make_state_dict(seed=0, num_classes=1211)
