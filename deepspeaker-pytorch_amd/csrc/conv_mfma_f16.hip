@@ -281,9 +281,16 @@ static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w
     DS_REQUIRE(DS_ALIGNED16(x_f16) && DS_ALIGNED16(w_f16) && DS_ALIGNED16(y) && DS_ALIGNED16(residual_f16) &&
                    DS_ALIGNED16(scale) && DS_ALIGNED16(shift) && DS_ALIGNED16(workspace), DS_ERR_ALIGNMENT);
     PlanH pl;
-    int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER), (flags & DS_CONV_HINT_CHUNK16) != 0);
+    const bool in_planes = (flags & DS_CONV_IN_PLANES16) != 0, out_planes = (flags & DS_EPI_OUT_PLANES16) != 0;
+    DS_REQUIRE(!in_planes || s->KS == 5, DS_ERR_UNSUPPORTED);          // plane-major input needs 16-channel chunks
+    DS_REQUIRE(!out_planes || !(flags & DS_EPI_OUT_F32), DS_ERR_UNSUPPORTED);
+    int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER), in_planes || (flags & DS_CONV_HINT_CHUNK16) != 0);
     if (rc != DS_OK) return rc;
+    DS_REQUIRE(!in_planes || pl.ck == 16, DS_ERR_UNSUPPORTED);
     ConvKH &k = pl.k;
+    k.x_pix_stride = in_planes ? 16 : s->Cin;
+    k.x_chunk_stride = in_planes ? s->B * s->H * s->W * 16 : pl.ck;
+    k.y_plane_stride = out_planes ? (unsigned)((long long)s->B * pl.k.Ho * pl.k.Wo * 16) : 0u;
     k.x = (const _Float16 *)x_f16; k.w = (const _Float16 *)w_f16; k.y = y;
     k.scale = scale; k.shift = shift; k.res = (const _Float16 *)residual_f16;
     k.flags = flags;
@@ -291,7 +298,7 @@ static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w
     k.y_bytes = (unsigned)(n_out * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
     k.res_bytes = (unsigned)(n_out * 2);
     const int n_chunks = s->Cin / pl.ck;
-    int ways = workspace ? splitk_ways(pl, s) : 1;
+    int ways = (workspace && !out_planes) ? splitk_ways(pl, s) : 1;
     if (ways > 1 && ws_bytes < (long long)ways * n_out * 4) ways = 1;
     k.tiles = pl.grid;
     k.chunks_per_split = ds_ceil_div(n_chunks, ways);

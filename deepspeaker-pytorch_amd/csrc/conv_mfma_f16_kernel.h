@@ -40,6 +40,11 @@ struct ConvKH {
     unsigned y_bytes, res_bytes;    // sizes for the buffer descriptors
     // split-K (small launches: serving latency): workgroup blockIdx = split * tiles + tile contracts the input-channel
     // chunks [split * chunks_per_split, ...) and stores its raw f32 accumulators into partial + split * partial_elems
+    // Layouts.  Channels-last: pixel stride Cin, the next chunk CK elements further.  Channel-plane-major
+    // ([C/16][pixels][16], DS_CONV_IN_PLANES16 / DS_EPI_OUT_PLANES16): pixel stride 16, the next (16-channel) chunk one
+    // plane further -- a chunk then reads WHOLE 128-byte lines instead of a quarter of every pixel record.
+    int x_pix_stride, x_chunk_stride;
+    unsigned y_plane_stride;        // 0: y is channels-last; else elements per 16-channel plane of y
     int tiles, n_splits, chunks_per_split;
     float *partial;
     unsigned partial_elems;
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                 const int cc = c - p.dw_min;
                 const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
                 const bool ok = sg < live_segs;
-                g_off[it] = ok ? ((img_row0 + sg * p.H + rr) * p.W + c) * p.Cin + q * 8 : 0;
+                g_off[it] = ok ? ((img_row0 + sg * p.H + rr) * p.W + c) * p.x_pix_stride + q * 8 : 0;
                 l_off[it] = ok ? (sg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16 : CKH * 2;
                 c += dc;
                 vr += dvr;
@@ -223,7 +228,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                     // so that the 32 lanes of a fragment read (stride-2 columns) touch CONSECUTIVE records
                     const int cc = c - p.dw_min;
                     const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
-                    g_off[it] = ((img_row + rr) * p.W + c) * p.Cin + q * 8;
+                    g_off[it] = ((img_row + rr) * p.W + c) * p.x_pix_stride + q * 8;
                     l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16;
                 }
                 c += dc;
@@ -239,7 +244,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     f32x4 st[NIT];                              // 8 halfs each, moved as 16 opaque bytes
     if constexpr (PREF) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + c0 * CKH);
+        for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + (size_t)c0 * p.x_chunk_stride);
     }
     // ---- everything below overlaps the first chunk's loads ----
     // Only in-image pixels are ever staged: the zero halo (and the row padding) is written once, here.
@@ -264,7 +269,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             if (seg < p.NI && gseg < p.n_segs) {
                 const int b = ds_div_small(gseg, p.segs_per_img, rcp_spi);
                 const int rr = (gseg - b * p.segs_per_img) * p.RT + r;
-                if (rr < p.Ho) off = ((b * p.Ho + rr) * p.Wo + c) * p.Cout;
+                if (rr < p.Ho) off = (b * p.Ho + rr) * p.Wo + c;              // output pixel index
             }
             out_off[m] = off;
         }
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             DS_OPAQUE_VGPR(a_off[ms]);          // keep the NU x MSUB fragment addresses out of registers
             a[0][ms] = *(const f16x8 *)(buf + a_off[ms] + tap_off(0));
         }
-        const _Float16 *xn = p.x + (chunk + 1) * CKH;
+        const _Float16 *xn = p.x + (size_t)(chunk + 1) * p.x_chunk_stride;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -362,7 +367,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             __syncthreads();                    // previous chunk's fragment reads (chunk 0: the zero fill) are done
             if constexpr (!PREF) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + chunk * CKH);
+                for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + (size_t)chunk * p.x_chunk_stride);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
@@ -422,15 +427,15 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         for (int k = 0; k < NRI; ++k) {
             const int m = (wm * MSUB + ms) * 32 + k * PPI + my_p;
             int off;
-            if (linear) off = m < lin_valid ? (lin_base + m) * p.Cout : -1;
-            else off = out_off[m];
-            voff[ms][k] = off >= 0 ? (unsigned)(off + col) : DS_BUFFER_OOB;
+            if (linear) off = m < lin_valid ? lin_base + m : -1;
+            else off = out_off[m];                                 // output pixel index, or -1
+            // y: channels-last, or 16-channel planes (the lane's 8 channels lie inside one plane); the residual is
+            // always channels-last
+            const unsigned cl = (unsigned)(off * p.Cout + col);
+            voff[ms][k] = off < 0 ? DS_BUFFER_OOB
+                          : p.y_plane_stride ? (unsigned)(col >> 4) * p.y_plane_stride + (unsigned)off * 16u + (unsigned)(col & 15) : cl;
+            resv[ms][k] = ds_buffer_load_f32x4(rbuf, off >= 0 ? cl * 2u : DS_BUFFER_OOB);
         }
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-        for (int k = 0; k < NRI; ++k)
-            resv[ms][k] = ds_buffer_load_f32x4(rbuf, voff[ms][k] != DS_BUFFER_OOB ? voff[ms][k] * 2u : DS_BUFFER_OOB);
     auto put_tile = [&](int ms) {               // accumulators of sub-tile ms -> this wave's buffer ms & 1
         float *dst = tb + (ms & 1) * (32 * TP);
 #pragma unroll

@@ -15,8 +15,8 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from ._native import (ConvShape, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_OUT_F16, DS_EPI_OUT_F32, DS_EPI_RESIDUAL,
-                      DS_EPI_STATS, NativeLib)
+from ._native import (ConvShape, DS_CONV_IN_PLANES16, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_OUT_F16, DS_EPI_OUT_F32,
+                      DS_EPI_OUT_PLANES16, DS_EPI_RESIDUAL, DS_EPI_STATS, NativeLib)
 
 PRECISIONS = ("f32", "bf16x3", "bf16", "f16")
 
@@ -369,11 +369,12 @@ class Engine:
             keep.append(t)
             return t
 
-        def conv_call(src_p, w_f32, w_bf16, Bc, h, w, cin, cout, ks, stride, sc, sh, res, w_f16=None, last=False):
+        def conv_call(src_p, w_f32, w_bf16, Bc, h, w, cin, cout, ks, stride, sc, sh, res, w_f16=None, last=False,
+                      layout_flags=0):
             shp = ConvShape(Bc, h, w, cin, cout, ks, stride)
             keep.append(shp)
             ho, wo = conv_out(h, ks, stride), conv_out(w, ks, stride)
-            flags = AC | (DS_EPI_RESIDUAL if res is not None else 0)
+            flags = AC | (DS_EPI_RESIDUAL if res is not None else 0) | layout_flags
             label = f"conv{ks}x{ks}s{stride}_{cin}to{cout}_{ho}x{wo}"
             flops = 2.0 * Bc * ho * wo * cout * cin * ks * ks
             if h16:         # fp16 activations between the layers; the last layer hands f32 to the tail
@@ -402,6 +403,11 @@ class Engine:
 
         h, w, cin = T, F, 1
         a = None
+        # fp16 path: the 64-channel tensor between stage 1 and the 64->128 5x5 layer travels channel-plane-major
+        # ([4][pixels][16]): that layer works in 16-channel chunks, and a channels-last 64-channel record is one
+        # 128-byte line of which every chunk would read a quarter (4x the HBM / L2 traffic, measured).  Nobody else
+        # reads that tensor.  (Masked variable-length plans and the split-K small-launch plans keep channels-last.)
+        planes = h16 and not masked and not low_latency and len(pw.stages) > 1
         for s, sw in enumerate(pw.stages):
             i, c = s + 1, STAGE_CHANNELS[s]
             sc, sh = folded[f"model.bn{i}"]
@@ -413,7 +419,8 @@ class Engine:
                                AC | (DS_EPI_OUT_F16 if h16 else 0), st_slot), None, 0.0))
                 h, w = ho, wo
             else:
-                a, h, w = conv_call(self._p(a), sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2, sc, sh, None, sw.conv_f16)
+                a, h, w = conv_call(self._p(a), sw.conv, sw.conv_bf16, B, h, w, cin, c, 5, 2, sc, sh, None, sw.conv_f16,
+                                    layout_flags=DS_CONV_IN_PLANES16 if (planes and i == 2) else 0)
             mask_call(a, s, h)
             cin = c
             sc, sh = folded[f"model.layer{i}.0.bn1"]
@@ -421,7 +428,8 @@ class Engine:
             mask_call(y, s, h)
             sc, sh = folded[f"model.layer{i}.0.bn2"]
             a, _, _ = conv_call(self._p(y), sw.l_conv2, sw.l_conv2_bf16, B, h, w, c, c, 3, 1, sc, sh, a, sw.l_conv2_f16,
-                                last=(s == len(pw.stages) - 1))
+                                last=(s == len(pw.stages) - 1),
+                                layout_flags=DS_EPI_OUT_PLANES16 if (planes and i == 1) else 0)
             if s < len(pw.stages) - 1:          # (the masked pool below never reads the last stage's padding rows)
                 mask_call(a, s, h)
         k = w * cin

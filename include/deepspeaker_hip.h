@@ -49,6 +49,10 @@ extern "C" {
 #define DS_EPI_OUT_F32  16  /* fp16 convolution: store the result as f32 (the layer feeding the f32 tail)     */
 #define DS_EPI_OUT_F16  32  /* conv1 (ds_conv5x5s2_c1_fwd_bf16): store the result as fp16                    */
 
+#define DS_EPI_OUT_PLANES16  256 /* fp16 convolution: store y channel-plane-major, [Cout/16][B*Ho*Wo][16] fp16          */
+#define DS_CONV_IN_PLANES16  512 /* fp16 5x5 convolution: x is channel-plane-major [Cin/16][B*H*W][16]: every
+                                    16-channel chunk then reads whole 128-byte lines (a 64-channel channels-last
+                                    record is one line, of which a chunk would use a quarter)                       */
 #define DS_CONV_HINT_SINGLE_BUFFER 64  /* fp16 convolution: plan with one LDS pixel tile (tuning / test hint)  */
 #define DS_CONV_HINT_CHUNK16      128  /* fp16 5x5 convolution: plan with 16-channel chunks (tuning / test hint)  */
 
