@@ -452,7 +452,7 @@ def test_forward_triplet_equals_three_calls(dev, precision):
     # sums, and the tiling of an 18-utterance launch differs from that of a 6-utterance one: last-bit differences
     for a, b in zip(o0, o1):
         assert rel_err(b.detach().cpu().numpy(), a.detach().cpu().numpy()) < 2e-5
-    assert abs(float(l0) - float(l1)) < 1e-6 * max(1.0, abs(float(l0)))
+    assert abs(float(l0) - float(l1)) < 2e-5 * max(1.0, abs(float(l0)))
     for k in s0:                                                   # three sequential running-statistics updates
         assert rel_err(s1[k].double().cpu().numpy(), s0[k].double().cpu().numpy()) < 1e-6, k
     assert int(s1["model.bn1.num_batches_tracked"]) == 3
