@@ -359,19 +359,19 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         for (int i = 0; i + 1 < n_chunks; ++i) {
             char *b0 = lds + (i & 1) * tile_bytes, *b1 = lds + ((i & 1) ^ 1) * tile_bytes;
             run_chunk(std::false_type{}, c0 + i, b0, b1);
-            __syncthreads();
+            ds_lds_barrier();                   // LDS only: the filter-ring loads in flight stay in flight
         }
         run_chunk(std::true_type{}, c0 + n_chunks - 1, lds + ((n_chunks - 1) & 1) * tile_bytes, lds);
     } else {
         auto stage_chunk = [&](int chunk) __attribute__((always_inline)) {
-            __syncthreads();                    // previous chunk's fragment reads (chunk 0: the zero fill) are done
+            ds_lds_barrier();                   // previous chunk's fragment reads (chunk 0: the zero fill) are done
             if constexpr (!PREF) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it] + (size_t)chunk * p.x_chunk_stride);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
-            __syncthreads();
+            ds_lds_barrier();
         };
         for (int i = 0; i + 1 < n_chunks; ++i) {
             stage_chunk(c0 + i);

@@ -44,6 +44,15 @@ __device__ __forceinline__ void ds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic ONLY: __syncthreads() also drains the vector-memory counter, i.e. it waits
+// for every global load in flight -- inside a software-pipelined loop that is the youngest filter-ring refill, a full
+// L2 round trip per barrier.  Here only this wave's LDS operations are waited for before the barrier.
+__device__ __forceinline__ void ds_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ds_read_b64_tr_b16 (gfx950 transposing LDS read).  Within each group of 16 lanes, lane i supplies the
 // address of an 8-byte piece -- row i>>2, column quad i&3 of a [4 rows][16 columns] block of 16-bit
 // elements -- and receives COLUMN i of that block (rows 0..3).  Verified on MI355X with row strides of

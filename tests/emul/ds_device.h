@@ -139,6 +139,7 @@ static inline float ds_buffer_load_f32(ds_buffer b, unsigned byte_off) {
 static inline void ds_buffer_store_f32(ds_buffer b, unsigned byte_off, float v) {
     if ((unsigned long long)byte_off + 4 <= b.bytes) memcpy(b.base + byte_off, &v, 4);
 }
+static inline void ds_lds_barrier() { __syncthreads(); }
 static inline void ds_wave_sync() {
     float all[64];
     emu::wave_exchange(0.0f, all);
