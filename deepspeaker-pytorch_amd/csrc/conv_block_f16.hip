@@ -1,0 +1,396 @@
+// conv_block_f16.hip -- one whole BasicBlock of the eval forward in ONE kernel on the fp16 matrix cores:
+//
+//     y = clip( bn2( conv3x3( clip( bn1( conv3x3(x) ) ) ) ) + x )                 (reference model.py:66-82)
+//
+// for the two shallow stages (64 channels on 80x32 maps, 128 channels on 40x16 maps at T = 160).  There the contraction
+// of one 3x3 layer is only K = 576 / 1152 deep and a workgroup of conv_mfma_f16_kernel spends more clocks in its
+// prologue and epilogue than in its MFMA stream.  Fusing the block's two convolutions pays one prologue
+// and one HBM epilogue for two MFMA streams: the intermediate activation (rows r0-1 .. r0+R of the image, the halo
+// rows recomputed) goes from the accumulators straight into LDS in the pixel-record layout the second convolution
+// reads its fragments from -- it never exists in HBM.  Arithmetic, rounding points (the intermediate is rounded to fp16
+// exactly as the unfused path stores it) and accumulation order are those of two ds_conv_fwd_f16 calls: results are
+// bit-identical (asserted by the tests).
+#include <ds_device.h>
+#include <algorithm>
+#include <type_traits>
+#include "ds_common.h"
+
+namespace {
+
+constexpr int BK_R = 8;                 // output rows per workgroup; the first convolution computes BK_R + 2
+constexpr int BK_CK = 32;               // input channels per chunk (two MFMA k-steps per tap)
+constexpr int BK_PS = 80;               // bytes per staged input record: 32 halfs + 16 B pad
+
+struct BlockK {
+    const _Float16 *x;                  // [B,H,W,C] fp16 channels-last: block input and residual
+    const _Float16 *wa, *wb;            // packed [C/16][9][C][16] (ds_pack_conv_weight_f16)
+    const float *sa, *ha, *sb, *hb;     // folded BatchNorm of the two layers (scale, shift)
+    void *y;                            // [B,H,W,C] fp16 (f32 with DS_EPI_OUT_F32; plane-major with DS_EPI_OUT_PLANES16)
+    int B, H, W, C;
+    int tiles_per_img;
+    int flags;
+    unsigned y_bytes, x_bytes, y_plane_stride;
+};
+
+// WM x WN waves, each a 160x64 register tile for the first convolution (10 rows x W pixels per WM) and 128x64 for the
+// second (8 rows); W = 32 * WM / ... : MT_A = 160 * WM = 10 * W.  NIT: 16-byte staging items per thread and chunk.
+template <int WM, int WN, int NIT>
+__global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3x3_f16_kernel(const BlockK p) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MSA = 5, MSB = 4, NSUB = 2;
+    constexpr int NT = 9, NU = 2 * NT, RU = 6;
+    constexpr int NMFA = MSA * NSUB, NMFB = MSB * NSUB;
+    constexpr int SPU = (NMFA + 1) / 2 - NSUB;
+    constexpr int UL = (NIT + SPU - 1) / SPU;
+    static_assert(2 * UL <= NU, "not enough units for the staging traffic");
+    constexpr int ROWS_A = BK_R + 2, ROWS_IN = BK_R + 4;
+
+    char *lds = (char *)ds_dynamic_lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int W = p.W, C = p.C;
+    const int b = blockIdx.x / p.tiles_per_img;
+    const int r0 = (blockIdx.x - b * p.tiles_per_img) * BK_R;        // first output row of this tile
+    const int pitch = W + 2;                                         // records per tile row (both tiles)
+    const int tileA_bytes = ROWS_IN * pitch * BK_PS;
+    const int RSB = C * 2 + 16;                                      // bytes per intermediate record
+    const int n_chunks = C / BK_CK;
+    const int n_base = wn * NSUB * 32;
+    const size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);
+    const size_t w_kc_stride = (size_t)NT * C * 16, w_tap_stride = (size_t)C * 16;
+    auto w_unit = [&](const _Float16 *w, int chunk, int u) {         // k-step-major units, as conv_mfma_f16_kernel
+        return w + lane_w + (size_t)(2 * chunk + (u / NT)) * w_kc_stride + (size_t)(u % NT) * w_tap_stride;
+    };
+    f16x8 bq[RU][NSUB];
+#pragma unroll
+    for (int d = 0; d < RU; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(p.wa, 0, d) + (size_t)ns * 32 * 16);
+
+    f32x16 acc[MSA][NSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSA; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+
+    // ---- staging descriptors: input rows r0-2 .. r0+R+1 of image b, in-image rows only ----
+    const float rcp_w = 1.0f / (float)W;
+    const int h0 = r0 - 2;
+    const int lo = h0 < 0 ? -h0 : 0;
+    const int hi = p.H - h0 < ROWS_IN ? p.H - h0 : ROWS_IN;
+    const int cnt = hi > lo ? hi - lo : 0;
+    int g_off[NIT], l_off[NIT];
+    {
+        const int q = tid & 3;
+        const int dvr = ds_div_small(NTHR / 4, W, rcp_w), dc = NTHR / 4 - dvr * W;
+        int vr = ds_div_small(tid >> 2, W, rcp_w);
+        int c = (tid >> 2) - vr * W;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const bool ok = vr < cnt;
+            g_off[it] = ok ? ((b * p.H + h0 + lo + vr) * W + c) * C + q * 8 : 0;
+            l_off[it] = ok ? ((lo + vr) * pitch + c + 1) * BK_PS + q * 16 : 64;
+            c += dc;
+            vr += dvr;
+            if (c >= W) {
+                c -= W;
+                ++vr;
+            }
+        }
+    }
+    f32x4 st[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
+    // zero halo of both input buffers, written once
+    for (int i = tid; i < 2 * tileA_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // lane -> pixel permutation inside a 32-pixel sub-tile (conflict-free ds_read_b128 service groups, see
+    // conv_mfma_f16_kernel.h)
+    const int lpix = (l31 < 4 || l31 >= 28) ? l31
+                   : (l31 < 12) ? l31 + 12 : (l31 < 16) ? l31 - 8 : (l31 < 20) ? l31 + 8 : l31 - 12;
+    int a_off[MSA];                         // first convolution: top-left record of the pixel's 3x3 window
+#pragma unroll
+    for (int ms = 0; ms < MSA; ++ms) {
+        const int m = (wm * MSA + ms) * 32 + lpix;
+        const int i = ds_div_small(m, W, rcp_w), c = m - i * W;
+        a_off[ms] = (i * pitch + c) * BK_PS + 16 * lhi;
+    }
+    auto tap_off = [&](int tt, int rs) { return ((tt / 3) * pitch + (tt % 3)) * rs; };
+
+    // ---- first convolution: the MFMA stream of conv_mfma_f16_kernel (double-buffered tile, one side operation per MFMA)
+    auto run_chunk = [&](auto last_tag, int chunk, const char *buf, char *obuf) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        f16x8 a[2][MSA];
+#pragma unroll
+        for (int ms = 0; ms < MSA; ++ms) {
+            DS_OPAQUE_VGPR(a_off[ms]);
+            a[0][ms] = *(const f16x8 *)(buf + a_off[ms] + tap_off(0, BK_PS));
+        }
+        const _Float16 *xn = p.x + (chunk + 1) * BK_CK;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int cur = u & 1, slot = u % RU;
+            const bool more = u + 1 < NU;
+            const char *nfrag = buf + tap_off((u + 1) % NT, BK_PS) + 32 * ((u + 1) / NT);
+            const int ur = u - 1 + RU;
+            const bool refill = !(LAST && ur >= NU);
+            const _Float16 *rw = w_unit(p.wa, ur >= NU ? chunk + 1 : chunk, ur >= NU ? ur - NU : ur);
+            const int rslot = (u + RU - 1) % RU;
+#pragma unroll
+            for (int q = 0; q < NMFA; ++q) {
+                const int ms = q / NSUB, ns = q % NSUB;
+                acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
+                if (q & 1) {
+                    const int lm = q >> 1;
+                    if (lm < MSA && more) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + a_off[lm]);
+                } else {
+                    const int e = q >> 1;
+                    if (e < NSUB) {
+                        if (refill) bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+                    } else if constexpr (!LAST) {
+                        const int s = e - NSUB;
+                        if (u < UL) {
+                            const int it = u * SPU + s;
+                            if (it < NIT) st[it] = *(const f32x4 *)(xn + g_off[it]);
+                        } else if (u >= NU - UL) {
+                            const int it = (u - (NU - UL)) * SPU + s;
+                            if (it < NIT) *(f32x4 *)(obuf + l_off[it]) = st[it];
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    __syncthreads();                            // the zero fill is complete
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
+    __syncthreads();
+    for (int i = 0; i + 1 < n_chunks; ++i) {
+        char *b0 = lds + (i & 1) * tileA_bytes, *b1 = lds + ((i & 1) ^ 1) * tileA_bytes;
+        run_chunk(std::false_type{}, i, b0, b1);
+        ds_lds_barrier();
+    }
+    run_chunk(std::true_type{}, n_chunks - 1, lds + ((n_chunks - 1) & 1) * tileA_bytes, lds);
+
+    // ---- the second layer's first filter fragments travel during the hand-over ----
+#pragma unroll
+    for (int d = 0; d < RU; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(p.wb, 0, d) + (size_t)ns * 32 * 16);
+
+    // ---- hand-over: bn1 + clip, rounded to fp16, into the intermediate tile [ROWS_A][pitch] of C-channel records.
+    // Columns 0 and W + 1 and the rows outside the image are the second convolution's zero padding.
+    __syncthreads();                            // every wave is done reading the input tiles
+    const int interm_bytes = ROWS_A * pitch * RSB;
+    for (int i = tid; i < interm_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 sca[NSUB][4], sha[NSUB][4];
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = n_base + ns * 32 + 8 * g + 4 * lhi;
+            sca[ns][g] = *(const f32x4 *)(p.sa + c0);
+            sha[ns][g] = *(const f32x4 *)(p.ha + c0);
+        }
+    __syncthreads();                            // the zero fill is complete
+#pragma unroll
+    for (int ms = 0; ms < MSA; ++ms) {
+        const int m = (wm * MSA + ms) * 32 + lpix;
+        const int i = ds_div_small(m, W, rcp_w), c = m - i * W;
+        const int row = r0 - 1 + i;                                  // image row of this intermediate pixel
+        const bool inside = row >= 0 && row < p.H;
+        char *rec = lds + (i * pitch + c + 1) * RSB;
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = fminf(fmaxf(acc[ms][ns][4 * g + j] * sca[ns][g][j] + sha[ns][g][j], 0.0f), 20.0f);
+                    h[j] = inside ? (_Float16)t : (_Float16)0.0f;
+                    acc[ms][ns][4 * g + j] = 0.0f;                   // the accumulators start the second layer at zero
+                }
+                *(f16x4 *)(rec + (n_base + ns * 32 + 8 * g + 4 * lhi) * 2) = h;
+            }
+    }
+    __syncthreads();                            // the intermediate tile is complete
+
+    // ---- second convolution: fragments straight from the intermediate tile, all chunks resident ----
+    int b_off[MSB];
+#pragma unroll
+    for (int ms = 0; ms < MSB; ++ms) {
+        const int m = (wm * MSB + ms) * 32 + lpix;
+        const int i = ds_div_small(m, W, rcp_w), c = m - i * W;
+        b_off[ms] = (i * pitch + c) * RSB + 16 * lhi;
+    }
+    {
+        const int total = n_chunks * NU;        // units of the whole contraction, filter ring running through
+        f16x8 a[2][MSB];
+#pragma unroll
+        for (int ms = 0; ms < MSB; ++ms) {
+            DS_OPAQUE_VGPR(b_off[ms]);
+            a[0][ms] = *(const f16x8 *)(lds + b_off[ms] + tap_off(0, RSB));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int cur = u & 1, slot = u % RU;
+                const int gu = chunk * NU + u;                       // (NU is even and a multiple of RU: slots line up)
+                const bool more = gu + 1 < total;
+                const int nu = (u + 1) % NU, nchunk = (u + 1 < NU) ? chunk : chunk + 1;
+                const char *nfrag = lds + tap_off(nu % NT, RSB) + 32 * (nu / NT) + (more ? nchunk : chunk) * 64;
+                const int ur = u - 1 + RU;
+                const int rchunk = ur >= NU ? chunk + 1 : chunk;
+                const bool refill = rchunk < n_chunks;
+                const _Float16 *rw = w_unit(p.wb, refill ? rchunk : chunk, ur >= NU ? ur - NU : ur);
+                const int rslot = (u + RU - 1) % RU;
+#pragma unroll
+                for (int q = 0; q < NMFB; ++q) {
+                    const int ms = q / NSUB, ns = q % NSUB;
+                    acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
+                    if (q & 1) {
+                        const int lm = q >> 1;
+                        if (lm < MSB && more) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + b_off[lm]);
+                    } else {
+                        const int e = q >> 1;
+                        if (e < NSUB && refill && (gu > 0)) bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue of the block: bn2 + residual (the block's own input) + clip, as conv_mfma_f16_kernel ----
+    constexpr int TP = NSUB * 32 + 4, LPP = NSUB * 4, PPI = 64 / LPP, NRI = 32 / PPI;
+    const int flags = p.flags;
+    __syncthreads();                            // every wave is done reading the intermediate tile
+    float *tb = (float *)lds + wave * (2 * 32 * TP);
+    const int my_c = (lane % LPP) * 8, my_p = lane / LPP;
+    const int col = n_base + my_c;
+    f32x4 sc[2] = {*(const f32x4 *)(p.sb + col), *(const f32x4 *)(p.sb + col + 4)};
+    f32x4 sh[2] = {*(const f32x4 *)(p.hb + col), *(const f32x4 *)(p.hb + col + 4)};
+    const bool out32 = (flags & DS_EPI_OUT_F32) != 0;
+    const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
+    const ds_buffer rbuf = ds_make_buffer(p.x, p.x_bytes);
+    const int lin_base = (b * p.H + r0) * W;
+    const int lin_valid = (p.H - r0 < BK_R ? p.H - r0 : BK_R) * W;
+    unsigned voff[MSB][NRI];
+    f32x4 resv[MSB][NRI];
+#pragma unroll
+    for (int ms = 0; ms < MSB; ++ms)
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            const int m = (wm * MSB + ms) * 32 + k * PPI + my_p;
+            const int off = m < lin_valid ? lin_base + m : -1;
+            const unsigned cl = (unsigned)(off * C + col);
+            voff[ms][k] = off < 0 ? DS_BUFFER_OOB
+                          : p.y_plane_stride ? (unsigned)(col >> 4) * p.y_plane_stride + (unsigned)off * 16u + (unsigned)(col & 15) : cl;
+            resv[ms][k] = ds_buffer_load_f32x4(rbuf, off >= 0 ? cl * 2u : DS_BUFFER_OOB);
+        }
+    auto put_tile = [&](int ms) {
+        float *dst = tb + (ms & 1) * (32 * TP);
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
+                *(f32x4 *)(dst + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
+            }
+    };
+    put_tile(0);
+#pragma unroll
+    for (int ms = 0; ms < MSB; ++ms) {
+        const int cb = ms & 1;
+        ds_wave_sync();
+        const float *src = tb + cb * (32 * TP);
+        f32x4 tv[NRI][2];
+#pragma unroll
+        for (int k = 0; k < NRI; ++k)
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
+        if (ms + 1 < MSB) put_tile(ms + 1);
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            const f16x8 r8 = __builtin_bit_cast(f16x8, resv[ms][k]);
+            f32x4 o[2];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = tv[k][hq][j] * sc[hq][j] + sh[hq][j];
+                    t += (float)r8[4 * hq + j];
+                    o[hq][j] = fminf(fmaxf(t, 0.0f), 20.0f);
+                }
+            const unsigned vo = voff[ms][k];
+            if (out32) {
+                const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
+                ds_buffer_store_f32x4(ybuf, bo, o[0]);
+                ds_buffer_store_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
+            } else {
+                f16x8 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = (_Float16)o[0][j];
+                    h[4 + j] = (_Float16)o[1][j];
+                }
+                ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+            }
+        }
+    }
+}
+
+static size_t block_lds_bytes(int W, int C, int waves) {
+    const size_t tileA = (size_t)(BK_R + 4) * (W + 2) * BK_PS;
+    const size_t interm = (size_t)(BK_R + 2) * (W + 2) * (C * 2 + 16);
+    const size_t epi = (size_t)2 * waves * 32 * (2 * 32 + 4) * 4;
+    return std::max(std::max(2 * tileA, interm), epi) + 64;
+}
+
+}  // namespace
+
+// 1 if ds_conv_block_f16 handles this block geometry (the shallow stages: W = 32 with 64 channels, W = 16 with 128)
+extern "C" int ds_conv_block_f16_supported(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0) return 0;
+    if ((long long)B * H * W * C >= (1ll << 30)) return 0;
+    return (W == 32 && C == 64) || (W == 16 && C == 128);
+}
+
+// y = clip(bn2(conv3x3(clip(bn1(conv3x3(x))))) + x) for one BasicBlock in eval mode (reference model.py:66-82 with
+// module.eval()); x, y fp16 channels-last [B,H,W,C]; wa / wb from ds_pack_conv_weight_f16; flags: DS_EPI_OUT_F32,
+// DS_EPI_OUT_PLANES16.  Bit-identical to two ds_conv_fwd_f16 calls.
+extern "C" int ds_conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
+                                 const float *shift_a, const float *scale_b, const float *shift_b, void *y, int B, int H,
+                                 int W, int C, int flags, void *stream) {
+    DS_REQUIRE(x_f16 && wa_f16 && wb_f16 && scale_a && shift_a && scale_b && shift_b && y, DS_ERR_NULL);
+    DS_REQUIRE(ds_conv_block_f16_supported(B, H, W, C), DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(DS_ALIGNED16(x_f16) && DS_ALIGNED16(wa_f16) && DS_ALIGNED16(wb_f16) && DS_ALIGNED16(y) &&
+                   DS_ALIGNED16(scale_a) && DS_ALIGNED16(shift_a) && DS_ALIGNED16(scale_b) && DS_ALIGNED16(shift_b),
+               DS_ERR_ALIGNMENT);
+    DS_REQUIRE(!((flags & DS_EPI_OUT_F32) && (flags & DS_EPI_OUT_PLANES16)), DS_ERR_UNSUPPORTED);
+    BlockK k;
+    k.x = (const _Float16 *)x_f16; k.wa = (const _Float16 *)wa_f16; k.wb = (const _Float16 *)wb_f16;
+    k.sa = scale_a; k.ha = shift_a; k.sb = scale_b; k.hb = shift_b; k.y = y;
+    k.B = B; k.H = H; k.W = W; k.C = C;
+    k.tiles_per_img = ds_ceil_div(H, BK_R);
+    k.flags = flags;
+    const long long n = (long long)B * H * W * C;
+    k.x_bytes = (unsigned)(n * 2);
+    k.y_bytes = (unsigned)(n * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
+    k.y_plane_stride = (flags & DS_EPI_OUT_PLANES16) ? (unsigned)((long long)B * H * W * 16) : 0u;
+    const int grid = B * k.tiles_per_img;
+    if (C == 64) {          // W = 32: 2 x 1 waves, 12 x 32 x 4 items over 128 threads
+        DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 16>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+    } else {                // W = 16, C = 128: 1 x 2 waves
+        DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 8>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+    }
+    return ds_last_launch_error();
+}

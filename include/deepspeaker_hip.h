@@ -172,6 +172,15 @@ int ds_conv_fwd_f16_splitk(const ds_conv_shape *s, const void *x_f16, const void
 /* out8 = {M tile, N tile, rows per segment, segments per tile, workgroups, LDS bytes, threads per workgroup,
  * 1000 * double-buffered + 100 * (16-channel chunks) + staging items per thread} */
 int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8);
+/* One whole BasicBlock in eval mode as ONE kernel (reference model.py:66-82):
+ *     y = clip(bn2(conv3x3(clip(bn1(conv3x3(x))))) + x)
+ * for the shallow stages (W = 32 with 64 channels, W = 16 with 128: ds_conv_block_f16_supported), where a workgroup
+ * of the single-layer kernel spends more time in its prologue and epilogue than contracting.  The intermediate
+ * activation lives in LDS only.  Bit-identical to two ds_conv_fwd_f16 calls.  flags: DS_EPI_OUT_F32, DS_EPI_OUT_PLANES16. */
+int ds_conv_block_f16_supported(int B, int H, int W, int C);
+int ds_conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
+                      const float *shift_a, const float *scale_b, const float *shift_b, void *y, int B, int H, int W,
+                      int C, int flags, void *stream);
 int ds_cast_f32_to_f16(const float *x, void *y_f16, long long n, void *stream);
 int ds_cast_f16_to_f32(const void *x_f16, float *y, long long n, void *stream);
 

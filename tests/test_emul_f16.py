@@ -189,3 +189,44 @@ def test_conv1_fp16_output():
              fl | DS_EPI_OUT_F16, None)
     assert np.isfinite(y32).all()
     assert np.array_equal(y16, y32.astype(np.float16))
+
+
+@pytest.mark.parametrize("geom", [(2, 11, 32, 64), (1, 19, 16, 128), (1, 8, 32, 64), (1, 3, 16, 128)])
+@pytest.mark.parametrize("out", ["f16", "f32", "planes"])
+def test_conv_block_fused_equals_two_convolutions(geom, out):
+    """ds_conv_block_f16 (both 3x3 layers of a BasicBlock in one kernel, the intermediate in LDS only) must be
+    BIT-identical to two ds_conv_fwd_f16 calls: same products, same accumulation order, same fp16 rounding points."""
+    from deepspeaker_pytorch_amd._native import DS_EPI_OUT_PLANES16
+    lib = emul_lib()
+    b, h, w, c = geom
+    assert lib.raw("ds_conv_block_f16_supported")(b, h, w, c) == 1
+    rs = np.random.RandomState(3 + sum(geom))
+    x = (np.abs(rs.randn(b, h, w, c)) * 2).astype(np.float16)
+    xa = to_aligned(x, np.float16)
+    packs, folds = [], []
+    for _ in range(2):
+        wt = (rs.randn(c, c, 3, 3) / np.sqrt(c * 9)).astype(np.float32)
+        wp, src = aligned(wt.size, np.float16), to_aligned(wt)
+        lib.call("ds_pack_conv_weight_f16", ptr(src), ptr(wp), c, c, 3, None)
+        packs.append(wp)
+        folds.append((to_aligned(rs.uniform(0.5, 1.5, c).astype(np.float32)), to_aligned((rs.randn(c) * 0.5).astype(np.float32))))
+    shp = ConvShape(b, h, w, c, c, 3, 1)
+    mid = aligned((b, h, w, c), np.float16, fill=np.nan)
+    lib.call("ds_conv_fwd_f16", ctypes.byref(shp), ptr(xa), ptr(packs[0]), ptr(folds[0][0]), ptr(folds[0][1]), None, ptr(mid),
+             DS_EPI_AFFINE | DS_EPI_CLIP, None)
+    oflag = {"f16": 0, "f32": DS_EPI_OUT_F32, "planes": DS_EPI_OUT_PLANES16}[out]
+    dt = np.float32 if out == "f32" else np.float16
+    ref = aligned((b, h, w, c), dt, fill=np.nan)
+    lib.call("ds_conv_fwd_f16", ctypes.byref(shp), ptr(mid), ptr(packs[1]), ptr(folds[1][0]), ptr(folds[1][1]), ptr(xa), ptr(ref),
+             DS_EPI_AFFINE | DS_EPI_CLIP | DS_EPI_RESIDUAL | oflag, None)
+    got = aligned((b, h, w, c), dt, fill=np.nan)
+    lib.call("ds_conv_block_f16", ptr(xa), ptr(packs[0]), ptr(packs[1]), ptr(folds[0][0]), ptr(folds[0][1]), ptr(folds[1][0]),
+             ptr(folds[1][1]), ptr(got), b, h, w, c, oflag, None)
+    assert np.isfinite(got.astype(np.float32)).all()
+    assert np.array_equal(got, ref)
+
+
+def test_conv_block_unsupported_geometries():
+    lib = emul_lib()
+    assert lib.raw("ds_conv_block_f16_supported")(4, 20, 8, 256) == 0
+    assert lib.raw("ds_conv_block_f16_supported")(4, 20, 32, 128) == 0
