@@ -423,6 +423,20 @@ class Engine:
                                     layout_flags=DS_CONV_IN_PLANES16 if (planes and i == 2) else 0)
             mask_call(a, s, h)
             cin = c
+            last_stage = s == len(pw.stages) - 1
+            if (h16 and not masked and not low_latency
+                    and self.lib.raw("ds_conv_block_f16_supported")(B, h, w, c) == 1):
+                # the shallow stages: the whole BasicBlock as one kernel, the intermediate activation in LDS only
+                sc1, sh1 = folded[f"model.layer{i}.0.bn1"]
+                sc2, sh2 = folded[f"model.layer{i}.0.bn2"]
+                out = buf(B, h, w, c, dtype=torch.float32 if last_stage else torch.float16)
+                fl = (DS_EPI_OUT_F32 if last_stage else 0) | (DS_EPI_OUT_PLANES16 if (planes and i == 1) else 0)
+                calls.append((self.lib.raw("ds_conv_block_f16"),
+                              (self._p(a), self._p(sw.l_conv1_f16), self._p(sw.l_conv2_f16), self._p(sc1), self._p(sh1),
+                               self._p(sc2), self._p(sh2), self._p(out), B, h, w, c, fl, st_slot),
+                              f"block3x3_{c}_{h}x{w}", 2 * 2.0 * B * h * w * c * c * 9))
+                a = out
+                continue
             sc, sh = folded[f"model.layer{i}.0.bn1"]
             y, _, _ = conv_call(self._p(a), sw.l_conv1, sw.l_conv1_bf16, B, h, w, c, c, 3, 1, sc, sh, None, sw.l_conv1_f16)
             mask_call(y, s, h)
