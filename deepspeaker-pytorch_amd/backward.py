@@ -130,6 +130,46 @@ def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad, w_dgrad_bf16=None):
     return gx
 
 
+_wgrad_streams: Dict[torch.device, "torch.cuda.Stream"] = {}
+OVERLAP_FILTER_GRADIENTS = True        # module default of backward_train(overlap_filter_gradients=None); tools flip it for A/B runs
+
+
+class _FilterGradLane:
+    """Where the filter-gradient kernels run.  A layer's filter gradient is a leaf of the backward pass: nothing
+    downstream waits for it, while the data gradient -> BatchNorm-backward chain next to it is what the earlier
+    layers wait for, and that chain is half HBM-bound element-wise passes.  On the GPU the filter gradients are
+    therefore enqueued on a second HIP stream (fork after the kernel that produced dL/d(conv output), join at the end
+    of the pass): the matrix-core-bound gradient kernels and the HBM-bound BatchNorm passes then share the chip
+    instead of queueing behind each other.  Results are those of the one-stream order (same kernels, same inputs).
+    On the host emulator (CPU tensors) everything stays in program order."""
+
+    def __init__(self, device: torch.device, enabled: bool = True):
+        self.main = self.side = None
+        if device.type == "cuda" and enabled:
+            self.main = torch.cuda.current_stream(device)
+            side = _wgrad_streams.get(device)
+            if side is None:
+                side = _wgrad_streams[device] = torch.cuda.Stream(device=device)
+            self.side = side
+            side.wait_stream(self.main)
+
+    def run(self, fn, *inputs):
+        """fn() on the side stream, ordered after everything enqueued on the main stream so far; `inputs` are the
+        main-stream tensors it reads (their memory must not be recycled before the side stream is done with them)"""
+        if self.side is None:
+            return fn()
+        self.side.wait_event(self.main.record_event())
+        for t in inputs:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+
+
 class _GradBuckets:
     """The filter / fc gradients of one backward pass, laid out as one flat buffer per stage (+ one for fc): the
     gradient kernels write straight into views of their bucket, and under data parallelism each bucket's
@@ -164,13 +204,14 @@ class _GradBuckets:
 
 def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
                    ge: torch.Tensor, reducer=None, precision: str = "f32",
-                   reduce_gradients: bool = False) -> Dict[str, torch.Tensor]:
+                   reduce_gradients: bool = False, overlap_filter_gradients=None) -> Dict[str, torch.Tensor]:
     """Parameter gradients (reference key names, reference shapes) given dL/d(embedding) `ge` [B,512].
     precision "bf16x3": data and filter gradients of the 3x3 / 5x5 layers run on the bf16 matrix cores with
     split operands; conv1 and fc stay on the f32 matrix cores.  `reduce_gradients` (data parallelism): the
     per-stage gradient buckets are all-reduced over `reducer` as the pass produces them, overlapped with the rest
-    of the pass; the returned gradients are then the global sums."""
+    of the pass; the returned gradients are then the global sums.  `overlap_filter_gradients`: see _FilterGradLane."""
     x3 = precision == "bf16x3"
+    lane = _FilterGradLane(ge.device, OVERLAP_FILTER_GRADIENTS if overlap_filter_gradients is None else overlap_filter_gradients)
     lib = eng.lib
     grads: Dict[str, torch.Tensor] = {}
     n_stages = len(pw.stages)
@@ -220,15 +261,17 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         g_out, gz, gg, gbeta = _bn_bwd(eng, g, None, None if g_is_masked else c_act, saved.raws[name],
                                        saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
-        grads[f"model.layer{i}.0.conv2.weight"] = _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3), x3=x3,
-                                                         out=buckets.views[f"model.layer{i}.0.conv2.weight"])
+        grads[f"model.layer{i}.0.conv2.weight"] = lane.run(
+            lambda gz=gz: _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3), x3=x3,
+                                 out=buckets.views[f"model.layer{i}.0.conv2.weight"]), gz)
         g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad, pw.stages[s].l_conv2_dgrad_bf16 if x3 else None)
         # y = clip(bn1(conv1(r)))                  (model.py:69-71)
         name = f"model.layer{i}.0.bn1"
         _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
-        grads[f"model.layer{i}.0.conv1.weight"] = _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3), x3=x3,
-                                                         out=buckets.views[f"model.layer{i}.0.conv1.weight"])
+        grads[f"model.layer{i}.0.conv1.weight"] = lane.run(
+            lambda gz=gz: _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3), x3=x3,
+                                 out=buckets.views[f"model.layer{i}.0.conv1.weight"]), gz)
         g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad, pw.stages[s].l_conv1_dgrad_bf16 if x3 else None)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv-path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
@@ -237,11 +280,12 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
         shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)
         x_in = saved.x if s == 0 else saved.acts[f"stage{s}.c"]
-        grads[f"model.conv{i}.weight"] = _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5), x3=x3,
-                                                out=buckets.views[f"model.conv{i}.weight"])
-        buckets.done(s)                         # this stage's three filter gradients are enqueued: reduce them now
+        grads[f"model.conv{i}.weight"] = lane.run(
+            lambda gz=gz: _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5), x3=x3, out=buckets.views[f"model.conv{i}.weight"]), gz)
+        lane.run(lambda: buckets.done(s))       # this stage's three filter gradients are enqueued: reduce them now
         if s > 0:
             g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad, pw.stages[s].conv_dgrad_bf16 if x3 else None)   # unmasked: the next bn2 step masks it
             g_is_masked = False
+    lane.join()
     buckets.finish()
     return grads
