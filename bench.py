@@ -196,9 +196,12 @@ def main():
 
     def measure(precision, steps, warmup):
         model = load_model(precision).eval()
+        last_mined = [None] * n_slots
 
         def step(slot=0):
             emb_glob, lab_glob = emb_globs[slot], lab_globs[slot]
+            if multi and last_mined[slot] is not None:
+                last_mined[slot].wait()                 # the previous search over this slot's gather buffers has read them
             with torch.no_grad():
                 if args.split_apn:
                     embs = [model(x) for x in data]
@@ -208,7 +211,10 @@ def main():
                     embs = list(e_all.split(BATCH_TRIPLETS))
                 # cross-GPU semi-hard negative search over the all-gathered global batch (BASELINE configs[2]);
                 # at N = 1 the candidate set is the local batch, so per-GPU work has the same shape.  The
-                # gathers run on RCCL's stream while the local loss / filter kernels run on ours.
+                # gathers run on RCCL's stream while the local loss / filter kernels run on ours; the search (its
+                # result feeds the NEXT batch) is enqueued on the side stream next to the near-tie refinement, so
+                # this stream goes straight on to its next forward.  The timed region ends with a device-wide
+                # synchronize: all of it is inside.
                 if multi:
                     h_emb = dist.all_gather_into_tensor(emb_glob, e_all, async_op=True)
                     h_lab = dist.all_gather_into_tensor(lab_glob, labels_loc, async_op=True)
@@ -219,9 +225,10 @@ def main():
                 if multi:
                     h_emb.wait()
                     h_lab.wait()
-                    mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob)
+                    mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob, side_stream=True)
                 else:
-                    mined = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels_loc)
+                    mined = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels_loc, side_stream=True)
+            last_mined[slot] = mined
             return loss, sel, mined
 
         return timed(step, steps, warmup)

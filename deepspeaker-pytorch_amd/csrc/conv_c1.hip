@@ -14,6 +14,7 @@ namespace {
 
 constexpr int C1_RT = 16;         // output rows per workgroup
 constexpr int C1_COUT = 64;
+constexpr int C1_VSLOTS = 3;      // 16-byte staging pieces per thread (35 rows x 64 columns = 560 pieces)
 
 struct Conv1K {
     const float *x, *w, *scale, *shift;
@@ -105,6 +106,9 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_kernel(const Conv1K p) {
 // (lane = pixel), so the epilogue is the convolution kernel's: turn each 32-pixel sub-tile around through a
 // wave-private LDS buffer and store whole 256-byte pixel rows with raw buffer stores.  ~5x fewer issued
 // instructions per pixel than the VALU kernel (which is issue-bound at 1.6x the time of its HBM traffic).
+// OUT16 / STATS (the output type and the BatchNorm partial sums) are compile-time: the store loop is straight-line
+// code; the affine is data (identity when off) and the clip a select.
+template <bool OUT16, bool STATS>
 __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, unsigned y_bytes) {
     float *lds = ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,35 +135,73 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
                 w_hi[ks][ns][i] = h;
                 w_lo[ks][ns][i] = (__bf16)(v - (float)h);
             }
-    // tap offsets of this lane's 16 taps inside the input tile (taps >= 25 are padding: read word 0, times 0)
+    // tap offsets of this lane's 16 taps inside the input tile (taps >= 25 are padding: the pixel's own first tap,
+    // multiplied by a zero filter entry)
     int toff[2][8];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int t = 16 * ks + 8 * lhi + i;
-            toff[ks][i] = t < 25 ? (t / 5) * p.cols_in + (t % 5) : -1;
+            toff[ks][i] = t < 25 ? (t / 5) * p.cols_in + (t % 5) : 0;      // padding taps: any finite word (x 0)
         }
 
-    // stage the zero-padded input tile
+    // stage the zero-padded input tile.  The tile's image rows are whole rows of x, i.e. ONE contiguous span:
+    // every thread requests its 16-byte pieces up front (a few independent loads instead of a chain of ~10
+    // dependent word loads), zero-fills the tile meanwhile, then drops the pieces into the padded rows.
     const float *xb = p.x + (size_t)b * p.H * p.W;
-    const float rcp_ci = 1.0f / (float)p.cols_in;
-    for (int i = tid; i < n_in; i += 256) {
-        const int rr = ds_div_small(i, p.cols_in, rcp_ci), cc = i - rr * p.cols_in;
-        const int h = 2 * r0 - 2 + rr, w = cc - 2;
-        lds[i] = (h >= 0 && h < p.H && w >= 0 && w < p.W) ? xb[(size_t)h * p.W + w] : 0.0f;
+    if ((p.W & 3) == 0 && ROWS_IN * p.W <= 4 * 256 * C1_VSLOTS) {
+        const int h_first = 2 * r0 - 2;
+        const int h_lo = h_first < 0 ? 0 : h_first;
+        const int h_hi = (h_first + ROWS_IN < p.H) ? h_first + ROWS_IN : p.H;          // image rows [h_lo, h_hi)
+        const int n4 = (h_hi - h_lo) * (p.W >> 2);
+        const f32x4 *src = (const f32x4 *)(xb + (size_t)h_lo * p.W);
+        f32x4 piece[C1_VSLOTS];
+#pragma unroll
+        for (int it = 0; it < C1_VSLOTS; ++it) {
+            const int i = tid + it * 256;
+            piece[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < n4) piece[it] = src[i];
+        }
+        for (int i = tid; i < n_in; i += 256) lds[i] = 0.0f;
+        __syncthreads();
+        const int w4 = p.W >> 2;
+        const float rcp_w4 = 1.0f / (float)w4;
+#pragma unroll
+        for (int it = 0; it < C1_VSLOTS; ++it) {
+            const int i = tid + it * 256;
+            if (i < n4) {
+                const int rr = ds_div_small(i, w4, rcp_w4), q = i - rr * w4;
+                float *dst = lds + (h_lo - h_first + rr) * p.cols_in + 2 + 4 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j] = piece[it][j];
+            }
+        }
+    } else {
+        const float rcp_ci = 1.0f / (float)p.cols_in;
+        for (int i = tid; i < n_in; i += 256) {
+            const int rr = ds_div_small(i, p.cols_in, rcp_ci), cc = i - rr * p.cols_in;
+            const int h = 2 * r0 - 2 + rr, w = cc - 2;
+            lds[i] = (h >= 0 && h < p.H && w >= 0 && w < p.W) ? xb[(size_t)h * p.W + w] : 0.0f;
+        }
     }
     __syncthreads();
 
     const int n_pix = C1_RT * p.Wo, n_sub = (n_pix + 31) >> 5;
     const float rcp_wo = 1.0f / (float)p.Wo;
-    constexpr int LPP = 16, PPI = 4, NRI = 8;               // lanes per pixel row, rows per instruction
-    const int my_c = (lane % LPP) * 4, my_p = lane / LPP;
-    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    // lanes per pixel row, rows per store instruction: a lane owns 4 channels (16 bytes of f32) or 8 (16 bytes of fp16)
+    constexpr int LPP = OUT16 ? 8 : 16, PPI = 64 / LPP, NRI = 32 / PPI, CPL = C1_COUT / LPP;
+    const int my_c = (lane % LPP) * CPL, my_p = lane / LPP;
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, sc4b = sc4, sh4b = sh4;
     if (p.flags & DS_EPI_AFFINE) {
         sc4 = *(const f32x4 *)(p.scale + my_c);
         sh4 = *(const f32x4 *)(p.shift + my_c);
+        if (OUT16) {
+            sc4b = *(const f32x4 *)(p.scale + my_c + 4);
+            sh4b = *(const f32x4 *)(p.shift + my_c + 4);
+        }
     }
+    const bool clip = p.flags & DS_EPI_CLIP;
     const ds_buffer ybuf = ds_make_buffer(p.y, y_bytes);
     const int pix0 = (b * p.Ho + r0) * p.Wo;               // first output pixel of the tile
     const int rows_left = p.Ho - r0;
@@ -170,16 +212,15 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
         const int m = sub * 32 + l31;
         const int r = ds_div_small(m, p.Wo, rcp_wo), c = m - r * p.Wo;
         const float *in = lds + ((m < n_pix) ? (2 * r) * p.cols_in + 2 * c : 0);
-        bf16x8 x_hi[2], x_lo[2];
+        ds_u32x4 xh[2], xl[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float raw = in[toff[ks][i] >= 0 ? toff[ks][i] : 0];
-                const float v = toff[ks][i] >= 0 ? raw : 0.0f;
-                const __bf16 h = (__bf16)v;
-                x_hi[ks][i] = h;
-                x_lo[ks][i] = (__bf16)(v - (float)h);
+            for (int i = 0; i < 8; i += 2) {            // two taps per packed conversion
+                unsigned hi2, lo2;
+                ds_split_bf16x2(in[toff[ks][i]], in[toff[ks][i + 1]], hi2, lo2);
+                xh[ks][i >> 1] = hi2;
+                xl[ks][i >> 1] = lo2;
             }
         f32x16 acc[2];
 #pragma unroll
@@ -189,11 +230,11 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], x_lo[ks], acc[ns]);
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], __builtin_bit_cast(bf16x8, xl[ks]), acc[ns]);
 #pragma unroll
-            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_lo[ks][ns], x_hi[ks], acc[ns]);
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_lo[ks][ns], __builtin_bit_cast(bf16x8, xh[ks]), acc[ns]);
 #pragma unroll
-            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], x_hi[ks], acc[ns]);
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], __builtin_bit_cast(bf16x8, xh[ks]), acc[ns]);
         }
         // ---- epilogue of the sub-tile: lane = pixel, register quad g = channels 8g + 4*lhi .. +3 ----
 #pragma unroll
@@ -214,29 +255,38 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
             const unsigned eoff = (unsigned)((pix0 + pm) * C1_COUT + my_c);
             const unsigned voff = live ? eoff * 4u : DS_BUFFER_OOB;
             f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c);
+            if (OUT16) {
+                // fp16 activations for the fp16 convolution path: packed f32 affine, packed conversion, packed fp16 clip
+                // (0 and 20 are fp16 numbers and rounding is monotonic: clip(round(t)) == round(clip(t)))
+                const f32x4 vb = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c + 4);
+                const f32x4 ta = v * sc4 + sh4, tb4 = vb * sc4b + sh4b;
+                f16x8 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = (_Float16)ta[j];
+                    h[4 + j] = (_Float16)tb4[j];
+                }
+                const f16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {20, 20, 20, 20, 20, 20, 20, 20};
+                const f16x8 hc = __builtin_elementwise_min(__builtin_elementwise_max(h, lo), hi);
+                h = clip ? hc : h;
+                ds_buffer_store_f32x4(ybuf, live ? eoff * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = v[j];
-                if (p.flags & DS_EPI_STATS) {
+                if (STATS) {
                     ps1[j] += live ? t : 0.0f;
                     ps2[j] += live ? t * t : 0.0f;
                 }
                 t = t * sc4[j] + sh4[j];
-                if (p.flags & DS_EPI_CLIP) t = fminf(fmaxf(t, 0.0f), 20.0f);
-                v[j] = t;
+                v[j] = clip ? fminf(fmaxf(t, 0.0f), 20.0f) : t;       // a select, not a branch (NaN passes when off)
             }
-            if (p.flags & DS_EPI_OUT_F16) {     // fp16 activations for the fp16 convolution path
-                f16x4 h;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
-                ds_buffer_store_b64(ybuf, live ? eoff * 2u : DS_BUFFER_OOB, __builtin_bit_cast(ds_u32x2, h));
-            } else {
-                ds_buffer_store_f32x4(ybuf, voff, v);
-            }
+            ds_buffer_store_f32x4(ybuf, voff, v);
         }
         ds_wave_sync();
     }
-    if (p.flags & DS_EPI_STATS) {
+    if (STATS && !OUT16) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             ps1[j] += ds_shfl_xor(ps1[j], 16);
@@ -318,7 +368,12 @@ extern "C" int ds_conv5x5s2_c1_fwd_bf16(const float *x, const float *w_packed, c
     k.flags = flags;
     const size_t n_in = (size_t)(2 * (C1_RT - 1) + 5) * k.cols_in;
     const size_t lds = (((n_in + 3) & ~(size_t)3) + 4 * 32 * (C1_COUT + 4) + 4 * C1_COUT * 2) * 4;
-    DS_LAUNCH(conv5x5s2_c1_bf16_kernel, B * k.tiles_per_img, 256, lds, stream, k,
-              (unsigned)((long long)B * k.Ho * k.Wo * C1_COUT * ((flags & DS_EPI_OUT_F16) ? 2 : 4)));
+    const unsigned y_bytes = (unsigned)((long long)B * k.Ho * k.Wo * C1_COUT * ((flags & DS_EPI_OUT_F16) ? 2 : 4));
+    const int grid = B * k.tiles_per_img;
+    const bool h16 = flags & DS_EPI_OUT_F16, st = flags & DS_EPI_STATS;
+    DS_REQUIRE(!(h16 && st), DS_ERR_UNSUPPORTED);          // statistics come with the f32 (training) output
+    if (h16) DS_LAUNCH((conv5x5s2_c1_bf16_kernel<true, false>), grid, 256, lds, stream, k, y_bytes);
+    else if (st) DS_LAUNCH((conv5x5s2_c1_bf16_kernel<false, true>), grid, 256, lds, stream, k, y_bytes);
+    else DS_LAUNCH((conv5x5s2_c1_bf16_kernel<false, false>), grid, 256, lds, stream, k, y_bytes);
     return ds_last_launch_error();
 }

@@ -137,23 +137,62 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     return TripletSelection(idx, count, d_p, d_n, mean_diff, loss, t["amb_count"], cap, ready)
 
 
+class MinedNegatives:
+    """Result of a search that was enqueued on the side stream: `indices` / `distances` order the calling stream
+    after the search before they hand out the tensors; unpacks like the plain (indices, distances) tuple."""
+
+    def __init__(self, idx, dist, ready):
+        self._idx, self._dist, self._ready = idx, dist, ready
+
+    def wait(self):
+        if self._ready is not None:
+            torch.cuda.current_stream(self._idx.device).wait_event(self._ready)
+            self._ready = None
+        return self
+
+    @property
+    def indices(self) -> torch.Tensor:
+        return self.wait()._idx
+
+    @property
+    def distances(self) -> torch.Tensor:
+        return self.wait()._dist
+
+    def __iter__(self):
+        self.wait()
+        return iter((self._idx, self._dist))
+
+
 def mine_semihard_negatives(anchors: torch.Tensor, positives: torch.Tensor, anchor_labels: torch.Tensor,
-                            candidates: torch.Tensor, candidate_labels: torch.Tensor):
+                            candidates: torch.Tensor, candidate_labels: torch.Tensor, side_stream: bool = False):
     """Cross-GPU hard-negative search (BASELINE.json north_star; no reference counterpart).
 
     `candidates` / `candidate_labels` are normally the RCCL all-gather of every rank's embeddings and
     speaker ids.  For anchor i returns the index j of the candidate with a different speaker that is
     closest to the anchor among those farther than its positive (semi-hard), else the closest one;
-    ties -> lowest j; -1 if no candidate has another speaker.  Also returns the distances d(a_i, x_j)."""
+    ties -> lowest j; -1 if no candidate has another speaker.  Also returns the distances d(a_i, x_j).
+
+    `side_stream`: the mined negatives feed the NEXT batch, nothing of this step waits for them -- enqueue the search
+    on the side stream (after everything enqueued so far) and return a `MinedNegatives`, so the caller's stream goes
+    straight on to its next forward."""
     _require_cuda(anchors, "mine_semihard_negatives")
     eng = get_engine()
     a, p, c = (t.detach().contiguous() for t in (anchors, positives, candidates))
-    d_p = eng.pairwise_distance(a, p)
-    n, d = a.shape
-    idx = torch.empty(n, dtype=torch.int64, device=a.device)
-    dist_out = torch.empty(n, dtype=torch.float32, device=a.device)
-    ws = torch.empty(eng.lib.raw("ds_mine_workspace_floats")(n, c.shape[0]), dtype=torch.float32, device=a.device)
-    eng.lib.call("ds_mine_semihard_f32", eng._p(a), eng._p(d_p), eng._p(anchor_labels.to(torch.int64).contiguous()),
-                 eng._p(c), eng._p(candidate_labels.to(torch.int64).contiguous()), eng._p(ws), eng._p(idx),
-                 eng._p(dist_out), n, c.shape[0], d, eng._stream(a))
+    la, lc = anchor_labels.to(torch.int64).contiguous(), candidate_labels.to(torch.int64).contiguous()
+    main = torch.cuda.current_stream(a.device)
+    side = _side_stream(a.device) if side_stream else main
+    if side_stream:
+        side.wait_stream(main)
+        for t in (a, p, c, la, lc):
+            t.record_stream(side)                   # main-stream memory the side stream reads
+    with torch.cuda.stream(side):
+        d_p = eng.pairwise_distance(a, p)
+        n, d = a.shape
+        idx = torch.empty(n, dtype=torch.int64, device=a.device)
+        dist_out = torch.empty(n, dtype=torch.float32, device=a.device)
+        ws = torch.empty(eng.lib.raw("ds_mine_workspace_floats")(n, c.shape[0]), dtype=torch.float32, device=a.device)
+        eng.lib.call("ds_mine_semihard_f32", eng._p(a), eng._p(d_p), eng._p(la), eng._p(c), eng._p(lc), eng._p(ws),
+                     eng._p(idx), eng._p(dist_out), n, c.shape[0], d, eng._stream(a))
+        if side_stream:
+            return MinedNegatives(idx, dist_out, side.record_event())
     return idx, dist_out

@@ -50,6 +50,19 @@ static inline f32x16 ds_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// two f32 values -> their bf16 "hi" parts and the bf16 "lo" parts of the remainders (split operands: x = hi + lo up
+// to 2^-17 |x|), each pair packed into one dword with ONE packed conversion (v_cvt_pk_bf16_f32); same bits as the
+// scalar (__bf16)v / (__bf16)(v - (float)hi) sequence
+typedef float ds_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ds_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ds_split_bf16x2(float a, float b, unsigned &hi, unsigned &lo) {
+    const ds_bf16x2 h = __builtin_convertvector(ds_f32x2{a, b}, ds_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    const ds_bf16x2 l = __builtin_convertvector(ds_f32x2{a - ha, b - hb}, ds_bf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 // v_mfma_f32_32x32x16_f16: same fragment layout; fp16 products are exact in f32, summed as above
 static inline f32x16 ds_mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
     float A[8][64], B[8][64];
@@ -122,6 +135,7 @@ static inline f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte_off) {
 static inline void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
     if ((unsigned long long)byte_off + 16 <= b.bytes) memcpy(b.base + byte_off, &v, 16);
 }
+typedef unsigned int ds_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int ds_u32x2 __attribute__((ext_vector_type(2)));
 static inline void ds_buffer_store_b64(ds_buffer b, unsigned byte_off, ds_u32x2 v) {
     if ((unsigned long long)byte_off + 8 <= b.bytes) memcpy(b.base + byte_off, &v, 8);

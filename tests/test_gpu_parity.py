@@ -393,6 +393,11 @@ def test_mining_kernel_vs_oracle(dev):
     np.testing.assert_array_equal(idx.cpu().numpy(), ref)
     ref_d = np.sqrt(((a - cand[ref]) ** 2).sum(1) + 1e-4 / 512)
     assert rel_err(dd.cpu().numpy(), ref_d) < 1e-5
+    # enqueued on the side stream (the caller's stream goes on; consumers are ordered after the search): same result
+    mined = mine_semihard_negatives(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(la).cuda(),
+                                    torch.from_numpy(cand).cuda(), torch.from_numpy(lc).cuda(), side_stream=True)
+    idx2, dd2 = mined
+    assert torch.equal(idx2, idx) and torch.equal(dd2, dd) and torch.equal(mined.indices, idx)
 
 
 def test_data_parallel_world1_nccl(dev):
