@@ -26,7 +26,7 @@ def _bn_bwd_group(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     Bm = z.shape[0] // G
     dev = z.device
     n_pix = (z.numel() // c) // G
-    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix)
+    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix, c)
     gy, gz = torch.empty_like(z), torch.empty_like(z)
     gg_all = torch.empty((G, c), dtype=torch.float32, device=dev)
     gb_all = torch.empty((G, c), dtype=torch.float32, device=dev)
@@ -74,7 +74,7 @@ def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     c = z.shape[-1]
     n_pix = z.numel() // c
     dev = z.device
-    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix)
+    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix, c)
     gy = torch.empty_like(z)
     gz = torch.empty_like(z)
     partial = torch.empty((rows, c, 2), dtype=torch.float32, device=dev)

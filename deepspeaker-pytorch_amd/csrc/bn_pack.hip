@@ -501,11 +501,10 @@ extern "C" int ds_bn_bwd_reduce_f32(const float *g1, const float *g2, const floa
     DS_REQUIRE(n_pix > 0 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) && DS_ALIGNED16(mean) && DS_ALIGNED16(invstd),
                DS_ERR_ALIGNMENT);
-    long long blocks = (n_pix + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
     const int slots = 256 / (C / 4);
-    DS_LAUNCH(bn_bwd_reduce_kernel, (int)blocks, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd,
+    DS_LAUNCH(bn_bwd_reduce_kernel, blocks, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd,
               gy, partial, n_pix, C, ppb);
     return ds_last_launch_error();
 }
@@ -525,9 +524,14 @@ extern "C" int ds_bn_bwd_apply_f32(const double *sums, long long count, const fl
     return ds_last_launch_error();
 }
 
-extern "C" int ds_bn_bwd_partial_rows(long long n_pix) {
-    if (n_pix <= 0) return DS_ERR_BAD_SHAPE;
-    long long blocks = (n_pix + 255) / 256;            // >= 256 pixels per workgroup
+// Workgroups (= partial rows) of the reduction: a workgroup walks its pixels 1024 / C at a time, so the pixels per
+// workgroup shrink with the channel count (about 8 steps per thread) -- the 10x4 stage of a 256-utterance member
+// has only 10 k pixels, and 256 of them per workgroup left 40 workgroups on 256 CUs -- bounded by 2048 rows.
+extern "C" int ds_bn_bwd_partial_rows(long long n_pix, int C) {
+    if (n_pix <= 0 || C <= 0) return DS_ERR_BAD_SHAPE;
+    long long ppb = 8192 / C;
+    if (ppb < 8) ppb = 8;
+    long long blocks = (n_pix + ppb - 1) / ppb;
     if (blocks > 2048) blocks = 2048;
     return (int)blocks;
 }
@@ -539,7 +543,7 @@ extern "C" int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act,
     DS_REQUIRE(n_pix > 0 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) && DS_ALIGNED16(gz) && DS_ALIGNED16(mean) &&
                    DS_ALIGNED16(invstd) && DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
-    const int blocks = ds_bn_bwd_partial_rows(n_pix);
+    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
     const int slots = 256 / (C / 4);
     DS_LAUNCH(bn_bwd_reduce_kernel, blocks, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd, gy,

@@ -33,6 +33,8 @@ struct WgradKB {
     int rows_in, cols_in, seg_pix;
     int P;                       // output-pixel slots per tile (multiple of 16, >= NI*RT*Wo)
     int S, n_co_tiles, n_ci_tiles;
+    unsigned x_bytes, gz_bytes;  // extents of x / gz (32-bit buffer offsets)
+    int k0;                      // first kernel row of the group (5x5)
 };
 
 // one bf16x8 MFMA operand: pixels q0 .. q0+7 of this lane's channel; rec0 / rec1 are the byte addresses
@@ -43,10 +45,16 @@ __device__ __forceinline__ bf16x8 frag_tr(const char *rec0, const char *rec1) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// TG taps per workgroup: 9 (all of a 3x3) or 5 (one kernel row of a 5x5; blockIdx selects the row).
-// Four waves as 2 (co) x 2 (ci), each owning a 32 x 32 block of every tap of the group.
-template <int TG>
-__global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
+// TG taps per workgroup, KW taps per kernel row.  <9, 3>: all of a 3x3.  A 5x5 runs as two launches over kernel-row
+// GROUPS: rows k0, k0 + stride, ... (k0 = 0: three rows = <15, 5>; the other two = <10, 5>).  With the stride between
+// a group's rows equal to the convolution stride, kernel row m of the group reads, for output row r, tile row r + m:
+// the staged tile holds only the input rows of that residue (RT + rows - 1 of them), and each dY tile staged is
+// contracted against 15 (10) taps instead of the 5 of a single kernel row.
+// Four waves as 2 (co) x 2 (ci), each owning a 32 x 32 block of every tap of the group; the accumulators take most
+// of the register file (one wave per SIMD).
+template <int TG, int KW>
+__global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kernel(const WgradKB p) {
+    constexpr bool GROUP = KW == 5;                     // kernel-row group of a 5x5 (see above)
     char *lds = (char *)ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -58,7 +66,6 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
     const int cit = bid % p.n_ci_tiles;
     bid /= p.n_ci_tiles;
     const int cot = bid % p.n_co_tiles;
-    const int tg = bid / p.n_co_tiles;                  // tap group (kernel row for 5x5)
 
     const int tile_in_pix = p.NI * p.seg_pix;
     char *gzt = lds;                                    // [P] records
@@ -102,7 +109,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
             const int pix = i / QV, q = i - pix * QV;
             const int seg = pix / p.seg_pix, pr = pix - seg * p.seg_pix;
             const int rr = pr / p.cols_in, cc = pr - rr * p.cols_in;
-            const int hrel = (TG == 5) ? p.IS * rr + tg : rr;          // image row = IS*r0 - pad + hrel
+            const int hrel = GROUP ? p.IS * rr + p.k0 : rr;            // image row = IS*r0 - pad + hrel
             const int w = cc - p.pad;
             x_sr[it] = (w >= 0 && w < p.W) ? ((seg << 16) | hrel) : -2;
             x_rel[it] = (hrel * p.W + cc) * p.Cin + cit * WB_C + q * 4;
@@ -111,8 +118,8 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
     for (int pp = tid; pp < p.P; pp += 256) {
         const int seg = pp / pix_per_seg, rem = pp - seg * pix_per_seg;
         const int r = rem / p.Wo, c = rem - r * p.Wo;
-        // TG == 5: the tile holds, per output row, only the ONE input row this kernel row touches
-        pixtab[pp] = (seg < p.NI) ? (seg * p.seg_pix + ((TG == 5) ? r : p.IS * r) * p.cols_in + p.IS * c) * WB_REC : 0;
+        // GROUP: tile row j is image row IS*(r0 + j) - pad + k0, output row r's first tap sits in tile row r
+        pixtab[pp] = (seg < p.NI) ? (seg * p.seg_pix + (GROUP ? r : p.IS * r) * p.cols_in + p.IS * c) * WB_REC : 0;
     }
 
     // software pipeline over tiles: the next tile's global loads are issued into registers before this
@@ -135,24 +142,45 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
             e[0] = gbase; e[1] = rows_left; e[2] = xbase; e[3] = h0;
         }
     };
+    // Branch-free: a slot's segment entry is read from LDS, its validity folded into the offset (out-of-range
+    // offsets of a raw buffer load return 0) -- sixteen independent loads per thread instead of sixteen
+    // read -> compare -> branch -> load chains.
+    const ds_buffer gbuf = ds_make_buffer(p.gz, p.gz_bytes), xbuf = ds_make_buffer(p.x, p.x_bytes);
     auto issue_loads = [&](int buf) {
         const int *st = segtab + buf * p.NI * 4;
+        int g_org[GSL], g_rows[GSL], x_org[XSL], x_h0[XSL];
 #pragma unroll
-        for (int it = 0; it < GSL; ++it) {
-            gv[it] = zero4;
-            if (g_sr[it] >= 0) {
-                const int *e = st + (g_sr[it] >> 16) * 4;
-                if ((g_sr[it] & 0xFFFF) < e[1]) gv[it] = *(const f32x4 *)(p.gz + (e[0] + g_rel[it]));
-            }
+        for (int it = 0; it < GSL; ++it) {                 // every slot's segment entry, requested unconditionally
+            const int *e = st + (g_sr[it] >= 0 ? (g_sr[it] >> 16) : 0) * 4;
+            g_org[it] = e[0];
+            g_rows[it] = e[1];
         }
 #pragma unroll
         for (int it = 0; it < XSL; ++it) {
-            xv[it] = zero4;
-            if (x_sr[it] >= 0) {
-                const int *e = st + (x_sr[it] >> 16) * 4;
-                const int h = e[3] + (x_sr[it] & 0xFFFF);
-                if (h >= 0 && h < p.H) xv[it] = *(const f32x4 *)(p.x + (e[2] + x_rel[it]));
-            }
+            const int *e = st + (x_sr[it] >= 0 ? (x_sr[it] >> 16) : 0) * 4;
+            x_org[it] = e[2];
+            x_h0[it] = e[3];
+        }
+#pragma unroll
+        for (int it = 0; it < GSL; ++it) {                 // (the reads above must not sink into per-slot branches)
+            DS_OPAQUE_VGPR(g_org[it]);
+            DS_OPAQUE_VGPR(g_rows[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < XSL; ++it) {
+            DS_OPAQUE_VGPR(x_org[it]);
+            DS_OPAQUE_VGPR(x_h0[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < GSL; ++it) {
+            const bool ok = (g_sr[it] >= 0) & ((g_sr[it] & 0xFFFF) < g_rows[it]);
+            gv[it] = ds_buffer_load_f32x4(gbuf, ok ? (unsigned)(g_org[it] + g_rel[it]) * 4u : DS_BUFFER_OOB);
+        }
+#pragma unroll
+        for (int it = 0; it < XSL; ++it) {
+            const int h = x_h0[it] + (x_sr[it] & 0xFFFF);
+            const bool ok = (x_sr[it] >= 0) & (h >= 0) & (h < p.H);
+            xv[it] = ds_buffer_load_f32x4(xbuf, ok ? (unsigned)(x_org[it] + x_rel[it]) * 4u : DS_BUFFER_OOB);
         }
     };
     auto put_split = [&](char *rec, int q, const f32x4 v) {     // 4 channels -> hi / lo halves of the record
@@ -193,23 +221,56 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
         fill_segtab(tile + p.S, buf ^ 1);
         __syncthreads();
         if (tile + p.S < p.n_tiles) issue_loads(buf ^ 1);   // in flight during this tile's matrix work
-        // ---- contract: 16 pixels per MFMA, one accumulator per tap ----
-        for (int s = 0; s < p.P; s += 16) {
+        // ---- contract: 16 pixels per MFMA, one accumulator per tap.  Nothing but this wave hides its own LDS latency:
+        //      fragments travel AH taps ahead of their MFMAs through NS register slots (TG is a multiple of NS, so the
+        //      slot pattern repeats every step); the next step's dY fragments are requested with its first tap ----
+        constexpr int NS = (TG % 3 == 0) ? 3 : 2, AH = NS - 1;
+        static_assert(TG % NS == 0, "slot pattern must repeat per step");
+        auto tap_off = [&](int t) { return ((t / KW) * p.cols_in + (t % KW)) * WB_REC; };
+        auto step_ptrs = [&](int s, const char *&g0, const char *&g1, const char *&x0, const char *&x1) {
             const int pp0 = s + 8 * lhi + piece_pix, pp1 = pp0 + 4;
-            const char *g0 = gzt + (size_t)pp0 * WB_REC + a_col, *g1 = gzt + (size_t)pp1 * WB_REC + a_col;
-            const bf16x8 a_hi = frag_tr(g0, g1);
-            const bf16x8 a_lo = frag_tr(g0 + 2 * WB_C, g1 + 2 * WB_C);
-            const char *x0 = xt + pixtab[pp0] + b_col, *x1 = xt + pixtab[pp1] + b_col;
+            g0 = gzt + (size_t)pp0 * WB_REC + a_col;
+            g1 = gzt + (size_t)pp1 * WB_REC + a_col;
+            x0 = xt + pixtab[pp0] + b_col;
+            x1 = xt + pixtab[pp1] + b_col;
+        };
+        const char *g0, *g1, *x0, *x1;
+        step_ptrs(0, g0, g1, x0, x1);
+        bf16x8 a_hi = frag_tr(g0, g1), a_lo = frag_tr(g0 + 2 * WB_C, g1 + 2 * WB_C);
+        bf16x8 b_hi[NS], b_lo[NS];
+#pragma unroll
+        for (int t = 0; t < AH; ++t) {
+            b_hi[t] = frag_tr(x0 + tap_off(t), x1 + tap_off(t));
+            b_lo[t] = frag_tr(x0 + tap_off(t) + 2 * WB_C, x1 + tap_off(t) + 2 * WB_C);
+        }
+        for (int s = 0; s < p.P; s += 16) {
+            const char *ng0, *ng1, *nx0, *nx1;
+            step_ptrs(s + 16 < p.P ? s + 16 : s, ng0, ng1, nx0, nx1);      // last step: harmless re-reads of this one
+            bf16x8 na_hi = a_hi, na_lo = a_lo;
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
-                const int kh = (TG == 9) ? t / 3 : tg, kw = (TG == 9) ? t % 3 : t;
-                const int toff = ((TG == 5) ? kw : kh * p.cols_in + kw) * WB_REC;
-                const bf16x8 b_hi = frag_tr(x0 + toff, x1 + toff);
-                const bf16x8 b_lo = frag_tr(x0 + toff + 2 * WB_C, x1 + toff + 2 * WB_C);
-                acc[t] = ds_mfma_32x32x16_bf16(a_lo, b_hi, acc[t]);
-                acc[t] = ds_mfma_32x32x16_bf16(a_hi, b_lo, acc[t]);
-                acc[t] = ds_mfma_32x32x16_bf16(a_hi, b_hi, acc[t]);
+                const int ahead = t + AH, slot = ahead % NS;
+                if (ahead < TG) {
+                    b_hi[slot] = frag_tr(x0 + tap_off(ahead), x1 + tap_off(ahead));
+                    b_lo[slot] = frag_tr(x0 + tap_off(ahead) + 2 * WB_C, x1 + tap_off(ahead) + 2 * WB_C);
+                } else {
+                    if (ahead == TG) {
+                        na_hi = frag_tr(ng0, ng1);
+                        na_lo = frag_tr(ng0 + 2 * WB_C, ng1 + 2 * WB_C);
+                    }
+                    b_hi[slot] = frag_tr(nx0 + tap_off(ahead - TG), nx1 + tap_off(ahead - TG));
+                    b_lo[slot] = frag_tr(nx0 + tap_off(ahead - TG) + 2 * WB_C, nx1 + tap_off(ahead - TG) + 2 * WB_C);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = ds_mfma_32x32x16_bf16(a_lo, b_hi[t % NS], acc[t]);
+                acc[t] = ds_mfma_32x32x16_bf16(a_hi, b_lo[t % NS], acc[t]);
+                acc[t] = ds_mfma_32x32x16_bf16(a_hi, b_hi[t % NS], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            a_hi = na_hi;
+            a_lo = na_lo;
+            x0 = nx0;
+            x1 = nx1;
         }
     }
 
@@ -217,7 +278,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
     const int co0 = cot * WB_C + co_sub * 32, ci0 = cit * WB_C + ci_sub * 32;
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-        const int tap = (TG == 9) ? t : tg * 5 + t;
+        const int tap = GROUP ? (p.k0 + p.IS * (t / KW)) * p.KS + (t % KW) : t;
         float *dst = p.partial + (((size_t)sp * p.KS * p.KS + tap) * p.Cout) * p.Cin;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -228,8 +289,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(const WgradKB p) {
 }
 
 struct WgradPlanB {
-    WgradKB k;
-    int tg, n_tg;
+    WgradKB k;                   // 5x5: the geometry of the three-row group; wgrad_group_rows() derives the other
     int grid;
     size_t lds_bytes;
     long long partial_floats;
@@ -247,18 +307,21 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     k.Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
     k.Wo = (s->W + 2 * pad - s->KS) / s->stride + 1;
     DS_REQUIRE(k.Ho > 0 && k.Wo > 0 && k.Wo <= 64, DS_ERR_BAD_SHAPE);
-    DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 31), DS_ERR_BAD_SHAPE);
-    DS_REQUIRE((long long)s->B * k.Ho * k.Wo * s->Cout < (1ll << 31), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 30), DS_ERR_BAD_SHAPE);      // 32-bit byte offsets
+    DS_REQUIRE((long long)s->B * k.Ho * k.Wo * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);
+    k.x_bytes = (unsigned)((long long)s->B * s->H * s->W * s->Cin * 4);
+    k.gz_bytes = (unsigned)((long long)s->B * k.Ho * k.Wo * s->Cout * 4);
     k.KS = s->KS; k.IS = s->stride; k.pad = pad;
-    pl.tg = s->KS == 3 ? 9 : 5;
-    pl.n_tg = s->KS == 5 ? 5 : 1;
+    k.k0 = 0;
+    const int group_rows = 3;                             // kernel rows of the (larger) 5x5 group
     // segment height / segments per tile: <= 64 output pixels (4 staging slots) and <= 192 halo pixels
-    // (12 slots) per tile -- two workgroups of <= 80 KiB per CU
-    const int max_in_pix = 190;                           // 12 staging slots, (64 + 190) records <= 80 KiB
+    // (12 slots) per tile
+    const int max_in_pix = 190;                           // 12 staging slots; (64 + 190) records = 80 KiB, one workgroup per CU
     int best_rt = 0, best_ni = 1;
     for (int rt = 1; rt <= k.Ho; ++rt) {
         if (rt * k.Wo > 64) break;
-        const int rows_in = s->KS == 5 ? rt : s->stride * (rt - 1) + s->KS, cols_in = s->stride * (k.Wo - 1) + s->KS;
+        const int rows_in = s->KS == 5 ? rt + group_rows - 1 : s->stride * (rt - 1) + s->KS;
+        const int cols_in = s->stride * (k.Wo - 1) + s->KS;
         if (rows_in * cols_in > max_in_pix) break;
         best_rt = rt;
     }
@@ -266,7 +329,7 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     k.RT = best_rt;
     k.segs_per_img = ds_ceil_div(k.Ho, best_rt);
     k.n_segs = s->B * k.segs_per_img;
-    k.rows_in = s->KS == 5 ? best_rt : s->stride * (best_rt - 1) + s->KS;   // 5x5: one input row per output row and kernel row
+    k.rows_in = s->KS == 5 ? best_rt + group_rows - 1 : s->stride * (best_rt - 1) + s->KS;   // 5x5: the rows of one residue
     k.cols_in = s->stride * (k.Wo - 1) + s->KS;
     k.seg_pix = k.rows_in * k.cols_in;
     while ((best_ni + 1) * best_rt * k.Wo <= 64 && (best_ni + 1) * k.seg_pix <= max_in_pix && best_ni + 1 <= k.n_segs)
@@ -276,15 +339,15 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     k.n_tiles = ds_ceil_div(k.n_segs, best_ni);
     k.n_co_tiles = s->Cout / WB_C;
     k.n_ci_tiles = s->Cin / WB_C;
-    const int base_blocks = pl.n_tg * k.n_co_tiles * k.n_ci_tiles;
-    int S = ds_ceil_div(512, base_blocks);                // two workgroups per CU
+    const int base_blocks = k.n_co_tiles * k.n_ci_tiles;
+    int S = ds_ceil_div(256, base_blocks);                // one workgroup per CU, every one with the same share of the tiles
     if (S > k.n_tiles) S = k.n_tiles;
     if (S < 1) S = 1;
     k.S = S;
     pl.grid = base_blocks * S;
     pl.lds_bytes = ((size_t)k.P + (size_t)k.NI * k.seg_pix) * WB_REC + ((size_t)k.P + 8 * k.NI) * 4;
     DS_REQUIRE(k.P * (WB_C / 4) <= 4 * 256 && k.NI <= 255 && s->stride * k.rows_in + s->KS < 4096 &&
-                   pl.lds_bytes <= 80 * 1024, DS_ERR_UNSUPPORTED);
+                   pl.lds_bytes <= 96 * 1024, DS_ERR_UNSUPPORTED);
     pl.partial_floats = (long long)S * s->KS * s->KS * s->Cout * s->Cin;
     return DS_OK;
 }
@@ -305,8 +368,19 @@ extern "C" int ds_conv_wgrad_bf16(const ds_conv_shape *s, const float *x, const 
     int rc = plan_wgrad_b(pl, s);
     if (rc != DS_OK) return rc;
     pl.k.x = x; pl.k.gz = gy; pl.k.partial = workspace;
-    if (pl.tg == 9) DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<9>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
-    else DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<5>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    if (s->KS == 3) {
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<9, 3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+    } else {
+        // kernel rows 0, s, 2s (15 taps), then the remaining two (10 taps): same tiles, same splits, disjoint taps
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<15, 5>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        rc = ds_last_launch_error();
+        if (rc) return rc;
+        WgradKB k2 = pl.k;
+        k2.k0 = s->stride == 2 ? 1 : 3;
+        k2.rows_in = pl.k.RT + 1;
+        k2.seg_pix = k2.rows_in * k2.cols_in;
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<10, 5>), pl.grid, 256, pl.lds_bytes, stream, k2);
+    }
     rc = ds_last_launch_error();
     if (rc) return rc;
     const long long n = (long long)s->KS * s->KS * s->Cout * s->Cin;

@@ -250,9 +250,9 @@ int ds_conv_wgrad_bf16(const ds_conv_shape *s, const float *x, const float *gy, 
                        float *gw_oihw, void *stream);
 /* BatchNorm (train mode) backward in one call: gy = (g1 [+ g2]) masked by the clipped-ReLU of `act`
  * (NULL: unmasked); reductions sum gy, sum gy*xhat; ggamma, gbeta; gz = dL/d(conv output).
- * partial: ds_bn_bwd_partial_rows(n_pix) * C * 2 floats; coef: 3*C floats; gy is written (it is the
+ * partial: ds_bn_bwd_partial_rows(n_pix, C) * C * 2 floats; coef: 3*C floats; gy is written (it is the
  * masked gradient the residual branch re-uses). */
-int ds_bn_bwd_partial_rows(long long n_pix);
+int ds_bn_bwd_partial_rows(long long n_pix, int C);
 int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act, const float *z,
                   const float *mean, const float *invstd, const float *gamma, float *gy,
                   float *partial, float *coef, float *ggamma, float *gbeta, float *gz,

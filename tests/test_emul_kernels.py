@@ -224,7 +224,7 @@ def test_bn_bwd(C, npix, with_g2, with_act):
     zz = z.astype(np.float64).T.reshape(1, C, npix, 1)
     gz_ref, gg_ref, gb_ref = O.bn_train_bwd(zz, mean, invstd, gamma.astype(np.float64),
                                             gy_ref.T.reshape(1, C, npix, 1))
-    rows = lib.raw("ds_bn_bwd_partial_rows")(npix)
+    rows = lib.raw("ds_bn_bwd_partial_rows")(npix, C)
     bufs = dict(g1=to_aligned(g1), g2=to_aligned(g2) if with_g2 else None, act=to_aligned(act) if with_act else None,
                 z=to_aligned(z), mean=to_aligned(mean.astype(np.float32)), invstd=to_aligned(invstd.astype(np.float32)),
                 gamma=to_aligned(gamma), gy=aligned((npix, C), fill=np.nan), partial=aligned((rows, C, 2), fill=np.nan),

@@ -147,7 +147,7 @@ def test_clip_mask_is_strict_in_backward():
     z = torch.randn((n_pix, C)).cuda()
     mean, invstd = torch.zeros(C).cuda(), torch.ones(C).cuda()
     gy = torch.empty_like(g1)
-    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix)
+    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix, C)
     partial = torch.empty((rows, C, 2)).cuda()
     eng.lib.call("ds_bn_bwd_reduce_f32", eng._p(g1), None, eng._p(act), eng._p(z), eng._p(mean), eng._p(invstd),
                  eng._p(gy), eng._p(partial), n_pix, C, eng._stream(gy))
