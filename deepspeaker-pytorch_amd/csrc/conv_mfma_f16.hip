@@ -238,10 +238,17 @@ extern "C" int ds_cast_f16_to_f32(const void *x_f16, float *y, long long n, void
     return ds_last_launch_error();
 }
 
+extern "C" int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flags, int *out8);
 extern "C" int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8) {
+    return ds_conv_f16_plan_describe_hinted(s, 0, out8);
+}
+
+// the plan ds_conv_fwd_f16 would use under the DS_CONV_HINT_* / DS_CONV_IN_PLANES16 bits of `flags`
+extern "C" int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flags, int *out8) {
     DS_REQUIRE(out8 != nullptr, DS_ERR_NULL);
     PlanH pl;
-    int rc = plan_f16(pl, s);
+    int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER),
+                      (flags & (DS_CONV_IN_PLANES16 | DS_CONV_HINT_CHUNK16)) != 0);
     if (rc != DS_OK) return rc;
     const TileCfgH &cf = kCfgH[pl.cfg];
     out8[0] = cf.MT; out8[1] = cf.NTILE; out8[2] = pl.k.RT; out8[3] = pl.k.NI;

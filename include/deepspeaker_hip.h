@@ -172,6 +172,8 @@ int ds_conv_fwd_f16_splitk(const ds_conv_shape *s, const void *x_f16, const void
 /* out8 = {M tile, N tile, rows per segment, segments per tile, workgroups, LDS bytes, threads per workgroup,
  * 1000 * double-buffered + 100 * (16-channel chunks) + staging items per thread} */
 int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8);
+/* the same under the DS_CONV_HINT_* / DS_CONV_IN_PLANES16 bits of `flags` (what ds_conv_fwd_f16 would launch) */
+int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flags, int *out8);
 /* One whole BasicBlock in eval mode as ONE kernel (reference model.py:66-82):
  *     y = clip(bn2(conv3x3(clip(bn1(conv3x3(x))))) + x)
  * for the shallow stages (W = 32 with 64 channels, W = 16 with 128: ds_conv_block_f16_supported), where a workgroup
