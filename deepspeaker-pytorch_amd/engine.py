@@ -424,7 +424,7 @@ class Engine:
             mask_call(a, s, h)
             cin = c
             last_stage = s == len(pw.stages) - 1
-            if (h16 and not masked and not low_latency
+            if (h16 and not masked
                     and self.lib.raw("ds_conv_block_f16_supported")(B, h, w, c) == 1):
                 # the shallow stages: the whole BasicBlock as one kernel, the intermediate activation in LDS only
                 sc1, sh1 = folded[f"model.layer{i}.0.bn1"]
