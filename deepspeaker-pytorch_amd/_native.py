@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ds_conv_fwd_f16_splitk": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, c_int, _P, c_longlong, _P]),
     "ds_conv_block_f16_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "ds_conv_block_f16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv_block_f16_masked": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv_f16_plan_describe": (c_int, [POINTER(ConvShape), POINTER(c_int)]),
     "ds_conv_f16_plan_describe_hinted": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
     "ds_cast_f32_to_f16": (c_int, [_P, _P, c_longlong, _P]),

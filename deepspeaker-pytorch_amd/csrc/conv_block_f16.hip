@@ -30,11 +30,14 @@ struct BlockK {
     int tiles_per_img;
     int flags;
     unsigned y_bytes, x_bytes, y_plane_stride;
+    const int *lens;                    // MASKED: rows of each image that belong to its utterance (zero-padded batches)
 };
 
 // WM x WN waves, each a 160x64 register tile for the first convolution (10 rows x W pixels per WM) and 128x64 for the
 // second (8 rows); W = 32 * WM / ... : MT_A = 160 * WM = 10 * W.  NIT: 16-byte staging items per thread and chunk.
-template <int WM, int WN, int NIT>
+// MASKED (variable-length batches): rows past an image's own extent are zero in the intermediate and in the output, as
+// ds_mask_rows makes them after each of the two layers -- every kept row equals the utterance's own forward.
+template <int WM, int WN, int NIT, bool MASKED = false>
 __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3x3_f16_kernel(const BlockK p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MSA = 5, MSB = 4, NSUB = 2;
@@ -52,6 +55,11 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
     const int W = p.W, C = p.C;
     const int b = blockIdx.x / p.tiles_per_img;
     const int r0 = (blockIdx.x - b * p.tiles_per_img) * BK_R;        // first output row of this tile
+    int h_valid = p.H;                                               // rows of this image that carry data
+    if (MASKED) {
+        const int len = p.lens[b];
+        h_valid = len < p.H ? len : p.H;
+    }
     const int pitch = W + 2;                                         // records per tile row (both tiles)
     const int tileA_bytes = ROWS_IN * pitch * BK_PS;
     const int RSB = C * 2 + 16;                                      // bytes per intermediate record
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
         const int m = (wm * MSA + ms) * 32 + lpix;
         const int i = ds_div_small(m, W, rcp_w), c = m - i * W;
         const int row = r0 - 1 + i;                                  // image row of this intermediate pixel
-        const bool inside = row >= 0 && row < p.H;
+        const bool inside = row >= 0 && row < h_valid;
         char *rec = lds + (i * pitch + c + 1) * RSB;
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns)
@@ -281,6 +289,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
     const ds_buffer rbuf = ds_make_buffer(p.x, p.x_bytes);
     const int lin_base = (b * p.H + r0) * W;
     const int lin_valid = (p.H - r0 < BK_R ? p.H - r0 : BK_R) * W;
+    const int lin_kept = (h_valid - r0) * W;                          // MASKED: pixels of the tile below the extent
     unsigned voff[MSB][NRI];
     f32x4 resv[MSB][NRI];
 #pragma unroll
@@ -330,6 +339,13 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                     t += (float)r8[4 * hq + j];
                     o[hq][j] = fminf(fmaxf(t, 0.0f), 20.0f);
                 }
+            if (MASKED) {
+                const bool kept = (wm * MSB + ms) * 32 + k * PPI + my_p < lin_kept;
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[hq][j] = kept ? o[hq][j] : 0.0f;
+            }
             const unsigned vo = voff[ms][k];
             if (out32) {
                 const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
@@ -367,9 +383,9 @@ extern "C" int ds_conv_block_f16_supported(int B, int H, int W, int C) {
 // y = clip(bn2(conv3x3(clip(bn1(conv3x3(x))))) + x) for one BasicBlock in eval mode (reference model.py:66-82 with
 // module.eval()); x, y fp16 channels-last [B,H,W,C]; wa / wb from ds_pack_conv_weight_f16; flags: DS_EPI_OUT_F32,
 // DS_EPI_OUT_PLANES16.  Bit-identical to two ds_conv_fwd_f16 calls.
-extern "C" int ds_conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
-                                 const float *shift_a, const float *scale_b, const float *shift_b, void *y, int B, int H,
-                                 int W, int C, int flags, void *stream) {
+static int conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
+                          const float *shift_a, const float *scale_b, const float *shift_b, void *y, const int *lens,
+                          int B, int H, int W, int C, int flags, void *stream) {
     DS_REQUIRE(x_f16 && wa_f16 && wb_f16 && scale_a && shift_a && scale_b && shift_b && y, DS_ERR_NULL);
     DS_REQUIRE(ds_conv_block_f16_supported(B, H, W, C), DS_ERR_UNSUPPORTED);
     DS_REQUIRE(DS_ALIGNED16(x_f16) && DS_ALIGNED16(wa_f16) && DS_ALIGNED16(wb_f16) && DS_ALIGNED16(y) &&
@@ -386,11 +402,30 @@ extern "C" int ds_conv_block_f16(const void *x_f16, const void *wa_f16, const vo
     k.x_bytes = (unsigned)(n * 2);
     k.y_bytes = (unsigned)(n * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
     k.y_plane_stride = (flags & DS_EPI_OUT_PLANES16) ? (unsigned)((long long)B * H * W * 16) : 0u;
+    k.lens = lens;
     const int grid = B * k.tiles_per_img;
     if (C == 64) {          // W = 32: 2 x 1 waves, 12 x 32 x 4 items over 128 threads
-        DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 16>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 16, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        else DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 16>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
     } else {                // W = 16, C = 128: 1 x 2 waves
-        DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 8>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 8, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        else DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 8>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
     }
     return ds_last_launch_error();
+}
+
+extern "C" int ds_conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
+                                 const float *shift_a, const float *scale_b, const float *shift_b, void *y, int B, int H,
+                                 int W, int C, int flags, void *stream) {
+    return conv_block_f16(x_f16, wa_f16, wb_f16, scale_a, shift_a, scale_b, shift_b, y, nullptr, B, H, W, C, flags, stream);
+}
+
+// The same block over a zero-padded batch of utterances of different lengths: `lens` (device, int32 [B]) = the rows of
+// each image that belong to its utterance; rows past them are zero in the intermediate and in the output, exactly as
+// ds_mask_rows leaves them after each layer of the unfused sequence.
+extern "C" int ds_conv_block_f16_masked(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
+                                        const float *shift_a, const float *scale_b, const float *shift_b, void *y,
+                                        const int *lens, int B, int H, int W, int C, int flags, void *stream) {
+    DS_REQUIRE(lens != nullptr, DS_ERR_NULL);
+    return conv_block_f16(x_f16, wa_f16, wb_f16, scale_a, shift_a, scale_b, shift_b, y, lens, B, H, W, C, flags, stream);
 }

@@ -424,17 +424,23 @@ class Engine:
             mask_call(a, s, h)
             cin = c
             last_stage = s == len(pw.stages) - 1
-            if (h16 and not masked
-                    and self.lib.raw("ds_conv_block_f16_supported")(B, h, w, c) == 1):
+            if h16 and self.lib.raw("ds_conv_block_f16_supported")(B, h, w, c) == 1:
                 # the shallow stages: the whole BasicBlock as one kernel, the intermediate activation in LDS only
+                # (masked batches: the kernel zeroes the rows past each utterance's extent after both layers itself)
                 sc1, sh1 = folded[f"model.layer{i}.0.bn1"]
                 sc2, sh2 = folded[f"model.layer{i}.0.bn2"]
                 out = buf(B, h, w, c, dtype=torch.float32 if last_stage else torch.float16)
                 fl = (DS_EPI_OUT_F32 if last_stage else 0) | (DS_EPI_OUT_PLANES16 if (planes and i == 1) else 0)
-                calls.append((self.lib.raw("ds_conv_block_f16"),
-                              (self._p(a), self._p(sw.l_conv1_f16), self._p(sw.l_conv2_f16), self._p(sc1), self._p(sh1),
-                               self._p(sc2), self._p(sh2), self._p(out), B, h, w, c, fl, st_slot),
-                              f"block3x3_{c}_{h}x{w}", 2 * 2.0 * B * h * w * c * c * 9))
+                if masked:
+                    calls.append((self.lib.raw("ds_conv_block_f16_masked"),
+                                  (self._p(a), self._p(sw.l_conv1_f16), self._p(sw.l_conv2_f16), self._p(sc1), self._p(sh1),
+                                   self._p(sc2), self._p(sh2), self._p(out), self._p(lens_dev[s]), B, h, w, c, fl, st_slot),
+                                  f"block3x3_{c}_{h}x{w}", 2 * 2.0 * B * h * w * c * c * 9))
+                else:
+                    calls.append((self.lib.raw("ds_conv_block_f16"),
+                                  (self._p(a), self._p(sw.l_conv1_f16), self._p(sw.l_conv2_f16), self._p(sc1), self._p(sh1),
+                                   self._p(sc2), self._p(sh2), self._p(out), B, h, w, c, fl, st_slot),
+                                  f"block3x3_{c}_{h}x{w}", 2 * 2.0 * B * h * w * c * c * 9))
                 a = out
                 continue
             sc, sh = folded[f"model.layer{i}.0.bn1"]

@@ -183,6 +183,12 @@ int ds_conv_block_f16_supported(int B, int H, int W, int C);
 int ds_conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
                       const float *shift_a, const float *scale_b, const float *shift_b, void *y, int B, int H, int W,
                       int C, int flags, void *stream);
+/* the same block over a zero-padded batch of utterances of different lengths (BASELINE configs[4]): `lens` (device,
+ * int32 [B]) = the rows of each image that belong to its utterance; rows past them come out zero after both layers, as
+ * ds_mask_rows leaves them in the unfused sequence */
+int ds_conv_block_f16_masked(const void *x_f16, const void *wa_f16, const void *wb_f16, const float *scale_a,
+                             const float *shift_a, const float *scale_b, const float *shift_b, void *y, const int *lens,
+                             int B, int H, int W, int C, int flags, void *stream);
 int ds_cast_f32_to_f16(const float *x, void *y_f16, long long n, void *stream);
 int ds_cast_f16_to_f32(const void *x_f16, float *y, long long n, void *stream);
 
