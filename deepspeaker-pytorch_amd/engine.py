@@ -496,16 +496,21 @@ class Engine:
         stream_id = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
         key = (tuple(x.shape), precision, id(pw), id(folded), x.device, stream_id, lengths is not None, low_latency)
         plans = self.__dict__.setdefault("_eval_plans", {})
-        plan = plans.get(key)
+        plan = plans.pop(key, None)
+        if plan is not None:
+            plans[key] = plan                           # most recently used last
         if plan is None:
             # a plan pins its packed filters, folded BatchNorm and activation buffers: drop the plans of this
             # shape that were built for an older weights generation, and bound the total
             for k in [k for k in plans if k[:2] == key[:2] and k[4:] == key[4:] and k[2:4] != key[2:4]]:
                 del plans[k]
-            if len(plans) > 16:
-                plans.clear()
-            plan = plans[key] = self._build_eval_plan(x, pw, folded, precision, masked=lengths is not None,
-                                                      low_latency=low_latency and precision == "f16")
+            plan = self._build_eval_plan(x, pw, folded, precision, masked=lengths is not None,
+                                         low_latency=low_latency and precision == "f16")
+            plan["bytes"] = sum(t.numel() * t.element_size() for t in plan["keep"] if isinstance(t, torch.Tensor))
+            # least recently used first (dicts keep insertion order): at most 64 plans / 32 GiB of activation buffers
+            while plans and (len(plans) >= 64 or sum(q["bytes"] for q in plans.values()) + plan["bytes"] > (32 << 30)):
+                del plans[next(iter(plans))]
+            plans[key] = plan
         if lengths is not None:
             ln = lengths.to(torch.int64).cpu()
             if ln.numel() != x.shape[0] or int(ln.min()) < 1 or int(ln.max()) > x.shape[2]:

@@ -597,15 +597,16 @@ class DeepSpeakerModel(nn.Module):
         self.features = outs[2]
         return outs
 
-    def embed_variable_length(self, utterances, max_batch: int = 128, pad_to: int = 16):
+    def embed_variable_length(self, utterances, max_batch: int = 2048, pad_to: int = 16, max_frames: int = 262144):
         """Eval-mode embeddings of utterances of DIFFERENT lengths (BASELINE configs[4]: 100-800 frames; the
         temporal mean pool of model.py:207 accepts any T).  `utterances`: a sequence of [T_i, 64]
         (or [1, T_i, 64]) float tensors on the device, or a `data.FeatureStore` (the resident corpus: batches are
-        then one gather kernel each).  They are sorted by length, packed `max_batch` at a time into
-        zero-padded batches whose length is the longest member's rounded up to `pad_to` frames (so launch plans are
-        re-used), and run through the masked forward: each embedding is bit-identical to the utterance's own
-        forward -- padding never leaks (Engine.forward_eval_planned(lengths=...)).  Returns [N, embedding_size] in
-        the order given."""
+        then one gather kernel each).  They are sorted by length and packed into zero-padded batches whose length is
+        the longest member's rounded up to `pad_to` frames (so launch plans are re-used): as many utterances as fit
+        `max_frames` padded frames (about two 768 x 160-frame forwards: short utterances travel in larger batches, the
+        GPU sees the same amount of work per launch) and at most `max_batch`.  They run through the masked forward:
+        each embedding is bit-identical to the utterance's own forward -- padding never leaks
+        (Engine.forward_eval_planned(lengths=...)).  Returns [N, embedding_size] in the order given."""
         if self.training:
             raise RuntimeError("embed_variable_length is an inference path: call model.eval() first")
         n = len(utterances)
@@ -629,8 +630,15 @@ class DeepSpeakerModel(nn.Module):
         out = torch.empty((n, self.embedding_size), dtype=torch.float32, device=dev)
         pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
         eng = get_engine()
-        for i in range(0, n, max_batch):
-            idx = order[i:i + max_batch]
+        sorted_lens = lens[order].tolist()
+        i = 0
+        while i < n:
+            # the largest count whose padded frames fit the budget (lengths ascend: the last member is the longest)
+            cnt = min(max_batch, n - i)
+            while cnt > 1 and cnt * (-(-sorted_lens[i + cnt - 1] // pad_to) * pad_to) > max_frames:
+                cnt = min(cnt - 1, max_frames // (-(-sorted_lens[i + cnt - 1] // pad_to) * pad_to)) or 1
+            idx = order[i:i + cnt]
+            i += cnt
             ln = lens[idx]
             t_pad = int(-(-int(ln.max()) // pad_to) * pad_to)
             if store is not None:       # whole utterances from the resident corpus, zero-padded by the gather kernel
