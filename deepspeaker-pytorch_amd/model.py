@@ -634,9 +634,10 @@ class DeepSpeakerModel(nn.Module):
         i = 0
         while i < n:
             # the largest count whose padded frames fit the budget (lengths ascend: the last member is the longest)
-            cnt = min(max_batch, n - i)
-            while cnt > 1 and cnt * (-(-sorted_lens[i + cnt - 1] // pad_to) * pad_to) > max_frames:
-                cnt = min(cnt - 1, max_frames // (-(-sorted_lens[i + cnt - 1] // pad_to) * pad_to)) or 1
+            cnt = 1
+            while (cnt < max_batch and i + cnt < n
+                   and (cnt + 1) * (-(-sorted_lens[i + cnt] // pad_to) * pad_to) <= max_frames):
+                cnt += 1
             idx = order[i:i + cnt]
             i += cnt
             ln = lens[idx]

@@ -44,9 +44,9 @@ def run(model, n_utt=4096, max_batch=2048, seed=0, dev=None, max_frames=262144):
     order = np.sort(lengths).tolist()
     padded, i, n_batches = 0, 0, 0
     while i < n_utt:                                                      # the packing of embed_variable_length
-        cnt = min(max_batch, n_utt - i)
-        while cnt > 1 and cnt * (-(-order[i + cnt - 1] // 16) * 16) > max_frames:
-            cnt = min(cnt - 1, max_frames // (-(-order[i + cnt - 1] // 16) * 16)) or 1
+        cnt = 1
+        while cnt < max_batch and i + cnt < n_utt and (cnt + 1) * (-(-order[i + cnt] // 16) * 16) <= max_frames:
+            cnt += 1
         padded += cnt * (-(-order[i + cnt - 1] // 16) * 16)
         i += cnt
         n_batches += 1
