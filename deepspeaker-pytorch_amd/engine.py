@@ -406,8 +406,9 @@ class Engine:
         # fp16 path: the 64-channel tensor between stage 1 and the 64->128 5x5 layer travels channel-plane-major
         # ([4][pixels][16]): that layer works in 16-channel chunks, and a channels-last 64-channel record is one
         # 128-byte line of which every chunk would read a quarter (4x the HBM / L2 traffic, measured).  Nobody else
-        # reads that tensor.  (Masked variable-length plans and the split-K small-launch plans keep channels-last.)
-        planes = h16 and not masked and not low_latency and len(pw.stages) > 1
+        # reads that tensor (masked variable-length plans too: the fused block zeroes the rows past an utterance's
+        # extent itself).  The split-K small-launch plans keep channels-last.
+        planes = h16 and not low_latency and len(pw.stages) > 1
         for s, sw in enumerate(pw.stages):
             i, c = s + 1, STAGE_CHANNELS[s]
             sc, sh = folded[f"model.bn{i}"]
