@@ -328,7 +328,7 @@ def main():
         # BASELINE configs[4]: variable-length inference (100-800 frames) + enrolment scoring, same arithmetic
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import varlen_bench
-        varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=2048, dev=dev)
+        varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=4096, dev=dev)
 
     if rank == 0:
         value = emb_per_step * args.steps / elapsed
