@@ -123,9 +123,13 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                  # --force-collectives without a launcher: a group of one
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
 
-    from deepspeaker_pytorch_amd.mining import mine_semihard_negatives, select_triplets
+    from deepspeaker_pytorch_amd.mining import mine_semihard_negatives, select_triplets, side_stream as side_stream_of
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss, get_engine
     from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
 
@@ -142,9 +146,12 @@ def main():
     c1, c2 = c1.to(dev), c2.to(dev)
     labels_loc = torch.cat([c1, c1, c2])
     n_slots = max(1, args.streams)              # steps in flight, each with its own gather buffers
-    emb_globs = [torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if multi else None for _ in range(n_slots)]
-    lab_globs = [torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if multi else None
+    # two sets of gather buffers per slot, used alternately: the search over one set (side stream, overlapped with the
+    # next forward) is long done when that set is gathered into again two steps later
+    emb_globs = [[torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if multi else None for _ in range(2)]
                  for _ in range(n_slots)]
+    lab_globs = [[torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if multi else None
+                  for _ in range(2)] for _ in range(n_slots)]
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
 
@@ -196,12 +203,15 @@ def main():
 
     def measure(precision, steps, warmup):
         model = load_model(precision).eval()
-        last_mined = [None] * n_slots
+        last_mined = [[None, None] for _ in range(n_slots)]
+        parity = [0] * n_slots
 
         def step(slot=0):
-            emb_glob, lab_glob = emb_globs[slot], lab_globs[slot]
-            if multi and last_mined[slot] is not None:
-                last_mined[slot].wait()                 # the previous search over this slot's gather buffers has read them
+            par = parity[slot]
+            parity[slot] ^= 1
+            emb_glob, lab_glob = emb_globs[slot][par], lab_globs[slot][par]
+            if multi and last_mined[slot][par] is not None:
+                last_mined[slot][par].wait()            # the search that read this buffer set two steps ago (done long since)
             with torch.no_grad():
                 if args.split_apn:
                     embs = [model(x) for x in data]
@@ -223,12 +233,13 @@ def main():
                 sel = select_triplets(*embs, margin=0.1, model=model, inputs=data)
                 loss = loss_fn.forward(*embs)
                 if multi:
-                    h_emb.wait()
-                    h_lab.wait()
+                    with torch.cuda.stream(side_stream_of(dev)):    # the SIDE stream waits for the gathers: this one
+                        h_emb.wait()                                # never stalls on xGMI
+                        h_lab.wait()
                     mined = mine_semihard_negatives(embs[0], embs[1], c1, emb_glob, lab_glob, side_stream=True)
                 else:
                     mined = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels_loc, side_stream=True)
-            last_mined[slot] = mined
+            last_mined[slot][par] = mined
             return loss, sel, mined
 
         return timed(step, steps, warmup)

@@ -80,6 +80,12 @@ class TripletSelection:
 _side_streams = {}
 
 
+def side_stream(device) -> "torch.cuda.Stream":
+    """The stream `select_triplets` refines near ties on and `mine_semihard_negatives(side_stream=True)` searches on
+    (one per device): callers that feed these with asynchronous collectives let THIS stream wait for them."""
+    return _side_stream(device)
+
+
 def _side_stream(device) -> "torch.cuda.Stream":
     s = _side_streams.get(device)
     if s is None:
