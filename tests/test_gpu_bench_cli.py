@@ -1,0 +1,46 @@
+"""bench.py as the driver runs it: the JSON contract of the one line it prints, and the N > 1 code path (RCCL gathers,
+side-stream search over alternating gather buffers, barrier, max over ranks) taken with a single rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*flags, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-secondary", *flags], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_single_gpu():
+    d = run_bench(port=29541)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "embeddings/s" and d["value"] > 1e4 and d["vs_baseline"] is None and d["dtype"] == "f16"
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "workload" in d["config"]
+
+
+def test_bench_collective_path_with_one_rank():
+    """Same step through the data-parallel branch; it must not serialise the side stream with the next forward
+    (a step that waits for the previous step's search loses > 20 %)."""
+    plain = run_bench(port=29542)
+    coll = run_bench("--force-collectives", port=29543)
+    assert coll["n_gpus"] == 1 and coll["value"] > 0.85 * plain["value"], (coll["value"], plain["value"])
+
+
+def test_bench_train_mode_collective_path():
+    d = run_bench("--train", "--force-collectives", port=29544)
+    assert d["unit"] == "utterances/s" and d["value"] > 1e3 and d["dtype"] == "bf16x3"
