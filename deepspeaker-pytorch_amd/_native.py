@@ -86,6 +86,7 @@ _SIGNATURES = {
     "ds_conv_wgrad_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P]),
     "ds_bn_bwd_partial_rows": (c_int, [c_longlong, c_int]),
     "ds_bn_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
+    "ds_bn_bwd_group_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "ds_colsum_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "ds_partial_sum_f64": (c_int, [_P, c_int, _P, c_int, _P]),
     "ds_bn_stats_from_sums_f32": (c_int, [_P, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, _P]),

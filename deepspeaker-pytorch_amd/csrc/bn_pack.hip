@@ -25,9 +25,9 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const float *gamma, const 
 // a channel-per-thread layout left the chip idle), then lane 0 folds the 32 lane sums.
 constexpr int FOLD_C = 8, FOLD_R = 32;
 __device__ __forceinline__ bool fold_partials(const float *partial, int n_partial, int C, double *red, int &c,
-                                              double &t1, double &t2) {
+                                              double &t1, double &t2, int cgroup = -1) {
     const int cl = threadIdx.x % FOLD_C, rl = threadIdx.x / FOLD_C;
-    c = blockIdx.x * FOLD_C + cl;
+    c = (cgroup < 0 ? (int)blockIdx.x : cgroup) * FOLD_C + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         for (int r = rl; r < n_partial; r += FOLD_R) {
@@ -320,12 +320,26 @@ namespace {
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float *g1, const float *g2, const float *act,
                                                             const float *z, const float *mean, const float *invstd,
                                                             float *gy, float *partial, long long n_pix, int C,
-                                                            int pix_per_block) {
+                                                            int pix_per_block, int blocks_per_member) {
+    // a batch of G members with their own statistics (the three forwards of a triplet step run as one batch): member
+    // m = blockIdx.x / blocks_per_member owns pixels [m * n_pix, (m + 1) * n_pix), row m of mean / invstd and
+    // blocks_per_member partial rows
+    const int member = blockIdx.x / blocks_per_member, mblock = blockIdx.x - member * blocks_per_member;
+    {
+        const size_t off = (size_t)member * n_pix * C;
+        g1 += off;
+        if (g2) g2 += off;
+        if (act) act += off;
+        z += off;
+        gy += off;
+        mean += (size_t)member * C;
+        invstd += (size_t)member * C;
+    }
     float *red = ds_dynamic_lds();                         // [slots][C][2]
     const int cvec = C >> 2;
     const int slots = 256 / cvec;
     const int cg = threadIdx.x % cvec, slot = threadIdx.x / cvec;
-    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    const long long p0 = (long long)mblock * pix_per_block;
     long long p1 = p0 + pix_per_block;
     if (p1 > n_pix) p1 = n_pix;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -395,13 +409,76 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *gy, cons
     }
 }
 
-// out[c] = sum_r x[r][c]   (bias gradient of the fc layer); one workgroup per 256 columns
-__global__ void __launch_bounds__(256) colsum_kernel(const float *x, float *out, int R, int C) {
+// The same for a batch of G members in one launch: workgroup (channel group, member); per member its own partial rows,
+// invstd row, coefficient block and dgamma / dbeta rows (summed over the members by bn_member_sum_kernel)
+__global__ void __launch_bounds__(256) bn_bwd_finalize_group_kernel(const float *partial, int n_partial, double count,
+                                                                    const float *gamma, const float *invstd,
+                                                                    float *ggamma_m, float *gbeta_m, float *coef, int C,
+                                                                    int n_cgroups) {
+    double *red = (double *)ds_dynamic_lds();              // [FOLD_R][FOLD_C][2]
+    const int member = blockIdx.x / n_cgroups, cgroup = blockIdx.x - member * n_cgroups;
+    partial += (size_t)member * n_partial * C * 2;
+    invstd += (size_t)member * C;
+    coef += (size_t)member * 3 * C;
+    int c;
+    double t1, t2;
+    if (fold_partials(partial, n_partial, C, red, c, t1, t2, cgroup)) {
+        gbeta_m[(size_t)member * C + c] = (float)t1;
+        ggamma_m[(size_t)member * C + c] = (float)t2;
+        coef[c] = gamma[c] * invstd[c];
+        coef[C + c] = (float)(t1 / count);
+        coef[2 * C + c] = (float)(t2 / count);
+    }
+}
+
+// dgamma / dbeta of the layer = the members' contributions added in member order (what accumulating the reference's
+// three backward passes into .grad does)
+__global__ void __launch_bounds__(256) bn_member_sum_kernel(const float *ggamma_m, const float *gbeta_m, float *ggamma,
+                                                            float *gbeta, int G, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) s += x[(size_t)r * C + c];
-        out[c] = s;
+        float a = 0.f, b = 0.f;
+        for (int m = 0; m < G; ++m) {
+            a += ggamma_m[(size_t)m * C + c];
+            b += gbeta_m[(size_t)m * C + c];
+        }
+        ggamma[c] = a;
+        gbeta[c] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_group_kernel(const float *gy, const float *z, const float *mean,
+                                                                 const float *invstd, const float *coef, float *gz,
+                                                                 long long n_vec_member, int G, int C) {
+    const int cvec = C >> 2;
+    const long long n_vec = n_vec_member * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
+        const int member = (int)(i / n_vec_member);
+        const int c4 = (int)(i % cvec);
+        const float *mu_p = mean + (size_t)member * C, *is_p = invstd + (size_t)member * C, *cf = coef + (size_t)member * 3 * C;
+        const f32x4 mu = ((const f32x4 *)mu_p)[c4], is = ((const f32x4 *)is_p)[c4];
+        const f32x4 k1 = ((const f32x4 *)cf)[c4], k2 = ((const f32x4 *)(cf + C))[c4], k3 = ((const f32x4 *)(cf + 2 * C))[c4];
+        const f32x4 xh = (((const f32x4 *)z)[i] - mu) * is;
+        ((f32x4 *)gz)[i] = k1 * (((const f32x4 *)gy)[i] - k2 - xh * k3);
+    }
+}
+
+// out[c] = sum_r x[r][c]   (bias gradient of the fc layer).  A workgroup owns 32 columns; its 8 row lanes stride over
+// the rows and are folded in lane order (fixed order => deterministic).  (One thread per column walking all rows left
+// two workgroups busy for 170 us at the head of every backward pass.)
+__global__ void __launch_bounds__(256) colsum_kernel(const float *x, float *out, int R, int C) {
+    float *red = ds_dynamic_lds();                         // [8][32]
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int r = rl; r < R; r += 8) s += x[(size_t)r * C + c];
+    red[rl * 32 + cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + cl];
+        out[c] = t;
     }
 }
 
@@ -505,7 +582,7 @@ extern "C" int ds_bn_bwd_reduce_f32(const float *g1, const float *g2, const floa
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
     const int slots = 256 / (C / 4);
     DS_LAUNCH(bn_bwd_reduce_kernel, blocks, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd,
-              gy, partial, n_pix, C, ppb);
+              gy, partial, n_pix, C, ppb, blocks);
     return ds_last_launch_error();
 }
 
@@ -547,7 +624,7 @@ extern "C" int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act,
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
     const int slots = 256 / (C / 4);
     DS_LAUNCH(bn_bwd_reduce_kernel, blocks, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd, gy,
-              partial, n_pix, C, ppb);
+              partial, n_pix, C, ppb, blocks);
     int rc = ds_last_launch_error();
     if (rc) return rc;
     DS_LAUNCH(bn_bwd_finalize_kernel, ds_ceil_div(C, FOLD_C), 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream,
@@ -560,9 +637,46 @@ extern "C" int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act,
     return ds_last_launch_error();
 }
 
+// ds_bn_bwd_f32 for a batch made of G members with their own batch statistics (Engine.forward_train_group: the three
+// forwards of a triplet step as one batch), in four launches instead of 3 G + 2: g1 / g2 / act / z / gy / gz are
+// [G * n_pix, C]; mean, invstd [G][C]; partial G * ds_bn_bwd_partial_rows(n_pix, C) * C * 2 floats; coef [G][3C];
+// member_sums [2][G][C] scratch; ggamma / gbeta [C] = the members' dgamma / dbeta added in member order.
+extern "C" int ds_bn_bwd_group_f32(const float *g1, const float *g2, const float *act, const float *z, const float *mean,
+                                   const float *invstd, const float *gamma, float *gy, float *partial, float *coef,
+                                   float *member_sums, float *ggamma, float *gbeta, float *gz, long long n_pix, int C,
+                                   int G, void *stream) {
+    DS_REQUIRE(g1 && z && mean && invstd && gamma && gy && partial && coef && member_sums && ggamma && gbeta && gz,
+               DS_ERR_NULL);
+    DS_REQUIRE(n_pix > 0 && G > 0 && G <= 64 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) && DS_ALIGNED16(gz) && DS_ALIGNED16(mean) &&
+                   DS_ALIGNED16(invstd) && DS_ALIGNED16(coef) && (!g2 || DS_ALIGNED16(g2)) && (!act || DS_ALIGNED16(act)),
+               DS_ERR_ALIGNMENT);
+    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
+    const int ppb = (int)((n_pix + blocks - 1) / blocks);
+    const int slots = 256 / (C / 4);
+    DS_LAUNCH(bn_bwd_reduce_kernel, blocks * G, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd, gy,
+              partial, n_pix, C, ppb, blocks);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    const int n_cgroups = ds_ceil_div(C, FOLD_C);
+    float *gg_m = member_sums, *gb_m = member_sums + (size_t)G * C;
+    DS_LAUNCH(bn_bwd_finalize_group_kernel, n_cgroups * G, 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream,
+              (const float *)partial, blocks, (double)n_pix, gamma, invstd, gg_m, gb_m, coef, C, n_cgroups);
+    rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(bn_member_sum_kernel, ds_ceil_div(C, 256), 256, 0, stream, (const float *)gg_m, (const float *)gb_m, ggamma,
+              gbeta, G, C);
+    rc = ds_last_launch_error();
+    if (rc) return rc;
+    const long long n_vec_member = n_pix * (C / 4);
+    DS_LAUNCH(bn_bwd_apply_group_kernel, grid_for(n_vec_member * G), 256, 0, stream, (const float *)gy, z, mean, invstd,
+              (const float *)coef, gz, n_vec_member, G, C);
+    return ds_last_launch_error();
+}
+
 extern "C" int ds_colsum_f32(const float *x, float *out, int R, int C, void *stream) {
     DS_REQUIRE(x && out, DS_ERR_NULL);
     DS_REQUIRE(R > 0 && C > 0, DS_ERR_BAD_SHAPE);
-    DS_LAUNCH(colsum_kernel, ds_ceil_div(C, 256), 256, 0, stream, x, out, R, C);
+    DS_LAUNCH(colsum_kernel, ds_ceil_div(C, 32), 256, 8 * 32 * sizeof(float), stream, x, out, R, C);
     return ds_last_launch_error();
 }

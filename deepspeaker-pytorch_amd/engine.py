@@ -282,16 +282,19 @@ class Engine:
         return y, stats
 
     def bn_finalize(self, stats: torch.Tensor, count: int, bn: BNParams, update_running: bool = True,
-                    reducer=None):
+                    reducer=None, out=None):
         """Per-tile partial sums -> batch mean / invstd / (scale, shift) + running-stat update.  With a
         `reducer` (data-parallel training) the [C][2] float64 sums and the pixel count are summed over
         the ranks first, so every rank normalises with the statistics of the global batch."""
         c = bn.weight.numel()
         dev = stats.device
-        mean = torch.empty(c, dtype=torch.float32, device=dev)
-        invstd = torch.empty_like(mean)
-        scale = torch.empty_like(mean)
-        shift = torch.empty_like(mean)
+        if out is not None:                     # (mean, invstd) destinations, e.g. rows of a per-member table
+            mean, invstd = out
+        else:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            invstd = torch.empty_like(mean)
+        scale = torch.empty(c, dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
         if reducer is not None and reducer.world > 1:
             sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
             self.lib.call("ds_partial_sum_f64", self._p(stats), stats.shape[0], self._p(sums), c, self._stream(stats))
@@ -750,8 +753,12 @@ class Engine:
                                   self._stream(z))
                     per.append((mean, invstd, sc, sh))
             else:
+                # the members' mean / invstd as rows of one [G][C] tensor each: the backward pass then runs every
+                # BatchNorm layer's reductions for all members in one launch (backward._bn_bwd_group)
+                mean_all = torch.empty((G, c), dtype=torch.float32, device=dev)
+                invstd_all = torch.empty((G, c), dtype=torch.float32, device=dev)
                 for g in range(G):                                # running statistics update in call order
-                    per.append(self.bn_finalize(sts[g], count, bn))
+                    per.append(self.bn_finalize(sts[g], count, bn, out=(mean_all[g], invstd_all[g])))
             a = torch.empty_like(z)
             n_pix = member(z, 0).numel() // c
             for g in range(G):

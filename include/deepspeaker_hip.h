@@ -265,6 +265,14 @@ int ds_bn_bwd_f32(const float *g1, const float *g2, const float *act, const floa
                   const float *mean, const float *invstd, const float *gamma, float *gy,
                   float *partial, float *coef, float *ggamma, float *gbeta, float *gz,
                   long long n_pix, int C, void *stream);
+/* the same for a batch made of G members with their own batch statistics (the three forwards of a triplet step run as
+ * one batch, train_triplet.py:215), in four launches: tensors [G * n_pix, C]; mean, invstd [G][C]; partial
+ * G * ds_bn_bwd_partial_rows(n_pix, C) * C * 2 floats; coef [G][3C]; member_sums [2][G][C] scratch; ggamma / gbeta [C] =
+ * the members' gradients added in member order (what three backward passes accumulate into .grad) */
+int ds_bn_bwd_group_f32(const float *g1, const float *g2, const float *act, const float *z, const float *mean,
+                        const float *invstd, const float *gamma, float *gy, float *partial, float *coef,
+                        float *member_sums, float *ggamma, float *gbeta, float *gz, long long n_pix, int C, int G,
+                        void *stream);
 int ds_colsum_f32(const float *x, float *out, int R, int C, void *stream);
 
 /* ---- split forms for data-parallel training (one process per GPU): the caller all-reduces the
