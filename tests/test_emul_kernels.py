@@ -237,6 +237,48 @@ def test_bn_bwd(C, npix, with_g2, with_act):
     assert rel_err(bufs["gz"], gz_ref[0, :, :, 0].T) < 1e-4
 
 
+
+@pytest.mark.parametrize("C,npix,G,with_g2,with_act", [(64, 300, 3, True, True), (512, 40, 3, False, True),
+                                                         (128, 77, 2, False, False)])
+def test_bn_bwd_group_equals_member_calls(C, npix, G, with_g2, with_act):
+    """ds_bn_bwd_group_f32 (all members of a grouped batch in four launches) == one ds_bn_bwd_f32 per member, bit for
+    bit, with dgamma / dbeta added in member order"""
+    lib = emul_lib()
+    rs = np.random.RandomState(C + npix + G)
+    z = (rs.randn(G * npix, C) * 2 + 1).astype(np.float32)
+    g1 = rs.randn(G * npix, C).astype(np.float32)
+    g2 = rs.randn(G * npix, C).astype(np.float32) if with_g2 else None
+    act = (rs.rand(G * npix, C).astype(np.float32) * 30 - 5).clip(0, 20) if with_act else None
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32)
+    zs = z.reshape(G, npix, C).astype(np.float64)
+    mean = zs.mean(1).astype(np.float32)
+    invstd = (1 / np.sqrt(zs.var(1) + 1e-5)).astype(np.float32)
+    rows = lib.raw("ds_bn_bwd_partial_rows")(npix, C)
+    A = dict(g1=to_aligned(g1), g2=to_aligned(g2) if with_g2 else None, act=to_aligned(act) if with_act else None,
+             z=to_aligned(z), mean=to_aligned(mean), invstd=to_aligned(invstd), gamma=to_aligned(gamma))
+    # grouped
+    gy, gz = aligned((G * npix, C), fill=np.nan), aligned((G * npix, C), fill=np.nan)
+    partial, coef = aligned((G, rows, C, 2), fill=np.nan), aligned((G, 3 * C), fill=np.nan)
+    msums, gg, gb = aligned((2, G, C), fill=np.nan), aligned(C, fill=np.nan), aligned(C, fill=np.nan)
+    lib.call("ds_bn_bwd_group_f32", ptr(A["g1"]), ptr(A["g2"]), ptr(A["act"]), ptr(A["z"]), ptr(A["mean"]),
+             ptr(A["invstd"]), ptr(A["gamma"]), ptr(gy), ptr(partial), ptr(coef), ptr(msums), ptr(gg), ptr(gb), ptr(gz),
+             npix, C, G, None)
+    # one call per member
+    gg_sum, gb_sum = np.zeros(C, np.float32), np.zeros(C, np.float32)
+    for g in range(G):
+        sl = slice(g * npix, (g + 1) * npix)
+        m = dict(g1=to_aligned(g1[sl]), g2=to_aligned(g2[sl]) if with_g2 else None,
+                 act=to_aligned(act[sl]) if with_act else None, z=to_aligned(z[sl]), mean=to_aligned(mean[g]),
+                 invstd=to_aligned(invstd[g]))
+        gy1, gz1 = aligned((npix, C), fill=np.nan), aligned((npix, C), fill=np.nan)
+        p1, c1, gg1, gb1 = aligned((rows, C, 2), fill=np.nan), aligned(3 * C), aligned(C), aligned(C)
+        lib.call("ds_bn_bwd_f32", ptr(m["g1"]), ptr(m["g2"]), ptr(m["act"]), ptr(m["z"]), ptr(m["mean"]), ptr(m["invstd"]),
+                 ptr(A["gamma"]), ptr(gy1), ptr(p1), ptr(c1), ptr(gg1), ptr(gb1), ptr(gz1), npix, C, None)
+        assert np.array_equal(gy[sl], gy1) and np.array_equal(gz[sl], gz1) and np.array_equal(coef[g], c1)
+        gg_sum, gb_sum = gg_sum + gg1, gb_sum + gb1
+    assert np.array_equal(gg, gg_sum) and np.array_equal(gb, gb_sum)
+
+
 WGRAD_CASES = [
     (2, 64, 64, 9, 32, 3, 1),       # stage-1 geometry, ragged rows
     (3, 128, 64, 20, 8, 3, 1),      # multi-row segments
