@@ -192,8 +192,12 @@ def main():
         else:
             for _ in range(steps):
                 step()
+        t_enq = time.perf_counter() - t0        # host time to enqueue the steps (the device may still be busy)
         fence()
         elapsed = time.perf_counter() - t0
+        if rank == 0:
+            print(f"[bench] host enqueue {t_enq / steps * 1e3:.3f} ms/step, device-complete {elapsed / steps * 1e3:.3f} ms/step",
+                  file=sys.stderr)
         prof, eng.profile = eng.profile, None
         if multi:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
