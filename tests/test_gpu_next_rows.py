@@ -183,3 +183,36 @@ def test_softmax_regime_reuses_embeddings():
     t_ref, t_new = timeit(reference_style), timeit(reuse_style)
     print(f"\nsoftmax regime step (B = {B}, eval BatchNorm): three extra forwards {t_ref:.2f} ms, re-used embeddings {t_new:.2f} ms")
     assert t_new < t_ref
+
+
+def test_overlapped_backward_same_gradients_and_memory():
+    """Filter gradients on the second stream (backward._FilterGradLane): the same gradients bit for bit, and the caching
+    allocator must not hold back the cross-stream blocks (Tensor.record_stream did: 3.7x the reserved memory)."""
+    from deepspeaker_pytorch_amd import backward
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
+    sd = O.make_state_dict(seed=41, num_classes=16)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(48, 1, 160, 64, generator=g).cuda() for _ in range(3)]
+    results = {}
+    try:
+        for overlap in (False, True):
+            backward.OVERLAP_FILTER_GRADIENTS = overlap
+            m = DeepSpeakerModel(512, 16, precision="bf16x3")
+            m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+            m = m.cuda().train()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            for _ in range(4):
+                m.zero_grad()
+                TripletMarginLoss(0.1).forward(*m.forward_triplet(*xs)).backward()
+            torch.cuda.synchronize()
+            results[overlap] = ({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                                torch.cuda.memory_reserved())
+            del m
+    finally:
+        backward.OVERLAP_FILTER_GRADIENTS = True
+    (g0, r0), (g1, r1) = results[False], results[True]
+    assert g0.keys() == g1.keys() and len(g0) > 30
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert r1 < 1.5 * r0, (r0 >> 20, r1 >> 20)
