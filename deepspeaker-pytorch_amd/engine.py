@@ -82,6 +82,9 @@ class SavedForward:
 
 
 class Engine:
+    PLAN_CACHE_ENTRIES = 64            # eval launch plans kept (each owns its activation buffers), LRU
+    PLAN_CACHE_BYTES = 32 << 30        # ... and their total size
+
     def __init__(self, lib: NativeLib):
         self.lib = lib
         # When set to a list, every implicit-GEMM convolution launch is bracketed by two events on the
@@ -511,8 +514,10 @@ class Engine:
             plan = self._build_eval_plan(x, pw, folded, precision, masked=lengths is not None,
                                          low_latency=low_latency and precision == "f16")
             plan["bytes"] = sum(t.numel() * t.element_size() for t in plan["keep"] if isinstance(t, torch.Tensor))
-            # least recently used first (dicts keep insertion order): at most 64 plans / 32 GiB of activation buffers
-            while plans and (len(plans) >= 64 or sum(q["bytes"] for q in plans.values()) + plan["bytes"] > (32 << 30)):
+            # least recently used first (dicts keep insertion order): at most PLAN_CACHE_ENTRIES plans /
+            # PLAN_CACHE_BYTES of activation buffers (class attributes; lower them on a GPU shared with other work)
+            while plans and (len(plans) >= self.PLAN_CACHE_ENTRIES
+                             or sum(q["bytes"] for q in plans.values()) + plan["bytes"] > self.PLAN_CACHE_BYTES):
                 del plans[next(iter(plans))]
             plans[key] = plan
         if lengths is not None:
