@@ -4,10 +4,10 @@ else in f32 -- embedding error, error of d_n - d_p and flipped filter decisions 
 the choice of the fp16 arithmetic was made on before the kernel existed.  python tools/arith_sim.py"""
 import os, sys, time, numpy as np, torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import deepspeaker_oracle as O
+sys.path.insert(0, ROOT)
+from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
 torch.set_num_threads(8)
-sd_np = O.make_state_dict(seed=0, num_classes=1211)
+sd_np = synthetic_state_dict(0, 1211)
 sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
 g = torch.Generator(device="cpu").manual_seed(1234)
 x_all = torch.randn(768, 1, 160, 64, generator=g)

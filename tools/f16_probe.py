@@ -5,16 +5,15 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    sys.path.insert(0, p)
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-import deepspeaker_oracle as O
 from deepspeaker_pytorch_amd.model import DeepSpeakerModel, get_engine
+from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
 
 dev = torch.device("cuda", 0)
-sd_np = O.make_state_dict(seed=0, num_classes=1211)
+sd_np = synthetic_state_dict(0, 1211)
 g = torch.Generator(device="cpu").manual_seed(1234)
 x = torch.randn(768, 1, 160, 64, generator=g).to(dev)
 embs = {}
