@@ -296,7 +296,7 @@ extern "C" int ds_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H
     return ds_last_launch_error();
 }
 
-extern "C" int ds_version(void) { return 100; }
+extern "C" int ds_version(void) { return 200; }   // 200: round-2 ABI (fp16 path, grouped BatchNorm backward, ds_bn_bwd_partial_rows(n_pix, C))
 
 extern "C" const char *ds_error_string(int code) {
     switch (code) {

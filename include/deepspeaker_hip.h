@@ -58,7 +58,7 @@ extern "C" {
 
 #define DS_CONV_CK      8   /* input-channel chunk of the packed weight layout */
 
-int ds_version(void);
+int ds_version(void);            /* 100: round 1; 200: round 2 (fp16 path, grouped BatchNorm backward, ds_bn_bwd_partial_rows takes C) */
 const char *ds_error_string(int code);
 
 /* ---- layout ---------------------------------------------------------------------------------- */
