@@ -20,10 +20,11 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const float *gamma, const 
     }
 }
 
-// Fold of [n_partial][C][2] partial sums in double precision, fixed order: one workgroup per 8 channels,
-// 32 row-lanes stride over the partial rows (stage-1 layers have thousands of rows and only 64 channels --
-// a channel-per-thread layout left the chip idle), then lane 0 folds the 32 lane sums.
-constexpr int FOLD_C = 8, FOLD_R = 32;
+// Fold of [n_partial][C][2] partial sums in double precision, fixed order: one workgroup per FOLD_C channels,
+// FOLD_R row-lanes stride over the partial rows (stage-1 layers have thousands of rows and only 64 channels --
+// a channel-per-thread layout left the chip idle; 8 channels x 32 lanes still meant 8 workgroups walking 64 rows
+// each: 27 us, now 8), then lane 0 folds the lane sums.
+constexpr int FOLD_C = 2, FOLD_R = 128;
 __device__ __forceinline__ bool fold_partials(const float *partial, int n_partial, int C, double *red, int &c,
                                               double &t1, double &t2, int cgroup = -1) {
     const int cl = threadIdx.x % FOLD_C, rl = threadIdx.x / FOLD_C;
