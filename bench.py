@@ -304,6 +304,13 @@ def main():
              "launches": len(prof), "avg_launch_ms": round(ms / max(len(prof), 1), 4),
              "conv_ms_per_step": round(ms / steps, 3),
              "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}}
+        # what this chip's matrix cores deliver when they do nothing else (tools/mfma_peak.hip, profiles/r02_mfma_peak.txt:
+        # back-to-back MFMAs from registers with random operand bits; the nominal peak assumes 2.4 GHz sustained, the
+        # chip's power management does not) -- context for `frac`, replayed, not measured in this run
+        attainable = {"f16": 1680.0, "bf16x3": 1823.0, "bf16": 1823.0, "f32": 151.0}.get(precision)
+        if attainable:
+            r["mfma_register_only_tflops"] = attainable
+            r["frac_of_register_only"] = round((3 if precision == "bf16x3" else 1) * achieved / attainable, 4)
         if precision == "bf16x3":
             # "achieved" counts each product once (algorithmic FLOPs); the matrix cores issue three MFMAs per
             # product, so their issue rate is 3x that
