@@ -46,42 +46,52 @@ ARITH = {"f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations",
          "f16": "fp16 MFMA operands (v_mfma_f32_32x32x16_f16, one MFMA per product, f32 accumulate), fp16 activations "
                 "in HBM, f32 conv1 input / pooling / projection / loss; embeddings 3.7e-4 from the reference (contract "
                 "1e-3, tests/test_gpu_bench_size.py); triplets within 1.25e-3 of the filter's decision boundary are "
-                "re-embedded through the split-operand bf16 path inside the timed step, so the selection is the "
-                "reference's"}
+                "re-embedded through the split-operand bf16 path inside the timed step (slots sized from the near-tie "
+                "counts of earlier steps; more near ties than slots => the selection re-embeds the whole batch at "
+                "f32-class precision when it is read), so the selection is the reference's; see `refine`"}
 
 
-def cpu_baseline(sd_np, budget_s=10.0):
+def cpu_baseline(sd_np, budget_s=9.0):
     """The reference's CPU forward (torch ATen/oneDNN; restated in oracle/torch_restatement.py because
-    /root/reference is absent on the GPU box), eval mode, fp32, on the host cores.  The thread count
-    is the best of a short scan (oneDNN degrades badly when over-subscribed).  Bounded sample."""
+    /root/reference is absent on the GPU box), eval mode, fp32, on the host cores, at B = 32 and B = 256
+    (BASELINE.md section 4).  The thread count is the best of a short scan (oneDNN degrades badly when
+    over-subscribed); `cores` = the threads used for the reported value.  Bounded samples."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))        # the checker, used by this leg only
     import torch_restatement as TR
     ncpu = os.cpu_count() or 1
     sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
-    B = 32
-    x = torch.randn(B, 1, FRAMES, 64)
+    x32 = torch.randn(32, 1, FRAMES, 64)
     best = None
     with torch.no_grad():
         for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
             torch.set_num_threads(nt)
-            TR.forward_eval(sd, x)                                # warm-up at this thread count
+            TR.forward_eval(sd, x32)                              # warm-up at this thread count
             t0 = time.perf_counter()
-            TR.forward_eval(sd, x)
+            TR.forward_eval(sd, x32)
             dt = time.perf_counter() - t0
             if best is None or dt < best[1]:
                 best = (nt, dt)
         cores = best[0]
         torch.set_num_threads(cores)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            TR.forward_eval(sd, x)
-            n += B
-            dt = time.perf_counter() - t0
-            if dt > budget_s or n >= 256 * B:
-                break
-    return {"value": round(n / dt, 1), "unit": "embeddings/s", "cores": cores, "kind": "port",
-            "sample": f"{n} utterances [1,{FRAMES},64] in batches of {B}, eval forward, fp32, "
-                      f"torch {torch.__version__} CPU, {cores} threads (best of a scan; host has {ncpu}), {dt:.1f} s"}
+        by_batch = {}
+        for B in (32, 256):
+            x = torch.randn(B, 1, FRAMES, 64)
+            TR.forward_eval(sd, x)                                # 1 warm-up (BASELINE.md section 4)
+            n, reps, t0 = 0, 0, time.perf_counter()
+            while True:
+                TR.forward_eval(sd, x)
+                n += B
+                reps += 1
+                dt = time.perf_counter() - t0
+                if (dt > budget_s and reps >= 3) or reps >= 64:
+                    break
+            by_batch[B] = (n / dt, n, reps, dt)
+    v32, v256 = by_batch[32], by_batch[256]
+    return {"value": round(v32[0], 1), "unit": "embeddings/s", "cores": cores, "host_cores": ncpu, "kind": "port",
+            "value_b256": round(v256[0], 1),
+            "sample": f"B=32: {v32[1]} utterances [1,{FRAMES},64] ({v32[2]} forwards, {v32[3]:.1f} s); B=256: {v256[1]} "
+                      f"utterances ({v256[2]} forwards, {v256[3]:.1f} s); eval forward, fp32, torch {torch.__version__} CPU, "
+                      f"{cores} threads (best of a scan over 8..128; the host has {ncpu})"}
 
 
 def main():
@@ -90,6 +100,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="after the contract's timed region (W warm-up + K steps -> `value`), time the same K-step region "
+                         "this many more times and report median / min / max ms per step (box-to-box and DVFS spread)")
     ap.add_argument("--precision", default="f16", choices=["f32", "bf16x3", "bf16", "f16"],
                     help="arithmetic of the stage convolutions: fp16 operands + fp16 activations (default; 3.7e-4 from "
                          "the reference, near-tie selections refined at f32-class precision), split-operand bf16 MFMA "
@@ -129,7 +142,8 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
 
-    from deepspeaker_pytorch_amd.mining import mine_semihard_negatives, select_triplets, side_stream as side_stream_of
+    from deepspeaker_pytorch_amd.mining import (REFINE_BAND, mine_semihard_negatives, select_triplets,
+                                                side_stream as side_stream_of)
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss, get_engine
     from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
 
@@ -166,19 +180,9 @@ def main():
         model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
         return model.to(dev)
 
-    def timed(step, steps, warmup):
-        eng.profile = []                        # warm-up with the event instrumentation on: the first
-        for _ in range(max(0, 30 - warmup)):    # timing events of a process cost ~40 ms to create; and a fresh
-            step()                              # box needs ~0.2 s of work before clocks / caches settle (setup,
-        fence()                                 # not part of the W contract warm-up steps that follow)
-        eng.profile = []
-        for _ in range(warmup):
-            step()
-        for j, st_ in enumerate(streams):       # launch plans / allocator pools of the side streams
-            with torch.cuda.stream(st_):
-                step(j)
+    def region(step, steps):
+        """K steps bracketed by barrier + synchronize on both sides; max over ranks."""
         fence()
-        eng.profile = []
         t0 = time.perf_counter()
         if args.streams > 1:
             cur = torch.cuda.current_stream(dev)
@@ -195,20 +199,40 @@ def main():
         t_enq = time.perf_counter() - t0        # host time to enqueue the steps (the device may still be busy)
         fence()
         elapsed = time.perf_counter() - t0
-        if rank == 0:
-            print(f"[bench] host enqueue {t_enq / steps * 1e3:.3f} ms/step, device-complete {elapsed / steps * 1e3:.3f} ms/step",
-                  file=sys.stderr)
-        prof, eng.profile = eng.profile, None
         if multi:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, prof
+        return elapsed, t_enq
 
-    def measure(precision, steps, warmup):
+    def timed(step, steps, warmup, repeats=0):
+        eng.profile = []                        # warm-up with the event instrumentation on: the first
+        for _ in range(max(0, 30 - warmup)):    # timing events of a process cost ~40 ms to create; and a fresh
+            step()                              # box needs ~0.2 s of work before clocks / caches settle (setup,
+        fence()                                 # not part of the W contract warm-up steps that follow)
+        eng.profile = []
+        for _ in range(warmup):
+            step()
+        for j, st_ in enumerate(streams):       # launch plans / allocator pools of the side streams
+            with torch.cuda.stream(st_):
+                step(j)
+        eng.profile = []
+        elapsed, t_enq = region(step, steps)
+        if rank == 0:
+            print(f"[bench] host enqueue {t_enq / steps * 1e3:.3f} ms/step, device-complete {elapsed / steps * 1e3:.3f} ms/step",
+                  file=sys.stderr)
+        prof, eng.profile = eng.profile, None
+        # the same region again, `repeats` times, without the per-launch events: the spread of the box
+        again = [region(step, steps)[0] / steps * 1e3 for _ in range(repeats)]
+        if rank == 0 and again:
+            print(f"[bench] repeats of the {steps}-step region, ms/step: " + ", ".join(f"{v:.3f}" for v in again), file=sys.stderr)
+        return elapsed, prof, again
+
+    def measure(precision, steps, warmup, repeats=0):
         model = load_model(precision).eval()
         last_mined = [[None, None] for _ in range(n_slots)]
         parity = [0] * n_slots
+        sels = []
 
         def step(slot=0):
             par = parity[slot]
@@ -244,18 +268,31 @@ def main():
                 else:
                     mined = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels_loc, side_stream=True)
             last_mined[slot][par] = mined
+            sels.append(sel)
+            if len(sels) > 4 * steps:
+                del sels[:-steps]
             return loss, sel, mined
 
-        return timed(step, steps, warmup)
+        elapsed, prof, again = timed(step, steps, warmup, repeats)
+        refine = None
+        if precision == "f16":
+            # what the near-tie refinement did in the steps just timed (read AFTER the timed regions: the step itself
+            # never synchronises; an overflow would re-embed the whole batch when the selection is read)
+            last = sels[-steps:]
+            ties = [s_.n_near_ties for s_ in last]
+            pol = model._refine_policy
+            refine = {"band": REFINE_BAND, "slots": [s_.amb_cap for s_ in last][-1], "near_ties_mean": round(sum(ties) / len(ties), 2),
+                      "near_ties_max": max(ties), "overflow_steps": sum(int(s_.refine_overflow) for s_ in last),
+                      "steps": len(last), "calls_total": pol.calls, "overflows_total": pol.overflows}
+        return elapsed, prof, again, refine
 
-    def measure_train(precision, steps, warmup):
+    def measure_train(precision, steps, warmup, repeats=0):
         """The training step of the triplet regime (train_triplet.py:215-224): train-mode forwards of a / p / n
         (three BatchNorm statistic sets, as the reference), triplet loss, backward (gradient all-reduce inside),
         fused Adagrad (lr 0.1, lr_decay 1e-4: train_triplet.py:369-383)."""
         from deepspeaker_pytorch_amd.optim import create_optimizer
         model = load_model(precision).train()
-        if multi:
-            model.enable_data_parallel()
+        red = model.enable_data_parallel(force=args.force_collectives) if multi else None
         opt = create_optimizer(model, 0.1, "adagrad", lr_decay=1e-4)
 
         def step(slot=0):
@@ -269,9 +306,18 @@ def main():
             opt.zero_grad(set_to_none=True)
             loss.backward()
             opt.step()
+            if multi:                           # the global loss the loop logs every step (train_triplet.py:226)
+                red.all_reduce_sum_(loss.detach())
             return loss
 
-        return timed(step, steps, warmup)
+        elapsed, prof, again = timed(step, steps, warmup, repeats)
+        per_step = None
+        if red is not None:
+            n0 = red.n_all_reduce
+            step()
+            per_step = red.n_all_reduce - n0
+            fence()
+        return elapsed, prof, again, per_step
 
     def roofline_of(precision, prof, steps):
         # live roofline of the dominant kernel family (the implicit-GEMM convolution of `precision`): algorithmic
@@ -304,6 +350,10 @@ def main():
              "launches": len(prof), "avg_launch_ms": round(ms / max(len(prof), 1), 4),
              "conv_ms_per_step": round(ms / steps, 3),
              "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}}
+        # the member of the family furthest below the roofline (what the next optimisation round goes after)
+        worst = min(((k, v[0] / (v[1] * 1e-3) / 1e12) for k, v in by.items() if v[1] > 0), key=lambda kv: kv[1], default=None)
+        if worst:
+            r["worst_kernel"] = {"name": worst[0], "tflops": round(worst[1], 1), "frac": round(worst[1] / peak, 4)}
         # what this chip's matrix cores deliver when they do nothing else (tools/mfma_peak.hip, profiles/r02_mfma_peak.txt:
         # back-to-back MFMAs from registers with random operand bits; the nominal peak assumes 2.4 GHz sustained, the
         # chip's power management does not) -- context for `frac`, replayed, not measured in this run
@@ -321,9 +371,9 @@ def main():
     emb_per_step = 3 * BATCH_TRIPLETS * world
     if args.train:
         tprec = "bf16x3" if args.precision in ("bf16x3", "f16") else "f32"
-        elapsed, prof = measure_train(tprec, args.steps, args.warmup)
+        elapsed, prof, again, ar_per_step = measure_train(tprec, args.steps, args.warmup, args.repeats)
         if rank == 0:
-            print(json.dumps({
+            line = {
                 "metric": "training utterances/sec (64-fbank x 160-frame utterances)",
                 "value": round(emb_per_step * args.steps / elapsed, 1), "unit": "utterances/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -331,22 +381,29 @@ def main():
                 "config": {"workload": "triplet-regime training step (train_triplet.py:215-224): train-mode forward of "
                                        "256 triplets = 768 x [1,160,64] utterances per GPU, triplet loss, backward, "
                                        "gradient all-reduce, fused Adagrad",
-                           "batch_triplets": BATCH_TRIPLETS, "parallelism": f"dp{world}"}}))
+                           "batch_triplets": BATCH_TRIPLETS, "parallelism": f"dp{world}"}}
+            if ar_per_step is not None:
+                # 12 BatchNorm layers x {forward, backward} + 5 gradient buckets + the logged loss
+                line["all_reduce_per_step"] = ar_per_step
+            if again:
+                line["repeats_ms_per_step"] = {"median": round(float(np.median(again)), 3), "min": round(min(again), 3),
+                                               "max": round(max(again), 3), "n": len(again)}
+            print(json.dumps(line))
         if multi:
             dist.destroy_process_group()
         return
 
-    elapsed, prof = measure(args.precision, args.steps, args.warmup)
+    elapsed, prof, again, refine = measure(args.precision, args.steps, args.warmup, args.repeats)
 
     secondary = {}
     if world == 1 and not args.no_secondary:
         for prec in ("bf16x3", "f32"):                              # untimed comparisons: the f32-class paths
             if prec != args.precision:
                 k2 = max(3, args.steps // 2)
-                e2, p2 = measure(prec, k2, 2)
+                e2, p2, _, _ = measure(prec, k2, 2)
                 secondary[prec] = (e2, p2, k2)
         kt = max(3, args.steps // 4)
-        et, _ = measure_train("bf16x3", kt, 2)
+        et, _, _, _ = measure_train("bf16x3", kt, 2)
         # BASELINE configs[4]: variable-length inference (100-800 frames) + enrolment scoring, same arithmetic
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import varlen_bench
@@ -370,6 +427,13 @@ def main():
             "roofline": roofline_of(args.precision, prof, args.steps),
             "whole_forward_tflops": round(value * FWD_FLOPS_PER_EMB / 1e12, 2),
         }
+        # the whole step (conv1, tail, loss, filter, refinement, search and launch gaps included) against the same peak
+        out["roofline"]["step_frac"] = round(value * FWD_FLOPS_PER_EMB / 1e12 / PEAK_TFLOPS[args.precision], 4)
+        if again:       # the contract's region is `value`; these are the same region timed again (box spread, DVFS)
+            out["repeats_ms_per_step"] = {"median": round(float(np.median(again)), 3), "min": round(min(again), 3),
+                                          "max": round(max(again), 3), "n": len(again)}
+        if refine is not None:
+            out["refine"] = refine
         for prec, (e2, p2, k2) in secondary.items():
             out[prec + "_path"] = {"value": round(emb_per_step * k2 / e2, 1), "unit": "embeddings/s", "steps": k2,
                                    "roofline": roofline_of(prec, p2, k2)}

@@ -89,6 +89,9 @@ _SIGNATURES = {
     "ds_bn_bwd_group_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "ds_colsum_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "ds_partial_sum_f64": (c_int, [_P, c_int, _P, c_int, _P]),
+    "ds_partial_sum_f64_group": (c_int, [_P, c_int, _P, c_longlong, c_int, c_int, _P]),
+    "ds_bn_bwd_group_reduce_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
+    "ds_bn_bwd_group_apply_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "ds_bn_stats_from_sums_f32": (c_int, [_P, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_bn_bwd_reduce_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
     "ds_bn_bwd_apply_f32": (c_int, [_P, c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
@@ -131,6 +134,7 @@ class NativeLib:
                 f"{path} not found: build it with `make` (hipcc --offload-arch=gfx950); "
                 "this package has no fallback path")
         self.path = path
+        self.trace = None                       # set to a dict to count calls per entry point (NativeLib.call only)
         self._dll = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(self._dll, name)        # AttributeError if the ABI is incomplete
@@ -142,6 +146,8 @@ class NativeLib:
         return self._ds_error_string(code).decode()
 
     def call(self, name: str, *args):
+        if self.trace is not None:              # tests / tools: which entry points a step really went through
+            self.trace[name] = self.trace.get(name, 0) + 1
         rc = getattr(self, "_" + name)(*args)
         if rc != 0:
             raise DeepSpeakerHipError(f"{name} failed: {rc} ({self.error_string(rc)})")

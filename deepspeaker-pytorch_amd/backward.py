@@ -35,7 +35,7 @@ def _bn_bwd_group(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     def m(t, g):
         return None if t is None else t[g * Bm:(g + 1) * Bm]
 
-    dp = reducer is not None and reducer.world > 1
+    dp = reducer is not None and reducer.active
     partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=dev)
     coef = torch.empty((G, 3 * c), dtype=torch.float32, device=dev)
     # the members' statistics as consecutive rows of one table (Engine.forward_train_group lays them out so): all
@@ -48,6 +48,17 @@ def _bn_bwd_group(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
         eng.lib.call("ds_bn_bwd_group_f32", eng._p(g1), eng._p(g2), eng._p(act), eng._p(z), eng._p(stats[0][0]),
                      eng._p(stats[0][1]), eng._p(gamma.detach()), eng._p(gy), eng._p(partial), eng._p(coef),
                      eng._p(member_sums), eng._p(gg), eng._p(gb), eng._p(gz), n_pix, c, G, st)
+        return gy, gz, gg, gb
+    if dp and tabled:
+        # the same grouped launches, split where the sums of ALL members travel in one all-reduce (2 + 3 launches)
+        sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=dev)
+        eng.lib.call("ds_bn_bwd_group_reduce_f32", eng._p(g1), eng._p(g2), eng._p(act), eng._p(z), eng._p(stats[0][0]),
+                     eng._p(stats[0][1]), eng._p(gy), eng._p(partial), eng._p(sums), n_pix, c, G, st)
+        reducer.all_reduce_sum_(sums)
+        gg, gb = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
+        eng.lib.call("ds_bn_bwd_group_apply_f32", eng._p(sums), eng._p(gy), eng._p(z), eng._p(stats[0][0]),
+                     eng._p(stats[0][1]), eng._p(gamma.detach()), eng._p(coef), eng._p(member_sums), eng._p(gg), eng._p(gb),
+                     eng._p(gz), n_pix, c, G, st)
         return gy, gz, gg, gb
     if not dp:
         for g in range(G):
@@ -92,7 +103,7 @@ def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     coef = torch.empty(3 * c, dtype=torch.float32, device=dev)
     gg = torch.empty(c, dtype=torch.float32, device=dev)
     gb = torch.empty_like(gg)
-    if reducer is not None and reducer.world > 1:
+    if reducer is not None and reducer.active:
         st = eng._stream(z)
         eng.lib.call("ds_bn_bwd_reduce_f32", eng._p(g1), eng._p(g2), eng._p(act), eng._p(z), eng._p(mean),
                      eng._p(invstd), eng._p(gy), eng._p(partial), n_pix, c, st)
@@ -192,7 +203,7 @@ class _GradBuckets:
     statistic sums and are not reduced."""
 
     def __init__(self, shapes: Dict[int, Dict[str, tuple]], device, reducer=None):
-        self.reducer = reducer if (reducer is not None and reducer.world > 1) else None
+        self.reducer = reducer if (reducer is not None and reducer.active) else None
         self.views: Dict[str, torch.Tensor] = {}
         self.flat: Dict[int, torch.Tensor] = {}
         self.work = []

@@ -297,7 +297,7 @@ extern "C" int ds_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H
     return ds_last_launch_error();
 }
 
-extern "C" int ds_version(void) { return 200; }   // 200: round-2 ABI (fp16 path, grouped BatchNorm backward, ds_bn_bwd_partial_rows(n_pix, C))
+extern "C" int ds_version(void) { return 300; }   // 300: round-3 ABI (+ split grouped BatchNorm backward for data parallelism, grouped f64 sums)
 
 extern "C" const char *ds_error_string(int code) {
     switch (code) {
@@ -550,6 +550,56 @@ __global__ void __launch_bounds__(256) bn_bwd_from_sums_kernel(const double *sum
     coef[2 * C + c] = (float)(sums[c * 2 + 1] / count);
 }
 
+// The grouped forms (a batch of G members with their own statistics, data-parallel): workgroup = (member, channel
+// group).  sums is [G][2C+1] doubles: per member C pairs, then the member's pixel count (which travels with the
+// all-reduce).
+__global__ void __launch_bounds__(256) partial_sum_f64_group_kernel(const float *partial, int n_partial, double *sums,
+                                                                    double count, int C, int n_cgroups) {
+    double *red = (double *)ds_dynamic_lds();
+    const int member = blockIdx.x / n_cgroups, cgroup = blockIdx.x - member * n_cgroups;
+    partial += (size_t)member * n_partial * C * 2;
+    sums += (size_t)member * (2 * C + 1);
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = cgroup * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rl; r < n_partial; r += 8) {
+            s1 += (double)partial[((size_t)r * C + c) * 2 + 0];
+            s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
+        }
+    red[(rl * 32 + cl) * 2 + 0] = s1;
+    red[(rl * 32 + cl) * 2 + 1] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            t1 += red[(k * 32 + cl) * 2 + 0];
+            t2 += red[(k * 32 + cl) * 2 + 1];
+        }
+        sums[c * 2 + 0] = t1;
+        sums[c * 2 + 1] = t2;
+    }
+    if (cgroup == 0 && threadIdx.x == 0) sums[2 * C] = count;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_from_sums_group_kernel(const double *sums, const float *gamma,
+                                                                     const float *invstd, float *ggamma_m,
+                                                                     float *gbeta_m, float *coef, int C,
+                                                                     int n_cgroups) {
+    const int member = blockIdx.x / n_cgroups, cgroup = blockIdx.x - member * n_cgroups;
+    const int c = cgroup * 256 + threadIdx.x;
+    if (c >= C) return;
+    sums += (size_t)member * (2 * C + 1);
+    invstd += (size_t)member * C;
+    coef += (size_t)member * 3 * C;
+    const double count = sums[2 * C];
+    gbeta_m[(size_t)member * C + c] = (float)sums[c * 2];
+    ggamma_m[(size_t)member * C + c] = (float)sums[c * 2 + 1];
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(sums[c * 2] / count);
+    coef[2 * C + c] = (float)(sums[c * 2 + 1] / count);
+}
+
 }  // namespace
 
 extern "C" int ds_partial_sum_f64(const float *partial, int n_partial, double *sums, int C, void *stream) {
@@ -672,6 +722,62 @@ extern "C" int ds_bn_bwd_group_f32(const float *g1, const float *g2, const float
     const long long n_vec_member = n_pix * (C / 4);
     DS_LAUNCH(bn_bwd_apply_group_kernel, grid_for(n_vec_member * G), 256, 0, stream, (const float *)gy, z, mean, invstd,
               (const float *)coef, gz, n_vec_member, G, C);
+    return ds_last_launch_error();
+}
+
+// ds_bn_bwd_group_f32 split at the point where data-parallel training exchanges the sums: the local
+// reductions of all G members -> sums [G][2C+1] float64 (C pairs {sum gy, sum gy*xhat} and the member's pixel count)
+// ... all-reduce by the caller ... -> coefficients, dgamma / dbeta and gz of all members.  Two + three launches.
+extern "C" int ds_bn_bwd_group_reduce_f32(const float *g1, const float *g2, const float *act, const float *z,
+                                          const float *mean, const float *invstd, float *gy, float *partial,
+                                          double *sums, long long n_pix, int C, int G, void *stream) {
+    DS_REQUIRE(g1 && z && mean && invstd && gy && partial && sums, DS_ERR_NULL);
+    DS_REQUIRE(n_pix > 0 && G > 0 && G <= 64 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) && DS_ALIGNED16(mean) && DS_ALIGNED16(invstd) &&
+                   (!g2 || DS_ALIGNED16(g2)) && (!act || DS_ALIGNED16(act)), DS_ERR_ALIGNMENT);
+    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
+    const int ppb = (int)((n_pix + blocks - 1) / blocks);
+    const int slots = 256 / (C / 4);
+    DS_LAUNCH(bn_bwd_reduce_kernel, blocks * G, 256, (size_t)slots * C * 2 * 4, stream, g1, g2, act, z, mean, invstd, gy,
+              partial, n_pix, C, ppb, blocks);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(partial_sum_f64_group_kernel, ds_ceil_div(C, 32) * G, 256, 8 * 32 * 2 * sizeof(double), stream,
+              (const float *)partial, blocks, sums, (double)n_pix, C, ds_ceil_div(C, 32));
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_bn_bwd_group_apply_f32(const double *sums, const float *gy, const float *z, const float *mean,
+                                         const float *invstd, const float *gamma, float *coef, float *member_sums,
+                                         float *ggamma, float *gbeta, float *gz, long long n_pix, int C, int G,
+                                         void *stream) {
+    DS_REQUIRE(sums && gy && z && mean && invstd && gamma && coef && member_sums && ggamma && gbeta && gz, DS_ERR_NULL);
+    DS_REQUIRE(n_pix > 0 && G > 0 && G <= 64 && C >= 4 && (C % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(gy) && DS_ALIGNED16(z) && DS_ALIGNED16(gz) && DS_ALIGNED16(mean) && DS_ALIGNED16(invstd) &&
+                   DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
+    float *gg_m = member_sums, *gb_m = member_sums + (size_t)G * C;
+    DS_LAUNCH(bn_bwd_from_sums_group_kernel, ds_ceil_div(C, 256) * G, 256, 0, stream, sums, gamma, invstd, gg_m, gb_m,
+              coef, C, ds_ceil_div(C, 256));
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(bn_member_sum_kernel, ds_ceil_div(C, 256), 256, 0, stream, (const float *)gg_m, (const float *)gb_m, ggamma,
+              gbeta, G, C);
+    rc = ds_last_launch_error();
+    if (rc) return rc;
+    const long long n_vec_member = n_pix * (C / 4);
+    DS_LAUNCH(bn_bwd_apply_group_kernel, grid_for(n_vec_member * G), 256, 0, stream, gy, z, mean, invstd,
+              (const float *)coef, gz, n_vec_member, G, C);
+    return ds_last_launch_error();
+}
+
+// The forward counterpart: per-tile partial statistics of G members (each n_partial rows of [C][2]) -> sums [G][2C+1]
+// float64 in ONE launch (what the per-BatchNorm-layer all-reduce of data-parallel training carries).
+extern "C" int ds_partial_sum_f64_group(const float *partial, int n_partial, double *sums, long long count, int C, int G,
+                                        void *stream) {
+    DS_REQUIRE(partial && sums, DS_ERR_NULL);
+    DS_REQUIRE(n_partial > 0 && C > 0 && G > 0 && G <= 64 && count > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(partial_sum_f64_group_kernel, ds_ceil_div(C, 32) * G, 256, 8 * 32 * 2 * sizeof(double), stream, partial,
+              n_partial, sums, (double)count, C, ds_ceil_div(C, 32));
     return ds_last_launch_error();
 }
 

@@ -22,6 +22,7 @@ left to hide behind).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -32,13 +33,18 @@ import torch.distributed as dist
 class Reducer:
     """Thin handle on a process group (backend "nccl" = RCCL on ROCm; "gloo" in the CPU logic tests)."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, force: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised: launch one process per GPU with "
                                "torch.distributed.run and call dist.init_process_group('nccl') first")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # `active`: take the data-parallel launch sequence (float64 sums -> all-reduce -> *_from_sums kernels, gradient
+        # buckets reduced from inside the backward pass, all-gather / reduce-scatter of embeddings).  A group of one
+        # has nothing to exchange and skips it -- unless `force` (or DS_FORCE_COLLECTIVES=1) asks for the very same
+        # sequence an N-rank job runs, collectives included: how the path is exercised on a single GPU.
+        self.active = self.world > 1 or force or os.environ.get("DS_FORCE_COLLECTIVES", "0") == "1"
         self.n_all_reduce = 0           # collectives issued so far (tests assert the per-step count)
 
     def all_reduce_sum_(self, t: torch.Tensor, async_op: bool = False):
@@ -85,7 +91,7 @@ def needs_allreduce(name: str) -> bool:
 def allreduce_gradients(grads: Dict[str, torch.Tensor], reducer: Reducer, n_buckets: int = 5) -> None:
     """Sum filter / fc gradients over the ranks in place: a few flat buckets (one per stage + fc),
     launched asynchronously back to back, then copied back.  Deterministic bucket composition."""
-    if reducer.world == 1:
+    if not reducer.active:
         return
     names = sorted(n for n in grads if needs_allreduce(n))
     buckets: List[List[str]] = [[] for _ in range(n_buckets)]
@@ -146,7 +152,7 @@ def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, redu
         c1, c2 = labels
         loc = torch.cat([ea, ep, en])
         lab = torch.cat([c1, c1, c2]).to(torch.int64)
-        if reducer is not None and world > 1:
+        if reducer is not None and reducer.active:
             # [world][3*n_loc] rank-major candidate set and its labels
             gathered = reducer.all_gather_rows(loc)
             glab = reducer.all_gather_rows(lab)
@@ -165,7 +171,7 @@ def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, redu
     loss_loc, d_p, d_n = eng.triplet_margin(ea, ep, en_used, margin)
     # global mean: local mean * n_loc / n_glob, summed over ranks
     loss = loss_loc * (float(n_loc) / float(n_glob))
-    if reducer is not None and world > 1:
+    if reducer is not None and reducer.active:
         reducer.all_reduce_sum_(loss)
     gl = torch.full((1,), float(n_loc) / float(n_glob), dtype=torch.float32, device=ea.device)
     ga, gp, gn_used = torch.empty_like(ea), torch.empty_like(ep), torch.empty_like(en)
@@ -176,7 +182,7 @@ def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, redu
         gcand = torch.empty_like(gathered)
         lib.call("ds_scatter_add_rows_f32", eng._p(gn_used), eng._p(mined), eng._p(gcand), n_loc,
                  gathered.shape[0], d, 0, st)
-        if reducer is not None and world > 1:
+        if reducer is not None and reducer.active:
             gcand = reducer.reduce_scatter_rows(gcand)
         ga = ga + gcand[:n_loc]                         # elementwise accumulation of two gradient paths
         gp = gp + gcand[n_loc:2 * n_loc]

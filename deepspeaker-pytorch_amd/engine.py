@@ -67,6 +67,7 @@ class PackedWeights:
     fc_bias: torch.Tensor
     fc_ones: torch.Tensor
     fc_dgrad: Optional[torch.Tensor] = None
+    owner: Optional[int] = None     # id of the model these were packed for (plan-cache generations), or None
 
 
 @dataclass
@@ -83,7 +84,7 @@ class SavedForward:
 
 class Engine:
     PLAN_CACHE_ENTRIES = 64            # eval launch plans kept (each owns its activation buffers), LRU
-    PLAN_CACHE_BYTES = 32 << 30        # ... and their total size
+    PLAN_CACHE_BYTES = 12 << 30        # ... and their total size (a 768 x 160-frame f32-class plan is 3.3 GiB)
 
     def __init__(self, lib: NativeLib):
         self.lib = lib
@@ -298,7 +299,7 @@ class Engine:
             invstd = torch.empty_like(mean)
         scale = torch.empty(c, dtype=torch.float32, device=dev)
         shift = torch.empty_like(scale)
-        if reducer is not None and reducer.world > 1:
+        if reducer is not None and reducer.active:
             sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
             self.lib.call("ds_partial_sum_f64", self._p(stats), stats.shape[0], self._p(sums), c, self._stream(stats))
             sums[2 * c] = float(count)
@@ -507,13 +508,19 @@ class Engine:
         if plan is not None:
             plans[key] = plan                           # most recently used last
         if plan is None:
-            # a plan pins its packed filters, folded BatchNorm and activation buffers: drop the plans of this
-            # shape that were built for an older weights generation, and bound the total
-            for k in [k for k in plans if k[:2] == key[:2] and k[4:] == key[4:] and k[2:4] != key[2:4]]:
+            # a plan pins its packed filters, folded BatchNorm and activation buffers: drop EVERY plan (any shape) that
+            # was built from an older generation of these same weights -- i.e. for the same precision and device but
+            # another packed-filter / folded-BatchNorm object of a model whose current objects are `pw` / `folded` --
+            # and bound the total.  (Plans of other live models keep their own generation: owners are tracked.)
+            owner = getattr(pw, "owner", None)
+            for k in [k for k, q in plans.items()
+                      if k[1] == key[1] and k[4] == key[4] and k[2:4] != key[2:4]
+                      and (q.get("owner") is None or q.get("owner") == owner)]:
                 del plans[k]
             plan = self._build_eval_plan(x, pw, folded, precision, masked=lengths is not None,
                                          low_latency=low_latency and precision == "f16")
             plan["bytes"] = sum(t.numel() * t.element_size() for t in plan["keep"] if isinstance(t, torch.Tensor))
+            plan["owner"] = owner
             # least recently used first (dicts keep insertion order): at most PLAN_CACHE_ENTRIES plans /
             # PLAN_CACHE_BYTES of activation buffers (class attributes; lower them on a GPU shared with other work)
             while plans and (len(plans) >= self.PLAN_CACHE_ENTRIES
@@ -743,15 +750,26 @@ class Engine:
             bn = bns[name]
             c = bn.weight.numel()
             per = []
-            if reducer is not None and reducer.world > 1:
+            if reducer is not None and reducer.active:
                 sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=dev)
-                for g in range(G):
-                    self.lib.call("ds_partial_sum_f64", self._p(sts[g]), sts[g].shape[0], self._p(sums[g]), c,
+                rows = sts[0].shape[0]
+                if all(st_.shape[0] == rows and st_.data_ptr() == sts[0].data_ptr() + g * rows * c * 8
+                       for g, st_ in enumerate(sts)):
+                    # the members' partial rows are consecutive slices of one launch's statistics: one kernel
+                    self.lib.call("ds_partial_sum_f64_group", self._p(sts[0]), rows, self._p(sums), count, c, G,
                                   self._stream(z))
-                sums[:, 2 * c] = float(count)
+                else:
+                    for g in range(G):
+                        self.lib.call("ds_partial_sum_f64", self._p(sts[g]), sts[g].shape[0], self._p(sums[g]), c,
+                                      self._stream(z))
+                    sums[:, 2 * c] = float(count)
                 reducer.all_reduce_sum_(sums)                     # all members of this layer in ONE collective
-                for g in range(G):
-                    mean, invstd, sc, sh = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+                # mean / invstd as rows of one [G][C] table each (as below): the backward pass stays grouped
+                mean_all = torch.empty((G, c), dtype=torch.float32, device=dev)
+                invstd_all = torch.empty((G, c), dtype=torch.float32, device=dev)
+                for g in range(G):                                # running statistics update in call order
+                    mean, invstd = mean_all[g], invstd_all[g]
+                    sc, sh = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(2))
                     self.lib.call("ds_bn_stats_from_sums_f32", self._p(sums[g]), 0, self._p(bn.weight.detach()),
                                   self._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM, self._p(bn.running_mean),
                                   self._p(bn.running_var), self._p(mean), self._p(invstd), self._p(sc), self._p(sh), c,
@@ -814,23 +832,15 @@ class Engine:
     def triplet_tail(self, a, p, n, margin: float, band: float = 0.0, amb_cap: int = 0) -> dict:
         """The loss side of one triplet step (model.py:27-33, train_triplet.py:251-262) in two launches:
         distances, then one scan giving the loss, the ordered filter, mean(d_n - d_p) and (amb_cap > 0) the
-        near-tie list.  The result of the latest call is kept, keyed on the three embedding buffers (held alive,
-        so their addresses cannot be recycled) and their version counters: `TripletMarginLoss.forward` and
-        `select_triplets` on the same embeddings share one computation."""
+        near-tie list.  Nothing is cached between calls: buffers that are rewritten through raw pointers (a HIP
+        graph's static output, a collective's destination) keep their address AND their torch version counter, so a
+        result keyed on those would be served for new contents."""
         for t, nm in ((a, "anchor"), (p, "positive"), (n, "negative")):
             self._check(t, nm)
         assert a.size() == p.size() == n.size()
-        stream_id = torch.cuda.current_stream(a.device).cuda_stream if a.is_cuda else 0
-        base = (a.data_ptr(), a._version, p.data_ptr(), p._version, n.data_ptr(), n._version, tuple(a.shape),
-                float(margin), stream_id)
-        key = base + (float(band), int(amb_cap))
-        memo = self.__dict__.get("_tail_memo")
-        if memo is not None and (memo["key"] == key or (amb_cap == 0 and memo["key"][:len(base)] == base)):
-            return memo                         # (a result with a near-tie list also serves a request without one)
         rows, d = a.shape
         dev = a.device
-        out = {"key": key, "hold": (a, p, n),
-               "d_p": torch.empty(rows, dtype=torch.float32, device=dev),
+        out = {"d_p": torch.empty(rows, dtype=torch.float32, device=dev),
                "d_n": torch.empty(rows, dtype=torch.float32, device=dev),
                "loss": torch.empty(1, dtype=torch.float32, device=dev),
                "idx": torch.empty(rows, dtype=torch.int64, device=dev),
@@ -842,7 +852,6 @@ class Engine:
                       self._p(out["d_p"]), self._p(out["d_n"]), self._p(out["loss"]), self._p(out["idx"]),
                       self._p(out["count"]), self._p(out["mean_diff"]), self._p(out["amb_idx"]),
                       self._p(out["amb_count"]), int(amb_cap), rows, d, self._stream(a))
-        self._tail_memo = out
         return out
 
     def triplet_margin(self, a, p, n, margin: float):

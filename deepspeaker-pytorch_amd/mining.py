@@ -17,18 +17,100 @@ from .model import _require_cuda, get_engine
 # a triplet whose |d_n - d_p - margin| is below that can land on the other side of the filter.  Every triplet
 # inside REFINE_BAND is therefore re-embedded through the split-operand bf16 path (f32-class, 5e-6) and decided
 # on those distances; outside the band the fp16 decision is already the reference's.
+#
+# How many triplets that is depends on the weights: ~1 per 256 at random init, but a triplet-trained network
+# concentrates d_n - d_p AT the margin.  The number of re-embedding slots is therefore not a constant:
+#   * `RefinePolicy` sizes the slots of call k from the near-tie counts of the calls before it (read back through
+#     pinned memory, polled without blocking), in powers of two from REFINE_CAP_MIN up to the whole batch (at which
+#     point the "refinement" simply is the f32-class forward of the batch);
+#   * if a call still finds more near ties than it had slots for, its `TripletSelection` re-embeds the WHOLE batch at
+#     f32-class precision before it hands out anything (`refined_all`), and the policy has learned the new level.
+# So what an accessor returns is always decided on f32-class distances inside the band, whatever the weights are.
 REFINE_BAND = 1.25e-3       # 2x the largest observed |error| of d_n - d_p (6 sigma)
-REFINE_CAP = 4              # near ties refined per call (expected ~1 per 256 random-init triplets; P(>4) = 0.3 %)
+REFINE_CAP_MIN = 32         # smallest slot count (96 re-embedded rows: latency-bound, costs what 12 rows cost)
+REFINE_CAP = REFINE_CAP_MIN
+
+
+def _pow2ceil(v: int) -> int:
+    return 1 << max(0, int(v) - 1).bit_length()
+
+
+class RefinePolicy:
+    """Host-side sizing of the near-tie refinement (one per model): slot count for the next call from the near-tie
+    counts observed so far.  Pure bookkeeping -- no device work, no synchronisation."""
+
+    HISTORY = 8
+    RING = 256                          # pinned read-back slots (one per call in flight)
+
+    def __init__(self, cap_min: int = REFINE_CAP_MIN):
+        self.cap_min = cap_min
+        self.seen = []                  # near-tie counts of the last HISTORY observed calls
+        self.pending = []               # read-back records of calls whose count has not been taken in yet
+        self.calls = self.overflows = 0
+        self.max_seen = 0
+        self._ring = None
+        self._next = 0
+
+    def observe(self, count: int):
+        self.seen = (self.seen + [int(count)])[-self.HISTORY:]
+        self.max_seen = max(self.max_seen, int(count))
+
+    def readback(self, amb_count: torch.Tensor) -> dict:
+        """Enqueue (on the current stream) the copy of a call's near-tie count into a pinned slot; the returned
+        record carries the event after which `value()` is valid."""
+        if self._ring is None:
+            self._ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+        slot = self._next % self.RING
+        self._next += 1
+        self._ring[slot:slot + 1].copy_(amb_count, non_blocking=True)
+        rec = {"slot": slot, "serial": self._next, "event": torch.cuda.current_stream(amb_count.device).record_event(),
+               "device": amb_count, "taken": False}
+        self.pending.append(rec)
+        return rec
+
+    def value(self, rec: dict) -> int:
+        """The count of a finished call (its event must have completed)."""
+        if self._next - rec["serial"] >= self.RING:     # the slot has been handed to a later call since
+            return int(rec["device"].item())
+        return int(self._ring[rec["slot"]])
+
+    def take(self, rec: dict) -> int:
+        v = self.value(rec)
+        if not rec["taken"]:
+            rec["taken"] = True
+            self.observe(v)
+        return v
+
+    def poll(self):
+        """Take in the counts of earlier calls whose device work has finished (never blocks)."""
+        still = []
+        for rec in self.pending:
+            if rec["taken"]:
+                continue
+            if rec["event"].query():
+                self.take(rec)
+            else:
+                still.append(rec)
+        self.pending = still[-(self.RING // 2):]
+
+    def cap_for(self, n_triplets: int) -> int:
+        """Slots for a batch of n_triplets: twice the recent maximum, a power of two, at least cap_min; once that
+        passes half the batch the whole batch is re-embedded (cap == n_triplets)."""
+        want = max(self.cap_min, _pow2ceil(2 * max(self.seen, default=0)))
+        return n_triplets if want > n_triplets // 2 else want
 
 
 class TripletSelection:
     """Result of `select_triplets`.  Everything stays on the device; reading `.indices` / `.n_selected` /
     `.n_correct` is what synchronises (the reference branches on the count, train_triplet.py:263).
 
-    When the fp16 forward's near ties were refined, the refinement ran on a side stream: every accessor first
-    makes the CURRENT stream wait for it (no host synchronisation), so results are ordered like any other tensor."""
+    When the fp16 forward's near ties were refined, the refinement ran on a side stream: every accessor first makes
+    the CURRENT stream wait for it.  Accessors of a refined selection also check (one pinned int, after the side
+    stream's event) that the refinement had a slot for every near tie; if not, the whole batch is re-embedded at
+    f32-class precision first (`refined_all`), so what they return never rests on an undecided fp16 comparison."""
 
-    def __init__(self, idx_full, count, d_p, d_n, mean_diff, loss=None, amb_count=None, amb_cap=0, ready=None):
+    def __init__(self, idx_full, count, d_p, d_n, mean_diff, loss=None, amb_count=None, amb_cap=0, ready=None,
+                 readback=None, fallback=None, policy=None):
         self._idx_full = idx_full    # int64 [N]; the first `count` entries are valid, ascending
         self._count = count          # int32 [1] on the device
         self._d_p = d_p              # [N]  (train_triplet.py:251)
@@ -38,9 +120,33 @@ class TripletSelection:
         self._amb_count = amb_count  # near ties found (int32 [1]) when the fp16 forward was refined, else None
         self.amb_cap = amb_cap
         self._ready = ready          # event on the refinement stream, or None
+        self._readback = readback    # RefinePolicy.readback record of amb_count (pinned slot + its event)
+        self._n_amb = None
+        self._fallback = fallback    # () -> dict of replacement tensors: the whole batch at f32-class precision
+        self._policy = policy
+        self._resolved = fallback is None or readback is None
+        self.refined_all = False     # True once the overflow action has replaced the results
+
+    def resolve(self):
+        """Make sure every near tie was decided at f32-class precision (see the class docstring).  Waits on the host
+        for the refinement's event -- the same wait any host-side read of the selection implies."""
+        if not self._resolved:
+            self._resolved = True
+            self._readback["event"].synchronize()
+            n_amb = self._n_amb = self._policy.take(self._readback)
+            if n_amb > self.amb_cap:
+                self._policy.overflows += 1
+                t = self._fallback()
+                self._idx_full, self._count, self._d_p, self._d_n = t["idx"], t["count"], t["d_p"], t["d_n"]
+                self._mean_diff, self._loss = t["mean_diff"], t["loss"]
+                self._ready = None                  # produced on the current stream
+                self.refined_all = True
+            self._fallback = None                   # drops the references to the input batches
+        return self
 
     def wait(self):
-        """Order the current stream after the refinement (idempotent per stream; free when nothing was refined)."""
+        """Order the current stream after the refinement (idempotent; free when nothing was refined)."""
+        self.resolve()
         if self._ready is not None:
             cur = torch.cuda.current_stream(self._idx_full.device)
             cur.wait_event(self._ready)
@@ -72,9 +178,20 @@ class TripletSelection:
         return self._idx_full.numel() - self.n_selected
 
     @property
+    def n_near_ties(self) -> int:
+        """near ties the fp16 forward left undecided (0 when nothing was refined); synchronises"""
+        if self._amb_count is None:
+            return 0
+        if self._n_amb is None:
+            self._readback["event"].synchronize()
+            self._n_amb = self._policy.take(self._readback)
+        return self._n_amb
+
+    @property
     def refine_overflow(self) -> bool:
-        """True if more near ties were found than the refinement had slots to re-embed (synchronises)."""
-        return self._amb_count is not None and int(self.amb_count.item()) > self.amb_cap
+        """True if more near ties were found than the refinement had slots for -- in which case the results were
+        replaced by the whole-batch f32-class ones (`refined_all`); synchronises."""
+        return self.n_near_ties > self.amb_cap
 
 
 _side_streams = {}
@@ -93,15 +210,24 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return s
 
 
+def refine_policy(model) -> RefinePolicy:
+    pol = getattr(model, "_refine_policy", None)
+    if pol is None:
+        pol = RefinePolicy()
+        object.__setattr__(model, "_refine_policy", pol)
+    return pol
+
+
 def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tensor, margin: float,
-                    model=None, inputs=None, band: float = REFINE_BAND, cap: int = REFINE_CAP,
+                    model=None, inputs=None, band: float = REFINE_BAND, cap: int = None,
                     side_stream: bool = True) -> TripletSelection:
     """train_triplet.py:251-262.  With `model` (a DeepSpeakerModel in eval mode, precision "f16") and `inputs`
     (the three input batches the embeddings came from), near ties are re-embedded at f32-class precision first,
-    which makes the selection the reference's (see REFINE_BAND).  No host synchronisation either way.  The
-    re-embedding is a small-batch forward (latency-bound: a few workgroups walking the whole contraction), so by
-    default it runs on a side stream next to whatever the caller enqueues next; `TripletSelection` orders its
-    consumers after it."""
+    which makes the selection the reference's (see REFINE_BAND).  The call itself never synchronises with the
+    host.  The re-embedding is a small-batch forward (latency-bound: a few workgroups walking the whole
+    contraction), so by default it runs on a side stream next to whatever the caller enqueues next;
+    `TripletSelection` orders its consumers after it.  `cap`: re-embedding slots; default: sized by the model's
+    `RefinePolicy` from the near-tie counts of earlier calls."""
     _require_cuda(out_a, "select_triplets")
     eng = get_engine()
     a, p, n = (t.detach().contiguous() for t in (out_a, out_p, out_n))
@@ -111,36 +237,60 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
         return TripletSelection(t["idx"], t["count"], t["d_p"], t["d_n"], t["mean_diff"], t["loss"])
     if inputs is None or len(inputs) != 3:
         raise ValueError("refinement needs inputs=(data_a, data_p, data_n), the batches behind the embeddings")
+    xs = []
+    for x in inputs:
+        _require_cuda(x, "select_triplets(inputs=...)")
+        if x.shape[0] != a.shape[0]:
+            raise ValueError("inputs must hold one utterance per embedding row")
+        xs.append(x.contiguous().float())           # ds_gather_rows_f32 copies float32 rows
+    n_trip = a.shape[0]
+    policy = refine_policy(model)
+    policy.poll()
+    policy.calls += 1
+    cap = policy.cap_for(n_trip) if cap is None else max(1, min(int(cap), n_trip))
+    whole = cap >= n_trip
     t = eng.triplet_tail(a, p, n, margin, band=band, amb_cap=cap)
     main = torch.cuda.current_stream(a.device)
     side = _side_stream(a.device) if side_stream else main
+    # the f32-class path's packed filters / folded BatchNorm are built HERE, on the caller's stream, if they do not
+    # exist yet: built inside the side-stream section, a later main-stream use would not be ordered after the packing
+    model._packed(with_bf16=True)
+    model._folded()
+
+    def embed_all():
+        """the overflow action / the whole-batch tier: every triplet decided on f32-class embeddings"""
+        e = model.embed_reference(torch.cat(xs))
+        return eng.triplet_tail(*(r.contiguous() for r in e.split(n_trip)), margin)
+
     if side_stream:
         side.wait_stream(main)
     with torch.cuda.stream(side):
         if side_stream:
-            for v in t.values():                    # the memoised main-stream buffers the side stream reads
+            for v in list(t.values()) + xs:         # main-stream memory the side stream reads
                 if isinstance(v, torch.Tensor):
                     v.record_stream(side)
-        rows = inputs[0][0].numel()
-        xr = torch.empty((3 * cap,) + tuple(inputs[0].shape[1:]), dtype=torch.float32, device=a.device)
-        st = eng._stream(a)
-        for k, x in enumerate(inputs):
-            _require_cuda(x, "select_triplets(inputs=...)")
-            x = x.contiguous()
-            if side_stream:
-                x.record_stream(side)               # keep the batch's memory until the side stream has read it
-            eng.lib.call("ds_gather_rows_f32", eng._p(x), eng._p(t["amb_idx"]), eng._p(xr[k * cap:(k + 1) * cap]), cap,
-                         rows, st)
-        e_ref = model.embed_reference(xr)
-        d_p, d_n = t["d_p"].clone(), t["d_n"].clone()       # the memoised fp16 distances stay what they are
-        eng.lib.call("ds_refine_distances_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
-                     eng._p(d_p), eng._p(d_n), a.shape[1], st)
-        idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
-        mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])
-        eng.lib.call("ds_triplet_scan_f32", eng._p(d_p), eng._p(d_n), float(margin), eng._p(loss), eng._p(idx),
-                     eng._p(count), eng._p(mean_diff), d_p.numel(), st)
-        ready = side.record_event() if side_stream else None
-    return TripletSelection(idx, count, d_p, d_n, mean_diff, loss, t["amb_count"], cap, ready)
+        rb = policy.readback(t["amb_count"])
+        if whole:
+            r = embed_all()
+            idx, count, d_p, d_n, mean_diff, loss = r["idx"], r["count"], r["d_p"], r["d_n"], r["mean_diff"], r["loss"]
+        else:
+            rows = xs[0][0].numel()
+            xr = torch.empty((3 * cap,) + tuple(xs[0].shape[1:]), dtype=torch.float32, device=a.device)
+            st = eng._stream(a)
+            for k, x in enumerate(xs):
+                eng.lib.call("ds_gather_rows_f32", eng._p(x), eng._p(t["amb_idx"]), eng._p(xr[k * cap:(k + 1) * cap]), cap,
+                             rows, st)
+            e_ref = model.embed_reference(xr)
+            d_p, d_n = t["d_p"].clone(), t["d_n"].clone()
+            eng.lib.call("ds_refine_distances_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
+                         eng._p(d_p), eng._p(d_n), a.shape[1], st)
+            idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
+            mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])
+            eng.lib.call("ds_triplet_scan_f32", eng._p(d_p), eng._p(d_n), float(margin), eng._p(loss), eng._p(idx),
+                         eng._p(count), eng._p(mean_diff), d_p.numel(), st)
+        ready = side.record_event()
+    return TripletSelection(idx, count, d_p, d_n, mean_diff, loss, t["amb_count"], cap, ready if side_stream else None,
+                            readback=rb, fallback=None if whole else embed_all, policy=policy)
 
 
 class MinedNegatives:
@@ -152,8 +302,10 @@ class MinedNegatives:
 
     def wait(self):
         if self._ready is not None:
-            torch.cuda.current_stream(self._idx.device).wait_event(self._ready)
-            self._ready = None
+            cur = torch.cuda.current_stream(self._idx.device)
+            cur.wait_event(self._ready)             # idempotent: the event stays for consumers on other streams
+            self._idx.record_stream(cur)            # allocated on the side stream, consumed on this one
+            self._dist.record_stream(cur)
         return self
 
     @property

@@ -498,6 +498,7 @@ class DeepSpeakerModel(nn.Module):
         if pw is None:
             pw = self._pack_cache[variant] = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad,
                                                                        with_bf16=with_bf16, with_f16=with_f16)
+            pw.owner = id(self)         # lets the engine's plan cache drop this model's older generations
         return pw
 
     def _folded(self):
@@ -513,7 +514,7 @@ class DeepSpeakerModel(nn.Module):
         return self._fold_cache
 
     # ---- data-parallel training (new capability; the reference is single-GPU) ----
-    def enable_data_parallel(self, process_group=None):
+    def enable_data_parallel(self, process_group=None, force: bool = False):
         """One process per GPU (torch.distributed backend "nccl" = RCCL).  From now on train-mode forwards and
         their backward use global-batch BatchNorm statistics (all-reduced over the ranks -- one collective per
         BatchNorm layer when the step goes through `forward_triplet`), and the backward pass all-reduces the
@@ -522,7 +523,9 @@ class DeepSpeakerModel(nn.Module):
         equals the single-process step on the concatenated batch; the classifier head (not part of the embedding
         network's autograd node) is reduced by `allreduce_gradients()`."""
         from .distributed import Reducer
-        self._reducer = Reducer(process_group)
+        # force: run the data-parallel launch sequence (collectives included) even in a group of one -- the way the
+        # path is exercised and timed on a single GPU (bench.py --force-collectives)
+        self._reducer = Reducer(process_group, force=force)
         return self._reducer
 
     def allreduce_gradients(self):
@@ -597,7 +600,8 @@ class DeepSpeakerModel(nn.Module):
         self.features = outs[2]
         return outs
 
-    def embed_variable_length(self, utterances, max_batch: int = 2048, pad_to: int = 16, max_frames: int = 262144):
+    def embed_variable_length(self, utterances, max_batch: int = 2048, pad_to: int = 16, max_frames: int = 262144,
+                              batch_step: int = 32):
         """Eval-mode embeddings of utterances of DIFFERENT lengths (BASELINE configs[4]: 100-800 frames; the
         temporal mean pool of model.py:207 accepts any T).  `utterances`: a sequence of [T_i, 64]
         (or [1, T_i, 64]) float tensors on the device, or a `data.FeatureStore` (the resident corpus: batches are
@@ -638,7 +642,9 @@ class DeepSpeakerModel(nn.Module):
             while (cnt < max_batch and i + cnt < n
                    and (cnt + 1) * (-(-sorted_lens[i + cnt] // pad_to) * pad_to) <= max_frames):
                 cnt += 1
-            idx = order[i:i + cnt]
+            if cnt >= 2 * batch_step and i + cnt < n:
+                cnt -= cnt % batch_step         # batch sizes in steps: (B, t_pad) launch plans repeat instead of being
+            idx = order[i:i + cnt]              # built (and their buffers pinned) once per batch
             i += cnt
             ln = lens[idx]
             t_pad = int(-(-int(ln.max()) // pad_to) * pad_to)

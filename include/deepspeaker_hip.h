@@ -273,6 +273,20 @@ int ds_bn_bwd_group_f32(const float *g1, const float *g2, const float *act, cons
                         const float *invstd, const float *gamma, float *gy, float *partial, float *coef,
                         float *member_sums, float *ggamma, float *gbeta, float *gz, long long n_pix, int C, int G,
                         void *stream);
+/* ds_bn_bwd_group_f32 split where data-parallel training exchanges the sums (new capability, the
+ * reference is single-GPU: train_triplet.py:97): local reductions of all G members -> sums [G][2C+1] float64
+ * ({sum gy, sum gy*xhat} per channel, then the member's pixel count) ... the caller all-reduces `sums` over RCCL ...
+ * -> coefficients, dgamma / dbeta (members added in order) and gz of all members.  2 + 3 launches per layer. */
+int ds_bn_bwd_group_reduce_f32(const float *g1, const float *g2, const float *act, const float *z,
+                               const float *mean, const float *invstd, float *gy, float *partial, double *sums,
+                               long long n_pix, int C, int G, void *stream);
+int ds_bn_bwd_group_apply_f32(const double *sums, const float *gy, const float *z, const float *mean,
+                              const float *invstd, const float *gamma, float *coef, float *member_sums,
+                              float *ggamma, float *gbeta, float *gz, long long n_pix, int C, int G, void *stream);
+/* forward counterpart: per-tile partial statistics of G members (n_partial rows of [C][2] each, consecutive)
+ * -> sums [G][2C+1] float64 (count in the last slot of each row) in one launch */
+int ds_partial_sum_f64_group(const float *partial, int n_partial, double *sums, long long count, int C, int G,
+                             void *stream);
 int ds_colsum_f32(const float *x, float *out, int R, int C, void *stream);
 
 /* ---- split forms for data-parallel training (one process per GPU): the caller all-reduces the

@@ -1,4 +1,5 @@
-"""Data-parallel logic on CPU: world_size 2 over gloo, kernels on the host emulator.
+"""Data-parallel logic on CPU: world_size 2 and 4 over gloo (and the forced data-parallel launch sequence with one
+rank), kernels on the host emulator.
 
 Asserts the property SURVEY 8(e) asks for: an N-rank step (sharded triplets, all-reduced BatchNorm
 statistics, all-gathered embeddings for cross-rank mining, all-reduced gradients) reproduces the
@@ -15,7 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_STAGES, B_GLOBAL, T = 2, 4, 16
+B_GLOBAL, T = 4, 16
 
 
 def _setup_paths():
@@ -24,7 +25,7 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _problem():
+def _problem(N_STAGES):
     _setup_paths()
     import deepspeaker_oracle as O
     sd = O.make_state_dict(seed=51, num_classes=4, n_stages=N_STAGES)
@@ -34,13 +35,14 @@ def _problem():
     return sd, xs, c1, c2
 
 
-def _run(rank, world, mine, reducer):
+def _run(rank, world, mine, reducer, N_STAGES=2):
     _setup_paths()
     from emul_util import emul_lib
     from deepspeaker_pytorch_amd.distributed import triplet_train_step
     from deepspeaker_pytorch_amd.engine import BNParams, Engine
-    sd, xs, c1, c2 = _problem()
+    sd, xs, c1, c2 = _problem(N_STAGES)
     eng = Engine(emul_lib())
+    eng.lib.trace = {}
     tsd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
     pw = eng.pack_weights(tsd, N_STAGES, with_dgrad=True)
     names = []
@@ -55,6 +57,9 @@ def _run(rank, world, mine, reducer):
     res = triplet_train_step(eng, pw, bns, {n: b.weight for n, b in bns.items()}, xa, xp, xn, 0.1, reducer,
                              labels=labels, mine=mine)
     out = {"loss": res.loss.numpy()}
+    for k, v in eng.lib.trace.items():
+        out["calls/" + k] = np.array(v)
+    eng.lib.trace = None
     if reducer is not None:
         out["n_all_reduce"] = np.array(reducer.n_all_reduce)
     for k, v in res.grads.items():
@@ -67,14 +72,14 @@ def _run(rank, world, mine, reducer):
     return out
 
 
-def _worker(rank, world, port, mine, outdir):
+def _worker(rank, world, port, mine, outdir, n_stages=2, force=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _setup_paths()
     from deepspeaker_pytorch_amd.distributed import Reducer
-    out = _run(rank, world, mine, Reducer())
+    out = _run(rank, world, mine, Reducer(force=force), n_stages)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -88,11 +93,8 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("mine", [False, True])
-def test_two_ranks_reproduce_single_process(tmp_path, mine):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), mine, str(tmp_path)), nprocs=world, join=True)
-    ref = _run(0, 1, mine, None)                      # the whole batch in one process, no collectives
+def _check_against_single_process(tmp_path, world, mine, n_stages):
+    ref = _run(0, 1, mine, None, n_stages)            # the whole batch in one process, no collectives
     ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     n_loc = B_GLOBAL // world
     for r, got in enumerate(ranks):
@@ -107,12 +109,43 @@ def test_two_ranks_reproduce_single_process(tmp_path, mine):
                 np.testing.assert_allclose(got[k], v[r * n_loc:(r + 1) * n_loc], rtol=2e-5, atol=2e-5)
     # collective-lean: per BatchNorm LAYER one statistics all-reduce forward and one backward (all three members
     # together), one per gradient bucket (stages + fc), one for the loss -- not one per BatchNorm call
-    assert int(ranks[0]["n_all_reduce"]) == 2 * 3 * N_STAGES + (N_STAGES + 1) + 1
-    # both ranks hold identical global gradients
+    assert int(ranks[0]["n_all_reduce"]) == 2 * 3 * n_stages + (n_stages + 1) + 1
+    # the data-parallel step is the SAME grouped launch sequence as the single-process step, split at the all-reduce:
+    # one grouped reduce + one grouped apply per BatchNorm layer, no per-member fallback launches
+    assert int(ranks[0]["calls/ds_bn_bwd_group_reduce_f32"]) == 3 * n_stages
+    assert int(ranks[0]["calls/ds_bn_bwd_group_apply_f32"]) == 3 * n_stages
+    assert "calls/ds_bn_bwd_reduce_f32" not in ranks[0].files and "calls/ds_bn_bwd_f32" not in ranks[0].files
+    assert int(ref["calls/ds_bn_bwd_group_f32"]) == 3 * n_stages
+    # all ranks hold identical global gradients
     for k in ranks[0].files:
         if k.startswith("grad/"):
-            np.testing.assert_array_equal(ranks[0][k], ranks[1][k])
+            for other in ranks[1:]:
+                np.testing.assert_array_equal(ranks[0][k], other[k])
     assert float(ref["loss"]) > 0
+
+
+@pytest.mark.parametrize("mine", [False, True])
+def test_two_ranks_reproduce_single_process(tmp_path, mine):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), mine, str(tmp_path)), nprocs=world, join=True)
+    _check_against_single_process(tmp_path, world, mine, 2)
+
+
+def test_four_ranks_full_model_reproduce_single_process(tmp_path):
+    """world_size 4, the 4-stage network, one triplet per rank, with cross-rank mining"""
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path), 4), nprocs=world, join=True)
+    _check_against_single_process(tmp_path, world, True, 4)
+
+
+@pytest.mark.parametrize("mine", [False, True])
+def test_forced_data_parallel_sequence_with_one_rank(tmp_path, mine):
+    """Reducer(force=True) in a group of ONE takes every data-parallel branch (float64 sums -> all-reduce ->
+    *_from_sums kernels, bucket all-reduces from inside the backward pass, all-gather / reduce-scatter of the mined
+    candidates) and must reproduce the plain step: what `bench.py --train --force-collectives` and the GPU test run on
+    RCCL."""
+    mp.spawn(_worker, args=(1, _free_port(), mine, str(tmp_path), 2, True), nprocs=1, join=True)
+    _check_against_single_process(tmp_path, 1, mine, 2)
 
 
 def test_gradient_bucketing_names():

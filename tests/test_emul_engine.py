@@ -107,8 +107,14 @@ def test_triplet_tail_scan_and_refinement(N, cap):
     k = min(cap, len(amb_ref))
     np.testing.assert_array_equal(t["amb_idx"].numpy()[:k], amb_ref[:k])
     assert (t["amb_idx"].numpy()[k:] == 0).all()
-    # same call again: served from the memo (the same buffers come back)
-    assert eng.triplet_tail(*t["hold"], margin, band=band, amb_cap=cap) is t
+    # a buffer rewritten IN PLACE through its raw pointer (as a HIP graph's static output or a collective's
+    # destination is: same address, same torch version counter) must give the new contents' result
+    ta, tp, tn = (torch.from_numpy(v.copy()) for v in (a, p, n))
+    t1 = eng.triplet_tail(ta, tp, tn, margin)
+    ta.numpy()[:] = n                  # numpy view: bypasses torch's version counter
+    t2 = eng.triplet_tail(ta, tp, tn, margin)
+    ref_loss2, _, _ = O.triplet_margin_loss(n, p, n, margin)
+    assert abs(float(t2["loss"]) - float(ref_loss2)) < 1e-6 and abs(float(t1["loss"]) - float(ref_loss)) < 1e-6
     # refinement: "re-embedded" rows for the cap slots (anchors | positives | negatives)
     e_ref = rs.randn(3 * cap, D).astype(np.float32)
     dp2, dn2 = t["d_p"].clone(), t["d_n"].clone()

@@ -42,5 +42,11 @@ def test_bench_collective_path_with_one_rank():
 
 
 def test_bench_train_mode_collective_path():
+    """The training step through every data-parallel branch (RCCL, one rank) next to the plain step: the same launch
+    sequence split at its all-reduces -- 12 BatchNorm layers x 2 directions + 5 gradient buckets + the loss -- and a
+    step time close to the plain one (the collectives of a group of one are latency only)."""
+    plain = run_bench("--train", port=29545)
     d = run_bench("--train", "--force-collectives", port=29544)
     assert d["unit"] == "utterances/s" and d["value"] > 1e3 and d["dtype"] == "bf16x3"
+    assert d["all_reduce_per_step"] == 2 * 12 + 5 + 1, d["all_reduce_per_step"]
+    assert d["ms_per_step"] < 1.10 * plain["ms_per_step"], (d["ms_per_step"], plain["ms_per_step"])

@@ -98,6 +98,96 @@ def test_f16_refinement_decides_planted_near_ties(cfg1):
     print("\\nunrefined fp16 selections that differed from the f32-class one:", flips_seen, "of 4")
 
 
+def _planted(x, m3, n_plant, target):
+    """The cfg1 batch with the negatives of the first n_plant triplets replaced by slightly perturbed copies of their
+    positives, the perturbation scaled so that median |d_n - d_p| of those triplets is `target` (f32-class forward):
+    d_n - d_p concentrated at one value, as a triplet-trained network concentrates it at the margin."""
+    from deepspeaker_pytorch_amd.mining import select_triplets
+    xa, xp, xn = x[:256].clone(), x[256:512].clone(), x[512:].clone()
+    noise = torch.randn(n_plant, 1, 160, 64, generator=torch.Generator(device="cpu").manual_seed(77)).cuda()
+    delta = 1e-3
+    for _ in range(4):
+        xn[:n_plant] = xp[:n_plant] + delta * noise
+        with torch.no_grad():
+            e = m3(torch.cat([xa, xp, xn])).clone()
+        d = select_triplets(e[:256], e[256:512], e[512:], 0.0)
+        diff = (d.d_n - d.d_p).cpu().numpy()
+        med = float(np.median(np.abs(diff[:n_plant] - np.median(diff[:n_plant]))))
+        if 0.8 * target < med < 1.25 * target:
+            break
+        delta *= target / max(med, 1e-12)
+    return (xa, xp, xn), diff, float(np.median(diff[:n_plant]))
+
+
+def test_f16_refinement_default_slots_many_near_ties(cfg1):
+    """the DEFAULT slot count with >= 16 planted near ties -- refined selection == f32-class
+    selection, no overflow."""
+    from deepspeaker_pytorch_amd.mining import REFINE_CAP_MIN, select_triplets
+    g, sd, x = cfg1
+    m16, m3 = build(sd, "f16"), build(sd, "bf16x3")
+    (xa, xp, xn), diff3, margin = _planted(x, m3, 24, 0.6e-3)
+    with torch.no_grad():
+        e16 = m16(torch.cat([xa, xp, xn])).clone()
+        fine = select_triplets(e16[:256], e16[256:512], e16[512:], margin, model=m16, inputs=(xa, xp, xn))
+    want = np.where(diff3 < np.float32(margin))[0]
+    print(f"\nplanted 24: near ties found {fine.n_near_ties}, slots {fine.amb_cap}, selected {len(want)} of 256")
+    assert fine.amb_cap == REFINE_CAP_MIN and 16 <= fine.n_near_ties <= REFINE_CAP_MIN
+    assert not fine.refine_overflow and not fine.refined_all
+    np.testing.assert_array_equal(fine.indices.cpu().numpy(), want)
+
+
+def test_f16_refinement_margin_concentrated_batch(cfg1):
+    """d_n - d_p concentrated AT the margin for most of the batch (what triplet training produces).
+    The first call finds far more near ties than it has slots for: the selection then re-embeds the whole batch at
+    f32-class precision before anything is read (`refined_all`), and the policy sizes the next calls from what it saw
+    -- those decide every near tie in their own slots, no overflow.  Every selection equals the f32-class one."""
+    from deepspeaker_pytorch_amd.mining import REFINE_CAP_MIN, refine_policy, select_triplets
+    g, sd, x = cfg1
+    m16, m3 = build(sd, "f16"), build(sd, "bf16x3")
+    (xa, xp, xn), diff3, margin = _planted(x, m3, 200, 0.6e-3)
+    want = np.where(diff3 < np.float32(margin))[0]
+    with torch.no_grad():
+        e16 = m16(torch.cat([xa, xp, xn])).clone()
+        plain = select_triplets(e16[:256], e16[256:512], e16[512:], margin)
+        first = select_triplets(e16[:256], e16[256:512], e16[512:], margin, model=m16, inputs=(xa, xp, xn))
+        assert first.amb_cap == REFINE_CAP_MIN
+        np.testing.assert_array_equal(first.indices.cpu().numpy(), want)       # resolves the overflow first
+        assert first.refine_overflow and first.refined_all and first.n_near_ties > 64
+        second = select_triplets(e16[:256], e16[256:512], e16[512:], margin, model=m16, inputs=(xa, xp, xn))
+        assert second.amb_cap >= second.n_near_ties and not second.refine_overflow and not second.refined_all
+        np.testing.assert_array_equal(second.indices.cpu().numpy(), want)
+    pol = refine_policy(m16)
+    flips = int(len(plain.indices) != len(want) or (plain.indices.cpu().numpy() != want).any())
+    print(f"\nconcentrated batch: near ties {first.n_near_ties} of 256 (slots {first.amb_cap} -> {second.amb_cap}), "
+          f"policy calls {pol.calls} overflows {pol.overflows}; unrefined fp16 selection differs: {bool(flips)}")
+    assert pol.overflows == 1 and abs(float(second.loss) - float(first.loss)) < 1e-6
+
+
+def test_selection_and_loss_on_a_graphed_output(cfg1):
+    """a HIP graph's static output keeps its address and its torch version counter across replays; loss and
+    selection of the second batch must be the second batch's (nothing may be served from a result keyed on identity)."""
+    from deepspeaker_pytorch_amd.mining import select_triplets
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss
+    g, sd, x = cfg1
+    m = build(sd, "f32")
+    x1, x2 = x[:48].contiguous(), x[48:96].contiguous()
+    with torch.no_grad():
+        want = []
+        for xb in (x1, x2):
+            e = m(xb).clone()
+            want.append((float(TripletMarginLoss(0.1).forward(e[:16], e[16:32], e[32:])),
+                         select_triplets(e[:16], e[16:32], e[32:], 0.1).d_n.cpu().numpy().copy()))
+        graphed = m.graphed(x1)
+        got = []
+        for xb in (x1, x2):
+            e = graphed(xb)                             # the SAME tensor object both times
+            a, p, n = e[:16], e[16:32], e[32:]
+            got.append((float(TripletMarginLoss(0.1).forward(a, p, n)), select_triplets(a, p, n, 0.1).d_n.cpu().numpy().copy()))
+    assert abs(want[0][0] - want[1][0]) > 1e-6           # the two batches do differ
+    for (wl, wd), (gl, gd) in zip(want, got):
+        assert abs(wl - gl) < 1e-6 and np.abs(wd - gd).max() < 1e-5
+
+
 def test_f16_forward_properties(cfg1):
     g, sd, x = cfg1
     m = build(sd, "f16")

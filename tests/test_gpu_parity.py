@@ -401,27 +401,50 @@ def test_mining_kernel_vs_oracle(dev):
 
 
 def test_data_parallel_world1_nccl(dev):
-    """The RCCL code path with a single rank: enable_data_parallel must not change the step."""
+    """Every data-parallel branch on RCCL with a single rank (Reducer(force=True)): float64 sums -> all-reduce ->
+    *_from_sums kernels in the forward, the grouped BatchNorm backward split at its all-reduce, the gradient buckets
+    reduced from inside the backward pass on the filter-gradient stream.  The step must equal the plain step and issue
+    exactly the collectives an N-rank job issues."""
     import torch.distributed as dist
-    from deepspeaker_pytorch_amd.model import TripletMarginLoss
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss, get_engine
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     sd = O.make_state_dict(seed=31, num_classes=16)
     xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=4)).cuda() for i in range(3)]
-    grads = []
-    for dp in (False, True):
-        m = build_model(sd).train()
-        if dp:
-            m.enable_data_parallel()
-        loss = TripletMarginLoss(0.1).forward(m(xs[0]), m(xs[1]), m(xs[2]))
-        loss.backward()
-        if dp:
-            m.allreduce_gradients()
-        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
-    for n in grads[0]:
-        assert rel_err(grads[1][n].cpu().numpy(), grads[0][n].cpu().numpy()) < 1e-5, n
+    lib = get_engine().lib
+    for grouped in (False, True):
+        grads, losses, stats = [], [], []
+        for dp in (False, True):
+            m = build_model(sd).train()
+            red = m.enable_data_parallel(force=True) if dp else None
+            assert red is None or (red.active and red.world == 1)
+            lib.trace = {}
+            outs = m.forward_triplet(*xs) if grouped else (m(xs[0]), m(xs[1]), m(xs[2]))
+            loss = TripletMarginLoss(0.1).forward(*outs)
+            loss.backward()
+            trace, lib.trace = lib.trace, None
+            if dp:
+                m.allreduce_gradients()
+                # 12 BatchNorm layers x (forward + backward) x (1 grouped | 3 separate forwards) + 5 gradient buckets
+                # (per backward pass: 1 grouped | 3)
+                k = 1 if grouped else 3
+                assert red.n_all_reduce == k * (2 * 12 + 5), red.n_all_reduce
+                if grouped:     # the grouped launch sequence, split at the all-reduce -- no per-member fallback
+                    assert trace.get("ds_bn_bwd_group_reduce_f32") == 12 and trace.get("ds_bn_bwd_group_apply_f32") == 12
+                    assert "ds_bn_bwd_reduce_f32" not in trace
+                    assert trace.get("ds_partial_sum_f64_group", 0) + trace.get("ds_partial_sum_f64", 0) // 3 == 12
+                else:
+                    assert trace.get("ds_bn_bwd_reduce_f32") == 36 and trace.get("ds_bn_stats_from_sums_f32") == 36
+            grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+            losses.append(float(loss))
+            stats.append({k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+        assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0]))
+        for n in grads[0]:
+            assert rel_err(grads[1][n].cpu().numpy(), grads[0][n].cpu().numpy()) < 1e-5, (grouped, n)
+        for k in stats[0]:
+            assert rel_err(stats[1][k].cpu().numpy(), stats[0][k].cpu().numpy()) < 1e-6, (grouped, k)
     # the differentiable all-gather of the mining step and its adjoint, on RCCL's own kernels
     # (all_gather_into_tensor / reduce_scatter_tensor; gloo in the CPU tests takes a fall-back for the latter)
     from deepspeaker_pytorch_amd.distributed import AllGatherRows, Reducer

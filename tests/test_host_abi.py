@@ -94,3 +94,18 @@ def test_synthetic_state_dict_is_the_oracle_stream():
         a, b = O.make_state_dict(seed=seed, num_classes=ncls, n_stages=ns), synthetic_state_dict(seed, ncls, ns)
         assert set(a) == set(b)
         assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_refine_policy_sizes_slots_from_history():
+    """mining.RefinePolicy (host bookkeeping of the fp16 near-tie refinement): power-of-two slot counts from the recent
+    near-tie counts, whole batch once they pass half of it, decaying with the history window."""
+    from deepspeaker_pytorch_amd.mining import REFINE_CAP_MIN, RefinePolicy
+    pol = RefinePolicy()
+    assert pol.cap_for(256) == REFINE_CAP_MIN and pol.cap_for(8) == 8           # a batch smaller than the minimum
+    for seen, want in ((3, 32), (16, 32), (17, 64), (40, 128), (70, 256), (300, 256)):
+        pol.observe(seen)
+        assert pol.cap_for(256) == want, (seen, pol.cap_for(256))
+    assert pol.max_seen == 300
+    for _ in range(RefinePolicy.HISTORY):                                       # the large counts age out
+        pol.observe(1)
+    assert pol.cap_for(256) == REFINE_CAP_MIN
