@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refine-slots", type=int, default=0,
+                    help="smallest number of near-tie re-embedding slots of the fp16 path (0: the library default, "
+                         "mining.REFINE_CAP_MIN); the policy grows them from observed counts either way")
     ap.add_argument("--repeats", type=int, default=3,
                     help="after the contract's timed region (W warm-up + K steps -> `value`), time the same K-step region "
                          "this many more times and report median / min / max ms per step (box-to-box and DVFS spread)")
@@ -142,7 +145,7 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)            # "nccl" is RCCL on ROCm
 
-    from deepspeaker_pytorch_amd.mining import (REFINE_BAND, mine_semihard_negatives, select_triplets,
+    from deepspeaker_pytorch_amd.mining import (REFINE_BAND, mine_semihard_negatives, refine_policy, select_triplets,
                                                 side_stream as side_stream_of)
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss, get_engine
     from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
@@ -230,6 +233,8 @@ def main():
 
     def measure(precision, steps, warmup, repeats=0):
         model = load_model(precision).eval()
+        if args.refine_slots > 0:
+            refine_policy(model).cap_min = refine_policy(model).cap_start = args.refine_slots
         last_mined = [[None, None] for _ in range(n_slots)]
         parity = [0] * n_slots
         sels = []

@@ -219,7 +219,7 @@ class _GradBuckets:
 
     def done(self, bucket: int):
         if self.reducer is not None:
-            self.work.append(self.reducer.all_reduce_sum_(self.flat[bucket], async_op=True))
+            self.work.append(self.reducer.all_reduce_sum_(self.flat[bucket], async_op=True, gradients=True))
 
     def finish(self):
         for h in self.work:

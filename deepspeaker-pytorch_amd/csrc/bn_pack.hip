@@ -488,26 +488,14 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float *x, float *out,
 // ---- split forms for data-parallel training: local sums -> (all-reduce by the caller) -> finalize ----
 namespace {
 
-// sums[c][2] (double) = sum over the partial rows; one workgroup per 32 channels
+// sums[c][2] (double) = sum over the partial rows, folded like the single-process finalize kernels fold them
+// (fold_partials: FOLD_C channels x FOLD_R row lanes per workgroup).  One workgroup per 32 channels with 8 row lanes
+// left 6..48 workgroups walking up to 2048 rows each: 66 us per BatchNorm layer of the data-parallel step.
 __global__ void __launch_bounds__(256) partial_sum_f64_kernel(const float *partial, int n_partial, double *sums, int C) {
-    double *red = (double *)ds_dynamic_lds();
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rl; r < n_partial; r += 8) {
-            s1 += (double)partial[((size_t)r * C + c) * 2 + 0];
-            s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
-        }
-    red[(rl * 32 + cl) * 2 + 0] = s1;
-    red[(rl * 32 + cl) * 2 + 1] = s2;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < 8; ++k) {
-            t1 += red[(k * 32 + cl) * 2 + 0];
-            t2 += red[(k * 32 + cl) * 2 + 1];
-        }
+    double *red = (double *)ds_dynamic_lds();              // [FOLD_R][FOLD_C][2]
+    int c;
+    double t1, t2;
+    if (fold_partials(partial, n_partial, C, red, c, t1, t2)) {
         sums[c * 2 + 0] = t1;
         sums[c * 2 + 1] = t2;
     }
@@ -555,31 +543,17 @@ __global__ void __launch_bounds__(256) bn_bwd_from_sums_kernel(const double *sum
 // all-reduce).
 __global__ void __launch_bounds__(256) partial_sum_f64_group_kernel(const float *partial, int n_partial, double *sums,
                                                                     double count, int C, int n_cgroups) {
-    double *red = (double *)ds_dynamic_lds();
+    double *red = (double *)ds_dynamic_lds();              // [FOLD_R][FOLD_C][2]
     const int member = blockIdx.x / n_cgroups, cgroup = blockIdx.x - member * n_cgroups;
     partial += (size_t)member * n_partial * C * 2;
     sums += (size_t)member * (2 * C + 1);
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = cgroup * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rl; r < n_partial; r += 8) {
-            s1 += (double)partial[((size_t)r * C + c) * 2 + 0];
-            s2 += (double)partial[((size_t)r * C + c) * 2 + 1];
-        }
-    red[(rl * 32 + cl) * 2 + 0] = s1;
-    red[(rl * 32 + cl) * 2 + 1] = s2;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < 8; ++k) {
-            t1 += red[(k * 32 + cl) * 2 + 0];
-            t2 += red[(k * 32 + cl) * 2 + 1];
-        }
+    if (cgroup == 0 && threadIdx.x == 0) sums[2 * C] = count;
+    int c;
+    double t1, t2;
+    if (fold_partials(partial, n_partial, C, red, c, t1, t2, cgroup)) {
         sums[c * 2 + 0] = t1;
         sums[c * 2 + 1] = t2;
     }
-    if (cgroup == 0 && threadIdx.x == 0) sums[2 * C] = count;
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_from_sums_group_kernel(const double *sums, const float *gamma,
@@ -605,7 +579,7 @@ __global__ void __launch_bounds__(256) bn_bwd_from_sums_group_kernel(const doubl
 extern "C" int ds_partial_sum_f64(const float *partial, int n_partial, double *sums, int C, void *stream) {
     DS_REQUIRE(partial && sums, DS_ERR_NULL);
     DS_REQUIRE(n_partial > 0 && C > 0, DS_ERR_BAD_SHAPE);
-    DS_LAUNCH(partial_sum_f64_kernel, ds_ceil_div(C, 32), 256, 8 * 32 * 2 * sizeof(double), stream, partial, n_partial,
+    DS_LAUNCH(partial_sum_f64_kernel, ds_ceil_div(C, FOLD_C), 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream, partial, n_partial,
               sums, C);
     return ds_last_launch_error();
 }
@@ -742,8 +716,8 @@ extern "C" int ds_bn_bwd_group_reduce_f32(const float *g1, const float *g2, cons
               partial, n_pix, C, ppb, blocks);
     int rc = ds_last_launch_error();
     if (rc) return rc;
-    DS_LAUNCH(partial_sum_f64_group_kernel, ds_ceil_div(C, 32) * G, 256, 8 * 32 * 2 * sizeof(double), stream,
-              (const float *)partial, blocks, sums, (double)n_pix, C, ds_ceil_div(C, 32));
+    DS_LAUNCH(partial_sum_f64_group_kernel, ds_ceil_div(C, FOLD_C) * G, 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream,
+              (const float *)partial, blocks, sums, (double)n_pix, C, ds_ceil_div(C, FOLD_C));
     return ds_last_launch_error();
 }
 
@@ -776,8 +750,8 @@ extern "C" int ds_partial_sum_f64_group(const float *partial, int n_partial, dou
                                         void *stream) {
     DS_REQUIRE(partial && sums, DS_ERR_NULL);
     DS_REQUIRE(n_partial > 0 && C > 0 && G > 0 && G <= 64 && count > 0, DS_ERR_BAD_SHAPE);
-    DS_LAUNCH(partial_sum_f64_group_kernel, ds_ceil_div(C, 32) * G, 256, 8 * 32 * 2 * sizeof(double), stream, partial,
-              n_partial, sums, (double)count, C, ds_ceil_div(C, 32));
+    DS_LAUNCH(partial_sum_f64_group_kernel, ds_ceil_div(C, FOLD_C) * G, 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream, partial,
+              n_partial, sums, (double)count, C, ds_ceil_div(C, FOLD_C));
     return ds_last_launch_error();
 }
 

@@ -713,7 +713,14 @@ class Engine:
                 raise ValueError("members must be equally shaped [B,1,T,F] batches")
         Bm, _, T, F = xs[0].shape
         B = G * Bm
-        x = torch.cat(xs)
+        # members that already are consecutive slices of one buffer (a resident batch split into a / p / n) are used
+        # in place; otherwise they are concatenated
+        nbytes = xs[0].numel() * xs[0].element_size()
+        if all(x.is_contiguous() and x.data_ptr() == xs[0].data_ptr() + g * nbytes
+               and x.untyped_storage().data_ptr() == xs[0].untyped_storage().data_ptr() for g, x in enumerate(xs)):
+            x = torch.as_strided(xs[0], (B, 1, T, F), xs[0].stride())
+        else:
+            x = torch.cat(xs)
         x3 = precision == "bf16x3"
         if x3 and pw.stages[0].l_conv1_bf16 is None:
             raise ValueError("pack_weights(..., with_bf16=True) is required for bf16x3")

@@ -19,16 +19,20 @@ from .model import _require_cuda, get_engine
 # on those distances; outside the band the fp16 decision is already the reference's.
 #
 # How many triplets that is depends on the weights: ~1 per 256 at random init, but a triplet-trained network
-# concentrates d_n - d_p AT the margin.  The number of re-embedding slots is therefore not a constant:
+# concentrates d_n - d_p AT the margin.  And a slot is not free: a re-embedded triplet is 3 utterances x 3 MFMAs per
+# product = 9 fp16 utterance-forwards of matrix work (measured on the 768-utterance step: 4 slots +0 %, 8 +4 %,
+# 16 +10 %, 32 +24 %).  The number of re-embedding slots is therefore neither a constant nor generous by default:
 #   * `RefinePolicy` sizes the slots of call k from the near-tie counts of the calls before it (read back through
-#     pinned memory, polled without blocking), in powers of two from REFINE_CAP_MIN up to the whole batch (at which
-#     point the "refinement" simply is the f32-class forward of the batch);
+#     pinned memory, polled without blocking): REFINE_CAP_START until it has seen a few calls, then twice the recent
+#     maximum in powers of two, from REFINE_CAP_MIN up to the whole batch (at which point the "refinement" simply is
+#     the f32-class forward of the batch);
 #   * if a call still finds more near ties than it had slots for, its `TripletSelection` re-embeds the WHOLE batch at
 #     f32-class precision before it hands out anything (`refined_all`), and the policy has learned the new level.
 # So what an accessor returns is always decided on f32-class distances inside the band, whatever the weights are.
 REFINE_BAND = 1.25e-3       # 2x the largest observed |error| of d_n - d_p (6 sigma)
-REFINE_CAP_MIN = 32         # smallest slot count (96 re-embedded rows: latency-bound, costs what 12 rows cost)
-REFINE_CAP = REFINE_CAP_MIN
+REFINE_CAP_START = 32       # slots while the policy has no history (96 re-embedded rows)
+REFINE_CAP_MIN = 4          # smallest slot count once it has
+REFINE_CAP = REFINE_CAP_START
 
 
 def _pow2ceil(v: int) -> int:
@@ -42,8 +46,11 @@ class RefinePolicy:
     HISTORY = 8
     RING = 256                          # pinned read-back slots (one per call in flight)
 
-    def __init__(self, cap_min: int = REFINE_CAP_MIN):
-        self.cap_min = cap_min
+    WARM = 4                            # observed calls before the slot count may drop below cap_start
+
+    def __init__(self, cap_min: int = REFINE_CAP_MIN, cap_start: int = REFINE_CAP_START):
+        self.cap_min, self.cap_start = cap_min, max(cap_min, cap_start)
+        self.n_seen = 0
         self.seen = []                  # near-tie counts of the last HISTORY observed calls
         self.pending = []               # read-back records of calls whose count has not been taken in yet
         self.calls = self.overflows = 0
@@ -54,6 +61,7 @@ class RefinePolicy:
     def observe(self, count: int):
         self.seen = (self.seen + [int(count)])[-self.HISTORY:]
         self.max_seen = max(self.max_seen, int(count))
+        self.n_seen += 1
 
     def readback(self, amb_count: torch.Tensor) -> dict:
         """Enqueue (on the current stream) the copy of a call's near-tie count into a pinned slot; the returned
@@ -94,9 +102,11 @@ class RefinePolicy:
         self.pending = still[-(self.RING // 2):]
 
     def cap_for(self, n_triplets: int) -> int:
-        """Slots for a batch of n_triplets: twice the recent maximum, a power of two, at least cap_min; once that
-        passes half the batch the whole batch is re-embedded (cap == n_triplets)."""
-        want = max(self.cap_min, _pow2ceil(2 * max(self.seen, default=0)))
+        """Slots for a batch of n_triplets: twice the recent maximum, a power of two, at least cap_min (cap_start
+        while fewer than WARM calls have been observed); once that passes half the batch the whole batch is
+        re-embedded (cap == n_triplets)."""
+        floor = self.cap_min if self.n_seen >= self.WARM else self.cap_start
+        want = max(floor, _pow2ceil(2 * max(self.seen, default=0)))
         return n_triplets if want > n_triplets // 2 else want
 
 

@@ -333,8 +333,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
         pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"))
         e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer, precision=prec)
         ctx.precision = prec
-        for bn in model._bn_modules():
-            bn.num_batches_tracked += 1                             # nn.BatchNorm2d.train() bookkeeping
+        model._bump_batches_tracked(1)        # nn.BatchNorm2d.train() bookkeeping, one launch
         model._stat_updates += 1
         ctx.saved_forward = saved
         ctx.model = model
@@ -364,8 +363,7 @@ class _ResCNNTripletFn(torch.autograd.Function):
         pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"))
         embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
                                               precision=prec)
-        for bn in model._bn_modules():
-            bn.num_batches_tracked += 3                             # three statistic updates, as three calls make
+        model._bump_batches_tracked(3)        # nn.BatchNorm2d.train() bookkeeping, one launch
         model._stat_updates += 3
         ctx.precision, ctx.saved_forward, ctx.model, ctx.pw = prec, saved, model, pw
         ctx.param_names = model._param_names
@@ -465,6 +463,21 @@ class DeepSpeakerModel(nn.Module):
             out += [getattr(self.model, f"bn{i}"), blk.bn1, blk.bn2]
         return out
 
+    def _bump_batches_tracked(self, n: int):
+        """nn.BatchNorm2d.train() bookkeeping for `n` forwards: every BatchNorm layer's batch counter goes up by n in
+        ONE launch -- the twelve counters are kept as views of one int64 tensor (re-established whenever .to() /
+        .cuda() has given the modules separate buffers again; load_state_dict copies in place and keeps the views)."""
+        mods = self._bn_modules()
+        flat = getattr(self, "_nbt_flat", None)
+        first = mods[0].num_batches_tracked
+        if (flat is None or flat.device != first.device or first.data_ptr() != flat.data_ptr()
+                or mods[-1].num_batches_tracked.data_ptr() != flat.data_ptr() + 8 * (len(mods) - 1)):
+            flat = torch.stack([m.num_batches_tracked.reshape(()) for m in mods]).to(torch.int64)
+            for i, m in enumerate(mods):
+                m._buffers["num_batches_tracked"] = flat[i]
+            object.__setattr__(self, "_nbt_flat", flat)
+        flat.add_(n)
+
     def _bn_names(self):
         out = []
         for i in range(1, self.n_stages + 1):
@@ -563,8 +576,7 @@ class DeepSpeakerModel(nn.Module):
             else:
                 e, _ = get_engine().forward_train(x, self._packed(), self._bn_params(), save=False,
                                                   reducer=self._reducer)
-                for bn in self._bn_modules():
-                    bn.num_batches_tracked += 1
+                self._bump_batches_tracked(1)        # nn.BatchNorm2d.train() bookkeeping, one launch
                 self._stat_updates += 1
                 self.features = e
         else:
@@ -593,8 +605,7 @@ class DeepSpeakerModel(nn.Module):
         else:
             embs, _ = get_engine().forward_train_group(xs, self._packed(), self._bn_params(), save=False,
                                                        reducer=self._reducer)
-            for bn in self._bn_modules():
-                bn.num_batches_tracked += 3
+            self._bump_batches_tracked(3)        # nn.BatchNorm2d.train() bookkeeping, one launch
             self._stat_updates += 3
             outs = tuple(embs)
         self.features = outs[2]

@@ -122,7 +122,7 @@ def _planted(x, m3, n_plant, target):
 def test_f16_refinement_default_slots_many_near_ties(cfg1):
     """the DEFAULT slot count with >= 16 planted near ties -- refined selection == f32-class
     selection, no overflow."""
-    from deepspeaker_pytorch_amd.mining import REFINE_CAP_MIN, select_triplets
+    from deepspeaker_pytorch_amd.mining import REFINE_CAP_START, select_triplets
     g, sd, x = cfg1
     m16, m3 = build(sd, "f16"), build(sd, "bf16x3")
     (xa, xp, xn), diff3, margin = _planted(x, m3, 24, 0.6e-3)
@@ -131,7 +131,7 @@ def test_f16_refinement_default_slots_many_near_ties(cfg1):
         fine = select_triplets(e16[:256], e16[256:512], e16[512:], margin, model=m16, inputs=(xa, xp, xn))
     want = np.where(diff3 < np.float32(margin))[0]
     print(f"\nplanted 24: near ties found {fine.n_near_ties}, slots {fine.amb_cap}, selected {len(want)} of 256")
-    assert fine.amb_cap == REFINE_CAP_MIN and 16 <= fine.n_near_ties <= REFINE_CAP_MIN
+    assert fine.amb_cap == REFINE_CAP_START and 16 <= fine.n_near_ties <= REFINE_CAP_START
     assert not fine.refine_overflow and not fine.refined_all
     np.testing.assert_array_equal(fine.indices.cpu().numpy(), want)
 
@@ -141,7 +141,7 @@ def test_f16_refinement_margin_concentrated_batch(cfg1):
     The first call finds far more near ties than it has slots for: the selection then re-embeds the whole batch at
     f32-class precision before anything is read (`refined_all`), and the policy sizes the next calls from what it saw
     -- those decide every near tie in their own slots, no overflow.  Every selection equals the f32-class one."""
-    from deepspeaker_pytorch_amd.mining import REFINE_CAP_MIN, refine_policy, select_triplets
+    from deepspeaker_pytorch_amd.mining import REFINE_CAP_START, refine_policy, select_triplets
     g, sd, x = cfg1
     m16, m3 = build(sd, "f16"), build(sd, "bf16x3")
     (xa, xp, xn), diff3, margin = _planted(x, m3, 200, 0.6e-3)
@@ -150,7 +150,7 @@ def test_f16_refinement_margin_concentrated_batch(cfg1):
         e16 = m16(torch.cat([xa, xp, xn])).clone()
         plain = select_triplets(e16[:256], e16[256:512], e16[512:], margin)
         first = select_triplets(e16[:256], e16[256:512], e16[512:], margin, model=m16, inputs=(xa, xp, xn))
-        assert first.amb_cap == REFINE_CAP_MIN
+        assert first.amb_cap == REFINE_CAP_START
         np.testing.assert_array_equal(first.indices.cpu().numpy(), want)       # resolves the overflow first
         assert first.refine_overflow and first.refined_all and first.n_near_ties > 64
         second = select_triplets(e16[:256], e16[256:512], e16[512:], margin, model=m16, inputs=(xa, xp, xn))

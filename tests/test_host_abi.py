@@ -97,12 +97,16 @@ def test_synthetic_state_dict_is_the_oracle_stream():
 
 
 def test_refine_policy_sizes_slots_from_history():
-    """mining.RefinePolicy (host bookkeeping of the fp16 near-tie refinement): power-of-two slot counts from the recent
-    near-tie counts, whole batch once they pass half of it, decaying with the history window."""
-    from deepspeaker_pytorch_amd.mining import REFINE_CAP_MIN, RefinePolicy
+    """mining.RefinePolicy (host bookkeeping of the fp16 near-tie refinement): a generous slot count until a few calls
+    have been observed, then power-of-two slot counts from the recent near-tie counts, the whole batch once they pass
+    half of it, decaying with the history window."""
+    from deepspeaker_pytorch_amd.mining import REFINE_CAP_MIN, REFINE_CAP_START, RefinePolicy
     pol = RefinePolicy()
-    assert pol.cap_for(256) == REFINE_CAP_MIN and pol.cap_for(8) == 8           # a batch smaller than the minimum
-    for seen, want in ((3, 32), (16, 32), (17, 64), (40, 128), (70, 256), (300, 256)):
+    assert pol.cap_for(256) == REFINE_CAP_START and pol.cap_for(8) == 8         # a batch smaller than the slots
+    for _ in range(RefinePolicy.WARM):
+        pol.observe(1)
+    assert pol.cap_for(256) == REFINE_CAP_MIN
+    for seen, want in ((2, 4), (3, 8), (16, 32), (17, 64), (40, 128), (70, 256), (300, 256)):
         pol.observe(seen)
         assert pol.cap_for(256) == want, (seen, pol.cap_for(256))
     assert pol.max_seen == 300

@@ -1,0 +1,28 @@
+#!/bin/bash
+# One GPU measurement cycle (inside gpurun): tools/gpu_cycle.sh <tag> [tests|bench|prof|pmc|train ...]
+# Everything lands under gpurun_out/<tag>/ ; copy what is to be kept into profiles/.
+TAG=${1:-cycle}; shift
+WHAT="${@:-tests bench}"
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+for w in $WHAT; do
+  case $w in
+    tests) timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest.log ;;
+    newtests) timeout 900 python -m pytest tests/test_gpu_bench_size.py tests/test_gpu_parity.py tests/test_gpu_bench_cli.py -m gpu -x -q -s > $OUT/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -5 $OUT/pytest_new.log ;;
+    bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json | head -c 6000 ;;
+    benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?"; cat $OUT/benchq.json | head -c 4000 ;;
+    train) timeout 600 python bench.py --train --no-cpu-baseline > $OUT/train.json 2> $OUT/train.err; echo "train rc=$?"; cat $OUT/train.json
+           MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 timeout 600 python bench.py --train --force-collectives --no-cpu-baseline > $OUT/train_dp.json 2> $OUT/train_dp.err; echo "train_dp rc=$?"; cat $OUT/train_dp.json ;;
+    prof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/prof.log 2>&1); echo "prof rc=$?"
+          python tools/rocpd_stats.py $(find $OUT/prof -name "*.db") > $OUT/kernel_stats.md 2>$OUT/kernel_stats.err; head -40 $OUT/kernel_stats.md ;;
+    trainprof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trainprof -- python $R/bench.py --train --steps 6 --warmup 2 --repeats 0 --no-cpu-baseline > $OUT/trainprof.log 2>&1); echo "trainprof rc=$?"
+          python tools/rocpd_stats.py $(find $OUT/trainprof -name "*.db") > $OUT/train_kernel_stats.md 2>$OUT/train_kernel_stats.err; python tools/timeline.py $(find $OUT/trainprof -name "*.db") adagrad | head -12 ;;
+    dpprof) (cd /tmp && export TMPDIR=/tmp && MASTER_ADDR=127.0.0.1 MASTER_PORT=29572 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/dpprof -- python $R/bench.py --train --force-collectives --steps 6 --warmup 2 --repeats 0 --no-cpu-baseline > $OUT/dpprof.log 2>&1); echo "dpprof rc=$?"
+          python tools/dp_gaps.py $(find $OUT/dpprof -name "*.db") > $OUT/dp_gaps.md 2>$OUT/dp_gaps.err; head -3 $OUT/dp_gaps.md; python tools/timeline.py $(find $OUT/dpprof -name "*.db") adagrad | head -12 ;;
+    slots) for c in 4 8 16 32; do timeout 300 python bench.py --no-secondary --no-cpu-baseline --refine-slots $c --repeats 2 > $OUT/slots_$c.json 2> $OUT/slots_$c.err; python -c "import json;d=json.load(open('$OUT/slots_$c.json'));print('slots',$c,d['value'],d['ms_per_step'],d['repeats_ms_per_step'],d['roofline']['achieved'],d['refine'])"; done ;;
+    pmc) timeout 1200 tools/pmc_run.sh $TAG/pmc --no-secondary; python tools/pmc_summary.py $OUT/pmc _kernel 40 > $OUT/pmc_summary.md 2> $OUT/pmc_summary.err; head -60 $OUT/pmc_summary.md ;;
+    *) echo "unknown step $w" ;;
+  esac
+done
