@@ -300,5 +300,40 @@ def make_cfg1():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def make_cfg1_train():
+    """The TRAINING step at the bench configuration through the unmodified reference (train_triplet.py:215-223):
+    model.train(); out_a, out_p, out_n = model(data_a), model(data_p), model(data_n) on the 3 x 256 utterances of
+    configs[1]; TripletMarginLoss(0.1); backward.  Recorded in float32 (what the reference runs) and with the model
+    in float64 (the exact derivative of the same function: the tight pin): loss, embeddings, all 36 running
+    statistics, a digest of every parameter gradient, and the small gradients (BatchNorm affine, fc bias) in full."""
+    sd, x = cfg1_inputs()
+    out = {}
+    for tag, dt in (("", torch.float32), ("64", torch.float64)):
+        m = build_ref(sd, 1211).train().to(dt)
+        xs = [x[i * 256:(i + 1) * 256].to(dt) for i in range(3)]
+        ea, ep, en = m(xs[0]), m(xs[1]), m(xs[2])
+        loss = ref.TripletMarginLoss(0.1).forward(ea, ep, en)
+        m.zero_grad()
+        loss.backward()
+        out[f"cfg1t{tag}_loss"] = loss.detach().numpy()
+        out[f"cfg1t{tag}_emb"] = torch.cat([ea, ep, en]).detach().float().numpy()
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[f"cfg1t{tag}_stat/" + k] = v.double().numpy() if v.is_floating_point() else v.numpy()
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                out[f"cfg1t{tag}_grad/" + k] = grad_digest(p.grad)
+                if p.grad.numel() <= 2048:
+                    out[f"cfg1t{tag}_gfull/" + k] = p.grad.detach().double().numpy()
+        print(f"cfg1 train step ({dt}): loss {float(loss):.9f}")
+    path = os.path.join(HERE, "reference_cfg1_train.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg1_train":
+        make_cfg1_train()
+    else:
+        main()
+        make_cfg1_train()

@@ -204,6 +204,46 @@ def test_torch_restatement(golden):
     assert rel_err(es.numpy(), golden["small_eval_emb"]) < 1e-6
 
 
+def test_torch_restatement_training_step(golden):
+    """oracle/torch_restatement.triplet_train_step (the masked-gradient oracle of tests/test_gpu_train_parity.py) against
+    the reference's recorded training step: forward bit-identical, gradients to the run-to-run noise of a multi-threaded
+    float32 backward; feeding a forward its own clip masks changes nothing."""
+    import torch
+    import torch_restatement as TR
+    torch.set_num_threads(8)
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    tsd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=8)) for i in range(3)]
+    r = TR.triplet_train_step(tsd, xs, 0.1, dtype=torch.float32)
+    assert float(r["loss"]) == float(golden["full_train_loss"])
+    for e, k in zip(r["embeddings"], ("a", "p", "n")):
+        np.testing.assert_array_equal(e.numpy(), golden["full_train_emb_" + k])
+
+    def digest(t):
+        a = t.detach().double().numpy().ravel()
+        stride = max(1, a.size // 64)
+        return np.concatenate([[np.sqrt((a * a).sum()), a.sum()], a[:16], a[::stride][:64]])
+
+    assert len(r["grads"]) == 38
+    for k, v in r["grads"].items():
+        ref = golden["full_train_grad/" + k]
+        assert np.abs(digest(v) - ref).max() <= 5e-5 * np.abs(ref).max(), k
+    for k, v in r["running"].items():
+        np.testing.assert_allclose(v.numpy(), golden["full_train_stat/" + k], rtol=1e-6, atol=1e-7)
+    masks = [{k: (a > 0) & (a < 20) for k, a in acts.items()} for acts in r["acts"]]
+    rm = TR.triplet_train_step(tsd, xs, 0.1, masks=masks, dtype=torch.float32)
+    for k, v in r["grads"].items():
+        assert rel_err(rm["grads"][k].numpy(), v.numpy()) < 5e-5, k
+    # float64 evaluation against the reference's float64 run (single forward, fixed embedding gradient)
+    ge = torch.from_numpy(np.random.RandomState(77).randn(8, 512).astype(np.float32))
+    z = torch.zeros(8, 512)
+    r64 = TR.triplet_train_step(tsd, [xs[0]], ge=[ge], dtype=torch.float64)
+    assert rel_err(r64["embeddings"][0].numpy(), golden["single_train64_emb"]) < 1e-12
+    for k, v in r64["grads"].items():
+        ref = golden["single_train64_grad/" + k]
+        assert np.abs(digest(v) - ref).max() <= 1e-9 * np.abs(ref).max(), k
+
+
 def test_roc_sweep_vs_reference_eval_metrics(golden):
     thr = np.arange(0, 30, 0.01)
     tp, fp, best, tpr, fpr, acc = O.roc_sweep(golden["roc_dist"], golden["roc_labels"], thr)
