@@ -41,7 +41,10 @@ template <int WM, int WN, int NIT, bool MASKED = false>
 __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3x3_f16_kernel(const BlockK p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MSA = 5, MSB = 4, NSUB = 2;
-    constexpr int NT = 9, NU = 2 * NT, RU = 6;
+#ifndef DS_BLOCK_RING
+#define DS_BLOCK_RING 6
+#endif
+    constexpr int NT = 9, NU = 2 * NT, RU = DS_BLOCK_RING;      // filter ring, in units (NU % RU == 0)
     constexpr int NMFA = MSA * NSUB, NMFB = MSB * NSUB;
     constexpr int SPU = (NMFA + 1) / 2 - NSUB;
     constexpr int UL = (NIT + SPU - 1) / SPU;

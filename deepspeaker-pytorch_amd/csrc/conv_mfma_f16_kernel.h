@@ -89,9 +89,11 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     constexpr int NU = KPT * NT;                    // (k-step, tap) units per chunk
 #ifndef DS_F16_RING_K3
 #define DS_F16_RING_K3 6
+#endif
+#ifndef DS_F16_RING_K5
 #define DS_F16_RING_K5 5
 #endif
-    constexpr int RU = (KS == 3) ? (KPT == 2 ? DS_F16_RING_K3 : 9) : DS_F16_RING_K5;   // filter ring, in units; NU % RU == 0
+    constexpr int RU = (KS == 3) ? (KPT == 2 ? DS_F16_RING_K3 : 9) : (KPT == 2 ? DS_F16_RING_K5 : 5);   // filter ring, in units; NU % RU == 0
     constexpr int NMF = MSUB * NSUB;                // MFMAs per unit
     constexpr bool PREF = DB || NIT <= 16;          // next chunk's pixels ride in registers through the taps
     static_assert(NU % RU == 0, "ring slots must be chunk-invariant");
