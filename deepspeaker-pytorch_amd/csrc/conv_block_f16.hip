@@ -27,96 +27,107 @@ struct BlockK {
     const float *sa, *ha, *sb, *hb;     // folded BatchNorm of the two layers (scale, shift)
     void *y;                            // [B,H,W,C] fp16 (f32 with DS_EPI_OUT_F32; plane-major with DS_EPI_OUT_PLANES16)
     int B, H, W, C;
-    int tiles_per_img;
+    int tiles_per_img, n_tiles;
     int flags;
     unsigned y_bytes, x_bytes, y_plane_stride;
     const int *lens;                    // MASKED: rows of each image that belong to its utterance (zero-padded batches)
+    int xcd_slots;                      // > 0: workgroups per XCD (grid = 8 * xcd_slots): image b is served by XCD b % 8
 };
 
-// WM x WN waves, each a 160x64 register tile for the first convolution (10 rows x W pixels per WM) and 128x64 for the
-// second (8 rows); W = 32 * WM / ... : MT_A = 160 * WM = 10 * W.  NIT: 16-byte staging items per thread and chunk.
-// MASKED (variable-length batches): rows past an image's own extent are zero in the intermediate and in the output, as
-// ds_mask_rows makes them after each of the two layers -- every kept row equals the utterance's own forward.
-template <int WM, int WN, int NIT, bool MASKED = false>
-__global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3x3_f16_kernel(const BlockK p) {
-    constexpr int NTHR = WM * WN * 64;
-    constexpr int MSA = 5, MSB = 4, NSUB = 2;
 #ifndef DS_BLOCK_RING
 #define DS_BLOCK_RING 6
 #endif
+
+// PERSISTENT workgroups: the grid is what the chip holds at once (two 2-wave workgroups per CU) and a workgroup walks
+// tiles (image, block of BK_R output rows) in a loop.  What that buys, per tile (tools/f16_phase_probe.py on the
+// one-tile-per-workgroup form of these kernels: 11 k clocks of prologue next to a 16 k MFMA stream at stage 1):
+//   * the staging / fragment / output descriptors -- a dozen reciprocal divisions per thread -- are tile-INVARIANT
+//     (every tile has the same shape; only a base offset and the in-image row window change): computed once;
+//   * the next tile's first input chunk is loaded (HBM -> registers) in the idle staging slots of this tile's second
+//     convolution, and the filter ring runs through from one MFMA stream into the next (first layer -> second layer ->
+//     next tile's first layer): no stream starts by waiting for memory;
+//   * the residual rows (the block's own input, just staged: L2-hot) are requested before the second convolution's
+//     stream instead of at the head of the epilogue;
+//   * only what must be zero is zeroed: the two halo columns of each tile.  Rows outside the image are STAGED as zeros
+//     (out-of-range buffer loads), so every tile stages the same ROWS_IN rows.
+// Arithmetic and accumulation order are unchanged: results stay bit-identical to two ds_conv_fwd_f16 calls.
+//
+// WM x WN waves, each a 160x64 register tile for the first convolution (10 rows x W pixels per WM) and 128x64 for the
+// second (8 rows): the map is W = 16 * WM pixels wide (MT_A = 160 * WM = 10 * W).  NIT: 16-byte staging items per thread
+// and chunk (12 rows x W pixels x 4 quarters over the workgroup's threads, exactly).
+// MASKED (variable-length batches): rows past an image's own extent are zero in the intermediate and in the output, as
+// ds_mask_rows makes them after each of the two layers -- every kept row equals the utterance's own forward.
+//
+// Register budget (one wave per SIMD: 512 registers, of which the 160 accumulators live in the AGPR half and everything
+// else must fit the 256 architectural ones or be shuttled): the persistent loop keeps NO per-tile table alive -- staging
+// offsets are the invariant g_rel minus a per-tile scalar inside a per-tile buffer descriptor, output offsets are
+// recomputed in the epilogue, the residual rows are requested in the LAST units of the second convolution and the next
+// tile's first chunk at the head of the epilogue (not one MFMA stream earlier).
+template <int WM, int WN, int NIT, bool MASKED = false>
+__global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3x3_f16_kernel(const BlockK p) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int W = 16 * WM, WSH = WM == 2 ? 5 : 4;          // map width (a power of two) and its log2
+    constexpr int MSA = 5, MSB = 4, NSUB = 2;
     constexpr int NT = 9, NU = 2 * NT, RU = DS_BLOCK_RING;      // filter ring, in units (NU % RU == 0)
     constexpr int NMFA = MSA * NSUB, NMFB = MSB * NSUB;
-    constexpr int SPU = (NMFA + 1) / 2 - NSUB;
+    constexpr int SPU = (NMFA + 1) / 2 - NSUB;                  // staging slots per unit, first convolution
     constexpr int UL = (NIT + SPU - 1) / SPU;
-    static_assert(2 * UL <= NU, "not enough units for the staging traffic");
+    constexpr int SPUB = NMFB / 2 - NSUB;                       // spare slots per unit, second convolution
     constexpr int ROWS_A = BK_R + 2, ROWS_IN = BK_R + 4;
+    constexpr int TP = NSUB * 32 + 4, LPP = NSUB * 4, PPI = 64 / LPP, NRI = 32 / PPI;
+    constexpr int NRES = MSB * NRI, ULR = (NRES + SPUB - 1) / SPUB;     // residual loads / the units that carry them
+    static_assert(WM == 1 || WM == 2, "map width 16 or 32");
+    static_assert(2 * UL <= NU && ULR + 2 <= NU && NU % RU == 0, "not enough units for the staging traffic");
+    static_assert(NIT * NTHR == ROWS_IN * W * 4, "staging items must tile the input rows exactly");
+    constexpr unsigned OOB = 0x80000000u;       // stays out of range of any buffer here after adding a chunk offset
+    constexpr int pitch = W + 2;                                     // records per tile row (both tiles)
+    constexpr int tileA_bytes = ROWS_IN * pitch * BK_PS;
 
     char *lds = (char *)ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int W = p.W, C = p.C;
-    const int b = blockIdx.x / p.tiles_per_img;
-    const int r0 = (blockIdx.x - b * p.tiles_per_img) * BK_R;        // first output row of this tile
-    int h_valid = p.H;                                               // rows of this image that carry data
-    if (MASKED) {
-        const int len = p.lens[b];
-        h_valid = len < p.H ? len : p.H;
-    }
-    const int pitch = W + 2;                                         // records per tile row (both tiles)
-    const int tileA_bytes = ROWS_IN * pitch * BK_PS;
+    const int C = p.C;
     const int RSB = C * 2 + 16;                                      // bytes per intermediate record
     const int n_chunks = C / BK_CK;
     const int n_base = wn * NSUB * 32;
-    const size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);
+    size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);
     const size_t w_kc_stride = (size_t)NT * C * 16, w_tap_stride = (size_t)C * 16;
     auto w_unit = [&](const _Float16 *w, int chunk, int u) {         // k-step-major units, as conv_mfma_f16_kernel
         return w + lane_w + (size_t)(2 * chunk + (u / NT)) * w_kc_stride + (size_t)(u % NT) * w_tap_stride;
     };
-    f16x8 bq[RU][NSUB];
-#pragma unroll
-    for (int d = 0; d < RU; ++d)
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(p.wa, 0, d) + (size_t)ns * 32 * 16);
 
-    f32x16 acc[MSA][NSUB];
-#pragma unroll
-    for (int ms = 0; ms < MSA; ++ms)
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+    // ---- which tiles this workgroup walks ----
+    // plain: tile = blockIdx.x + k * gridDim.x.  XCD-aware (grid = 8 * xcd_slots, batches of >= 8 images): workgroup w
+    // is dispatched to XCD w % 8 (observed, not contractual -- it only decides which L2 the halo rows are found in);
+    // that XCD serves images b = 8 j + (w % 8), so the row blocks of an image share one L2.
+    const int xcd = (int)blockIdx.x & 7, slot0 = (int)blockIdx.x >> 3;
+    const int my_imgs = p.xcd_slots > 0 ? (p.B - xcd + 7) / 8 : 0;
+    int t_cur = p.xcd_slots > 0 ? slot0 : (int)blockIdx.x;
+    const int t_step = p.xcd_slots > 0 ? p.xcd_slots : (int)gridDim.x;
+    const int t_end = p.xcd_slots > 0 ? my_imgs * p.tiles_per_img : p.n_tiles;
+    const float rcp_tpi = 1.0f / (float)p.tiles_per_img;
+    auto tile_of = [&](int t, int &b, int &r0) {
+        const int im = ds_div_small(t, p.tiles_per_img, rcp_tpi);
+        r0 = (t - im * p.tiles_per_img) * BK_R;
+        b = p.xcd_slots > 0 ? im * 8 + xcd : im;
+    };
 
-    // ---- staging descriptors: input rows r0-2 .. r0+R+1 of image b, in-image rows only ----
-    const float rcp_w = 1.0f / (float)W;
-    const int h0 = r0 - 2;
-    const int lo = h0 < 0 ? -h0 : 0;
-    const int hi = p.H - h0 < ROWS_IN ? p.H - h0 : ROWS_IN;
-    const int cnt = hi > lo ? hi - lo : 0;
-    int g_off[NIT], l_off[NIT];
+    // ---- tile-invariant descriptors ----
+    // staging item it of this thread: 8 channels (16 B) of pixel (tile row vr, column c), tile rows 0 .. ROWS_IN-1 =
+    // image rows r0-2 .. r0+R+1.  g_rel: byte offset from the tile's row 0; l_off: where it goes in the LDS tile.
+    unsigned g_rel[NIT];
+    int l_off[NIT];
     {
-        const int q = tid & 3;
-        const int dvr = ds_div_small(NTHR / 4, W, rcp_w), dc = NTHR / 4 - dvr * W;
-        int vr = ds_div_small(tid >> 2, W, rcp_w);
-        int c = (tid >> 2) - vr * W;
+        const int q = tid & 3, pix0 = tid >> 2;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const bool ok = vr < cnt;
-            g_off[it] = ok ? ((b * p.H + h0 + lo + vr) * W + c) * C + q * 8 : 0;
-            l_off[it] = ok ? ((lo + vr) * pitch + c + 1) * BK_PS + q * 16 : 64;
-            c += dc;
-            vr += dvr;
-            if (c >= W) {
-                c -= W;
-                ++vr;
-            }
+            const int pix = pix0 + it * (NTHR / 4);
+            const int vr = pix >> WSH, c = pix & (W - 1);
+            g_rel[it] = (unsigned)((pix * C + q * 8) * 2);
+            l_off[it] = (vr * pitch + c + 1) * BK_PS + q * 16;
         }
     }
-    f32x4 st[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) st[it] = *(const f32x4 *)(p.x + g_off[it]);
-    // zero halo of both input buffers, written once
-    for (int i = tid; i < 2 * tileA_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     // lane -> pixel permutation inside a 32-pixel sub-tile (conflict-free ds_read_b128 service groups, see
     // conv_mfma_f16_kernel.h)
     const int lpix = (l31 < 4 || l31 >= 28) ? l31
@@ -125,245 +136,331 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
 #pragma unroll
     for (int ms = 0; ms < MSA; ++ms) {
         const int m = (wm * MSA + ms) * 32 + lpix;
-        const int i = ds_div_small(m, W, rcp_w), c = m - i * W;
-        a_off[ms] = (i * pitch + c) * BK_PS + 16 * lhi;
+        a_off[ms] = ((m >> WSH) * pitch + (m & (W - 1))) * BK_PS + 16 * lhi;
     }
     auto tap_off = [&](int tt, int rs) { return ((tt / 3) * pitch + (tt % 3)) * rs; };
+    const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
+    const ds_buffer rbuf = ds_make_buffer(p.x, p.x_bytes);          // residual rows
+    const int x_row_bytes = W * C * 2;
+    const int my_c = (lane % LPP) * 8, my_p = lane / LPP;
+    const int col = n_base + my_c;
+    const bool out32 = (p.flags & DS_EPI_OUT_F32) != 0;
+    float *tb = (float *)lds + wave * (2 * 32 * TP);
 
-    // ---- first convolution: the MFMA stream of conv_mfma_f16_kernel (double-buffered tile, one side operation per MFMA)
-    auto run_chunk = [&](auto last_tag, int chunk, const char *buf, char *obuf) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        f16x8 a[2][MSA];
-#pragma unroll
-        for (int ms = 0; ms < MSA; ++ms) {
-            DS_OPAQUE_VGPR(a_off[ms]);
-            a[0][ms] = *(const f16x8 *)(buf + a_off[ms] + tap_off(0, BK_PS));
-        }
-        const _Float16 *xn = p.x + (chunk + 1) * BK_CK;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int cur = u & 1, slot = u % RU;
-            const bool more = u + 1 < NU;
-            const char *nfrag = buf + tap_off((u + 1) % NT, BK_PS) + 32 * ((u + 1) / NT);
-            const int ur = u - 1 + RU;
-            const bool refill = !(LAST && ur >= NU);
-            const _Float16 *rw = w_unit(p.wa, ur >= NU ? chunk + 1 : chunk, ur >= NU ? ur - NU : ur);
-            const int rslot = (u + RU - 1) % RU;
-#pragma unroll
-            for (int q = 0; q < NMFA; ++q) {
-                const int ms = q / NSUB, ns = q % NSUB;
-                acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
-                if (q & 1) {
-                    const int lm = q >> 1;
-                    if (lm < MSA && more) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + a_off[lm]);
-                } else {
-                    const int e = q >> 1;
-                    if (e < NSUB) {
-                        if (refill) bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
-                    } else if constexpr (!LAST) {
-                        const int s = e - NSUB;
-                        if (u < UL) {
-                            const int it = u * SPU + s;
-                            if (it < NIT) st[it] = *(const f32x4 *)(xn + g_off[it]);
-                        } else if (u >= NU - UL) {
-                            const int it = (u - (NU - UL)) * SPU + s;
-                            if (it < NIT) *(f32x4 *)(obuf + l_off[it]) = st[it];
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+    // The staged rows of a tile as a buffer of their own: it starts at the first in-image row of the tile's window and
+    // ends with the last one, so a row outside the image is out of range -- it reads as zeros and is written to LDS as
+    // such -- whichever side it is on: voffset = g_rel - lo wraps to > 2 GB for the rows above the window.
+    auto stage_window = [&](int b, int r0, ds_buffer &xb, unsigned &lo) {
+        const int h0 = r0 - 2;
+        const int first = h0 < 0 ? -h0 : 0;
+        const int last = p.H - h0 < ROWS_IN ? p.H - h0 : ROWS_IN;            // one past the last in-image tile row
+        lo = (unsigned)(first * x_row_bytes);
+        xb = ds_make_buffer((const char *)p.x + (size_t)(b * p.H + h0 + first) * x_row_bytes,
+                            (unsigned)((last > first ? last - first : 0) * x_row_bytes));
     };
-    __syncthreads();                            // the zero fill is complete
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
-    __syncthreads();
-    for (int i = 0; i + 1 < n_chunks; ++i) {
-        char *b0 = lds + (i & 1) * tileA_bytes, *b1 = lds + ((i & 1) ^ 1) * tileA_bytes;
-        run_chunk(std::false_type{}, i, b0, b1);
-        ds_lds_barrier();
-    }
-    run_chunk(std::true_type{}, n_chunks - 1, lds + ((n_chunks - 1) & 1) * tileA_bytes, lds);
 
-    // ---- the second layer's first filter fragments travel during the hand-over ----
+    f16x8 bq[RU][NSUB];
 #pragma unroll
     for (int d = 0; d < RU; ++d)
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(p.wb, 0, d) + (size_t)ns * 32 * 16);
+        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(p.wa, 0, d) + (size_t)ns * 32 * 16);
 
-    // ---- hand-over: bn1 + clip, rounded to fp16, into the intermediate tile [ROWS_A][pitch] of C-channel records.
-    // Columns 0 and W + 1 and the rows outside the image are the second convolution's zero padding.
-    __syncthreads();                            // every wave is done reading the input tiles
-    const int interm_bytes = ROWS_A * pitch * RSB;
-    for (int i = tid; i < interm_bytes / 16; i += NTHR) *(f32x4 *)(lds + 16 * i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 sca[NSUB][4], sha[NSUB][4];
+    f32x16 acc[MSA][NSUB];
 #pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = n_base + ns * 32 + 8 * g + 4 * lhi;
-            sca[ns][g] = *(const f32x4 *)(p.sa + c0);
-            sha[ns][g] = *(const f32x4 *)(p.ha + c0);
-        }
-    __syncthreads();                            // the zero fill is complete
-#pragma unroll
-    for (int ms = 0; ms < MSA; ++ms) {
-        const int m = (wm * MSA + ms) * 32 + lpix;
-        const int i = ds_div_small(m, W, rcp_w), c = m - i * W;
-        const int row = r0 - 1 + i;                                  // image row of this intermediate pixel
-        const bool inside = row >= 0 && row < h_valid;
-        char *rec = lds + (i * pitch + c + 1) * RSB;
+    for (int ms = 0; ms < MSB; ++ms)
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 h;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float t = fminf(fmaxf(acc[ms][ns][4 * g + j] * sca[ns][g][j] + sha[ns][g][j], 0.0f), 20.0f);
-                    h[j] = inside ? (_Float16)t : (_Float16)0.0f;
-                    acc[ms][ns][4 * g + j] = 0.0f;                   // the accumulators start the second layer at zero
-                }
-                *(f16x4 *)(rec + (n_base + ns * 32 + 8 * g + 4 * lhi) * 2) = h;
-            }
-    }
-    __syncthreads();                            // the intermediate tile is complete
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
 
-    // ---- second convolution: fragments straight from the intermediate tile, all chunks resident ----
-    int b_off[MSB];
+    f32x4 st[NIT];
+    int b = 0, r0 = 0;
+    ds_buffer xbuf = rbuf;
+    unsigned x_lo = 0;
+    if (t_cur < t_end) {
+        tile_of(t_cur, b, r0);
+        stage_window(b, r0, xbuf, x_lo);
 #pragma unroll
-    for (int ms = 0; ms < MSB; ++ms) {
-        const int m = (wm * MSB + ms) * 32 + lpix;
-        const int i = ds_div_small(m, W, rcp_w), c = m - i * W;
-        b_off[ms] = (i * pitch + c) * RSB + 16 * lhi;
+        for (int it = 0; it < NIT; ++it) st[it] = ds_buffer_load_f32x4(xbuf, g_rel[it] - x_lo);
     }
-    {
-        const int total = n_chunks * NU;        // units of the whole contraction, filter ring running through
-        f16x8 a[2][MSB];
-#pragma unroll
-        for (int ms = 0; ms < MSB; ++ms) {
-            DS_OPAQUE_VGPR(b_off[ms]);
-            a[0][ms] = *(const f16x8 *)(lds + b_off[ms] + tap_off(0, RSB));
+
+    for (; t_cur < t_end; t_cur += t_step) {
+        // every filter-fragment address below is tile-invariant; hoisted out of this loop they would be ~70 live 64-bit
+        // values (spilled, and reloaded from scratch between the MFMAs): keep them derived where they are used
+        DS_OPAQUE_VGPR(lane_w);
+        int h_valid = p.H;                                           // rows of this image that carry data
+        if (MASKED) {
+            const int len = p.lens[b];
+            h_valid = len < p.H ? len : p.H;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)                            // (rows 0 .. MSB-1 were cleared by the epilogue)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[MSA - 1][ns][r] = 0.0f;
+        // ---- (1) halo columns of both input buffers, the first chunk's pixels -> buffer 0 ----
+        ds_lds_barrier();                       // the previous tile's epilogue has finished with the LDS (its stores to
+                                                // HBM stay in flight: only LDS traffic is waited for)
+        for (int i = tid; i < 2 * ROWS_IN * 2 * (BK_PS / 16); i += NTHR) {
+            const int piece = i % (BK_PS / 16), rec = i / (BK_PS / 16);          // rec: (buffer, row, left | right)
+            const int side = rec & 1, row = (rec >> 1) % ROWS_IN, buf = (rec >> 1) / ROWS_IN;
+            *(f32x4 *)(lds + buf * tileA_bytes + (row * pitch + side * (W + 1)) * BK_PS + 16 * piece) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
+        ds_lds_barrier();
+
+        // ---- (2) first convolution: the MFMA stream of conv_mfma_f16_kernel (double-buffered tile, one side operation
+        // per MFMA); its last chunk's ring refills already fetch the second layer's first filter fragments ----
+        auto run_chunk = [&](auto last_tag, int chunk, const char *buf, char *obuf) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            f16x8 a[2][MSA];
+#pragma unroll
+            for (int ms = 0; ms < MSA; ++ms) {
+                DS_OPAQUE_VGPR(a_off[ms]);
+                a[0][ms] = *(const f16x8 *)(buf + a_off[ms] + tap_off(0, BK_PS));
+            }
+            const unsigned xn = (unsigned)((chunk + 1) * BK_CK * 2) - x_lo;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int cur = u & 1, slot = u % RU;
-                const int gu = chunk * NU + u;                       // (NU is even and a multiple of RU: slots line up)
-                const bool more = gu + 1 < total;
-                const int nu = (u + 1) % NU, nchunk = (u + 1 < NU) ? chunk : chunk + 1;
-                const char *nfrag = lds + tap_off(nu % NT, RSB) + 32 * (nu / NT) + (more ? nchunk : chunk) * 64;
+                const bool more = u + 1 < NU;
+                const char *nfrag = buf + tap_off((u + 1) % NT, BK_PS) + 32 * ((u + 1) / NT);
                 const int ur = u - 1 + RU;
-                const int rchunk = ur >= NU ? chunk + 1 : chunk;
-                const bool refill = rchunk < n_chunks;
-                const _Float16 *rw = w_unit(p.wb, refill ? rchunk : chunk, ur >= NU ? ur - NU : ur);
+                const _Float16 *rw = (LAST && ur >= NU) ? w_unit(p.wb, 0, ur - NU)
+                                                        : w_unit(p.wa, ur >= NU ? chunk + 1 : chunk, ur >= NU ? ur - NU : ur);
                 const int rslot = (u + RU - 1) % RU;
 #pragma unroll
-                for (int q = 0; q < NMFB; ++q) {
+                for (int q = 0; q < NMFA; ++q) {
                     const int ms = q / NSUB, ns = q % NSUB;
                     acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
                     if (q & 1) {
                         const int lm = q >> 1;
-                        if (lm < MSB && more) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + b_off[lm]);
+                        if (lm < MSA && more) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + a_off[lm]);
                     } else {
                         const int e = q >> 1;
-                        if (e < NSUB && refill && (gu > 0)) bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+                        if (e < NSUB) {
+                            bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+                        } else if constexpr (!LAST) {
+                            const int s = e - NSUB;
+                            if (u < UL) {
+                                const int it = u * SPU + s;
+                                if (it < NIT) st[it] = ds_buffer_load_f32x4(xbuf, g_rel[it] + xn);
+                            } else if (u >= NU - UL) {
+                                const int it = (u - (NU - UL)) * SPU + s;
+                                if (it < NIT) *(f32x4 *)(obuf + l_off[it]) = st[it];
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        };
+        for (int i = 0; i + 1 < n_chunks; ++i) {
+            char *b0 = lds + (i & 1) * tileA_bytes, *b1 = lds + ((i & 1) ^ 1) * tileA_bytes;
+            run_chunk(std::false_type{}, i, b0, b1);
+            ds_lds_barrier();
         }
-    }
+        run_chunk(std::true_type{}, n_chunks - 1, lds + ((n_chunks - 1) & 1) * tileA_bytes, lds);
 
-    // ---- epilogue of the block: bn2 + residual (the block's own input) + clip, as conv_mfma_f16_kernel ----
-    constexpr int TP = NSUB * 32 + 4, LPP = NSUB * 4, PPI = 64 / LPP, NRI = 32 / PPI;
-    const int flags = p.flags;
-    __syncthreads();                            // every wave is done reading the intermediate tile
-    float *tb = (float *)lds + wave * (2 * 32 * TP);
-    const int my_c = (lane % LPP) * 8, my_p = lane / LPP;
-    const int col = n_base + my_c;
-    f32x4 sc[2] = {*(const f32x4 *)(p.sb + col), *(const f32x4 *)(p.sb + col + 4)};
-    f32x4 sh[2] = {*(const f32x4 *)(p.hb + col), *(const f32x4 *)(p.hb + col + 4)};
-    const bool out32 = (flags & DS_EPI_OUT_F32) != 0;
-    const ds_buffer ybuf = ds_make_buffer(p.y, p.y_bytes);
-    const ds_buffer rbuf = ds_make_buffer(p.x, p.x_bytes);
-    const int lin_base = (b * p.H + r0) * W;
-    const int lin_valid = (p.H - r0 < BK_R ? p.H - r0 : BK_R) * W;
-    const int lin_kept = (h_valid - r0) * W;                          // MASKED: pixels of the tile below the extent
-    unsigned voff[MSB][NRI];
-    f32x4 resv[MSB][NRI];
+        // ---- (3) hand-over: bn1 + clip, rounded to fp16, into the intermediate tile [ROWS_A][pitch] of C-channel
+        // records.  Columns 0 and W + 1 and the rows outside the image are the second convolution's zero padding. ----
+        {
+            f32x4 sca[NSUB][4], sha[NSUB][4];
 #pragma unroll
-    for (int ms = 0; ms < MSB; ++ms)
+            for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
-        for (int k = 0; k < NRI; ++k) {
-            const int m = (wm * MSB + ms) * 32 + k * PPI + my_p;
-            const int off = m < lin_valid ? lin_base + m : -1;
-            const unsigned cl = (unsigned)(off * C + col);
-            voff[ms][k] = off < 0 ? DS_BUFFER_OOB
-                          : p.y_plane_stride ? (unsigned)(col >> 4) * p.y_plane_stride + (unsigned)off * 16u + (unsigned)(col & 15) : cl;
-            resv[ms][k] = ds_buffer_load_f32x4(rbuf, off >= 0 ? cl * 2u : DS_BUFFER_OOB);
-        }
-    auto put_tile = [&](int ms) {
-        float *dst = tb + (ms & 1) * (32 * TP);
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
-                *(f32x4 *)(dst + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
-            }
-    };
-    put_tile(0);
-#pragma unroll
-    for (int ms = 0; ms < MSB; ++ms) {
-        const int cb = ms & 1;
-        ds_wave_sync();
-        const float *src = tb + cb * (32 * TP);
-        f32x4 tv[NRI][2];
-#pragma unroll
-        for (int k = 0; k < NRI; ++k)
-#pragma unroll
-            for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
-        if (ms + 1 < MSB) put_tile(ms + 1);
-#pragma unroll
-        for (int k = 0; k < NRI; ++k) {
-            const f16x8 r8 = __builtin_bit_cast(f16x8, resv[ms][k]);
-            f32x4 o[2];
-#pragma unroll
-            for (int hq = 0; hq < 2; ++hq)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = tv[k][hq][j] * sc[hq][j] + sh[hq][j];
-                    t += (float)r8[4 * hq + j];
-                    o[hq][j] = fminf(fmaxf(t, 0.0f), 20.0f);
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = n_base + ns * 32 + 8 * g + 4 * lhi;
+                    sca[ns][g] = *(const f32x4 *)(p.sa + c0);
+                    sha[ns][g] = *(const f32x4 *)(p.ha + c0);
                 }
-            if (MASKED) {
-                const bool kept = (wm * MSB + ms) * 32 + k * PPI + my_p < lin_kept;
+            ds_lds_barrier();                       // every wave is done reading the input tiles
+            const int ppr = RSB / 16;               // 16-byte pieces per record
+            for (int i = tid; i < ROWS_A * 2 * ppr; i += NTHR) {
+                const int piece = i % ppr, rec = i / ppr;
+                *(f32x4 *)(lds + ((rec >> 1) * pitch + (rec & 1) * (W + 1)) * RSB + 16 * piece) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int ms = 0; ms < MSA; ++ms) {
+                const int m = (wm * MSA + ms) * 32 + lpix;
+                const int i = m >> WSH, c = m & (W - 1);
+                const int row = r0 - 1 + i;                              // image row of this intermediate pixel
+                const bool inside = row >= 0 && row < h_valid;
+                char *rec = lds + (i * pitch + c + 1) * RSB;
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 h;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float t = fminf(fmaxf(acc[ms][ns][4 * g + j] * sca[ns][g][j] + sha[ns][g][j], 0.0f), 20.0f);
+                            h[j] = inside ? (_Float16)t : (_Float16)0.0f;
+                            if (ms < MSB) acc[ms][ns][4 * g + j] = 0.0f;     // the second layer starts at zero
+                        }
+                        *(f16x4 *)(rec + (n_base + ns * 32 + 8 * g + 4 * lhi) * 2) = h;
+                    }
+            }
+            ds_lds_barrier();                       // the intermediate tile is complete
+        }
+
+        // ---- (4) second convolution: fragments straight from the intermediate tile, all chunks resident.  The ring
+        // runs on into the next tile's first layer; the LAST chunk's spare slots request the residual rows of the
+        // epilogue (the block's own input, staged a moment ago: L2-hot). ----
+        const int lin_base = (b * p.H + r0) * W;
+        const int lin_valid = (p.H - r0 < BK_R ? p.H - r0 : BK_R) * W;
+        f32x4 resv[MSB][NRI];
+        {
+            const int total = n_chunks * NU;        // units of the whole contraction, filter ring running through
+            int b_off[MSB];
+#pragma unroll
+            for (int ms = 0; ms < MSB; ++ms) {
+                const int m = (wm * MSB + ms) * 32 + lpix;
+                b_off[ms] = ((m >> WSH) * pitch + (m & (W - 1))) * RSB + 16 * lhi;
+            }
+            f16x8 a[2][MSB];
+#pragma unroll
+            for (int ms = 0; ms < MSB; ++ms) {
+                DS_OPAQUE_VGPR(b_off[ms]);
+                a[0][ms] = *(const f16x8 *)(lds + b_off[ms] + tap_off(0, RSB));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // LASTB is a compile-time property: a load behind a run-time condition would be branched around and waited
+            // for on the spot
+            auto run_b = [&](auto last_tag, int chunk) __attribute__((always_inline)) {
+                constexpr bool LASTB = decltype(last_tag)::value;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int cur = u & 1, slot = u % RU;
+                    const int gu = chunk * NU + u;                       // (NU is even and a multiple of RU: slots line up)
+                    const bool more = gu + 1 < total;
+                    const int nu = (u + 1) % NU, nchunk = (u + 1 < NU) ? chunk : chunk + 1;
+                    // (past the last unit the "next" fragment is read again from this chunk: valid address, unused value)
+                    const char *nfrag = lds + tap_off(nu % NT, RSB) + 32 * (nu / NT) + (more ? nchunk : chunk) * 64;
+                    const int ur = u - 1 + RU;
+                    const int rchunk = ur >= NU ? chunk + 1 : chunk;
+                    // past the end of this layer the ring runs on into the next tile's first layer (chunk 0 of wa)
+                    const _Float16 *rw = rchunk < n_chunks ? w_unit(p.wb, rchunk, ur >= NU ? ur - NU : ur)
+                                                           : w_unit(p.wa, 0, ur >= NU ? ur - NU : ur);
+                    const int rslot = (u + RU - 1) % RU;
+#pragma unroll
+                    for (int q = 0; q < NMFB; ++q) {
+                        const int ms = q / NSUB, ns = q % NSUB;
+                        acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
+                        if (q & 1) {
+                            const int lm = q >> 1;
+                            if (lm < MSB) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + b_off[lm]);
+                        } else {
+                            const int e = q >> 1;
+                            if (e < NSUB) {
+                                bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+                            } else if constexpr (LASTB) {                // residual rows -> registers, units NU-2-ULR ..
+                                const int ri = (u - (NU - 2 - ULR)) * SPUB + (e - NSUB);
+                                if (u >= NU - 2 - ULR && ri < NRES) {
+                                    const int rms = ri / NRI, rk = ri % NRI;
+                                    const int m = (wm * MSB + rms) * 32 + rk * PPI + my_p;
+                                    resv[rms][rk] = ds_buffer_load_f32x4(rbuf, m < lin_valid ? (unsigned)((lin_base + m) * C + col) * 2u
+                                                                                            : DS_BUFFER_OOB);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) run_b(std::false_type{}, chunk);
+            run_b(std::true_type{}, n_chunks - 1);
+        }
+
+        // ---- (5) epilogue of the block: bn2 + residual (the block's own input) + clip, as conv_mfma_f16_kernel.  At
+        // its head the NEXT tile's first input chunk is requested: it arrives while this tile is written out. ----
+        ds_lds_barrier();                           // every wave is done reading the intermediate tile
+        int nb = b, nr0 = r0;
+        {
+            const bool has_next = t_cur + t_step < t_end;
+            if (has_next) {
+                tile_of(t_cur + t_step, nb, nr0);
+                stage_window(nb, nr0, xbuf, x_lo);
+            } else {
+                xbuf = ds_make_buffer(p.x, 0u);     // nothing in range: the loads return zeros
+                x_lo = 0;
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) st[it] = ds_buffer_load_f32x4(xbuf, g_rel[it] - x_lo);
+        }
+        const int lin_kept = (h_valid - r0) * W;                          // MASKED: pixels of the tile below the extent
+        const f32x4 sc[2] = {*(const f32x4 *)(p.sb + col), *(const f32x4 *)(p.sb + col + 4)};
+        const f32x4 sh[2] = {*(const f32x4 *)(p.hb + col), *(const f32x4 *)(p.hb + col + 4)};
+        auto put_tile = [&](int ms) {
+            float *dst = tb + (ms & 1) * (32 * TP);
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[ms][ns][4 * g + j];
+                        acc[ms][ns][4 * g + j] = 0.0f;                   // ready for the next tile's first layer
+                    }
+                    *(f32x4 *)(dst + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
+                }
+        };
+        put_tile(0);
+#pragma unroll
+        for (int ms = 0; ms < MSB; ++ms) {
+            const int cb = ms & 1;
+            ds_wave_sync();
+            const float *src = tb + cb * (32 * TP);
+            f32x4 tv[NRI][2];
+#pragma unroll
+            for (int k = 0; k < NRI; ++k)
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
+            if (ms + 1 < MSB) put_tile(ms + 1);
+#pragma unroll
+            for (int k = 0; k < NRI; ++k) {
+                const f16x8 r8 = __builtin_bit_cast(f16x8, resv[ms][k]);
+                f32x4 o[2];
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[hq][j] = kept ? o[hq][j] : 0.0f;
-            }
-            const unsigned vo = voff[ms][k];
-            if (out32) {
-                const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
-                ds_buffer_store_f32x4(ybuf, bo, o[0]);
-                ds_buffer_store_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
-            } else {
-                f16x8 h;
+                    for (int j = 0; j < 4; ++j) {
+                        float t = tv[k][hq][j] * sc[hq][j] + sh[hq][j];
+                        t += (float)r8[4 * hq + j];
+                        o[hq][j] = fminf(fmaxf(t, 0.0f), 20.0f);
+                    }
+                const int m = (wm * MSB + ms) * 32 + k * PPI + my_p;
+                if (MASKED) {
+                    const bool kept = m < lin_kept;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h[j] = (_Float16)o[0][j];
-                    h[4 + j] = (_Float16)o[1][j];
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[hq][j] = kept ? o[hq][j] : 0.0f;
                 }
-                ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+                // element offset of (pixel row, first channel): channels-last, or 16-channel planes
+                const unsigned off = (unsigned)(lin_base + m);
+                const unsigned vo = m >= lin_valid ? DS_BUFFER_OOB
+                                    : p.y_plane_stride ? (unsigned)(col >> 4) * p.y_plane_stride + off * 16u + (unsigned)(col & 15)
+                                                       : off * (unsigned)C + (unsigned)col;
+                if (out32) {
+                    const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
+                    ds_buffer_store_f32x4(ybuf, bo, o[0]);
+                    ds_buffer_store_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
+                } else {
+                    f16x8 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        h[j] = (_Float16)o[0][j];
+                        h[4 + j] = (_Float16)o[1][j];
+                    }
+                    ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+                }
             }
         }
+        b = nb;
+        r0 = nr0;
     }
 }
 
@@ -400,19 +497,25 @@ static int conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_
     k.sa = scale_a; k.ha = shift_a; k.sb = scale_b; k.hb = shift_b; k.y = y;
     k.B = B; k.H = H; k.W = W; k.C = C;
     k.tiles_per_img = ds_ceil_div(H, BK_R);
+    k.n_tiles = B * k.tiles_per_img;
     k.flags = flags;
     const long long n = (long long)B * H * W * C;
     k.x_bytes = (unsigned)(n * 2);
     k.y_bytes = (unsigned)(n * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
     k.y_plane_stride = (flags & DS_EPI_OUT_PLANES16) ? (unsigned)((long long)B * H * W * 16) : 0u;
     k.lens = lens;
-    const int grid = B * k.tiles_per_img;
+    // persistent workgroups: as many as the chip holds at once (two 2-wave workgroups per CU: one wave per SIMD, 65 KB
+    // of LDS each); batches of >= 8 images that fill them are dealt to the XCDs by image (see the kernel)
+    const int resident = 2 * ds_cu_count();
+    int grid = k.n_tiles < resident ? k.n_tiles : resident;
+    k.xcd_slots = 0;
+    if (B >= 8 && grid == resident && resident % 8 == 0) k.xcd_slots = resident / 8;
     if (C == 64) {          // W = 32: 2 x 1 waves, 12 x 32 x 4 items over 128 threads
-        if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 16, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
-        else DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 16>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 12, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        else DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 12>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
     } else {                // W = 16, C = 128: 1 x 2 waves
-        if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 8, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
-        else DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 8>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 6, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
+        else DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<1, 2, 6>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
     }
     return ds_last_launch_error();
 }

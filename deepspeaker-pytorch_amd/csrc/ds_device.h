@@ -142,6 +142,20 @@ __device__ __forceinline__ float *ds_dynamic_lds() {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__);    \
     } while (0)
 
+// Compute units of the current device (persistent kernels size their grid by it); queried once per process.
+static inline int ds_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;                            // MI355X
+    }
+    return n;
+}
+
 static inline int ds_last_launch_error() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -4,6 +4,7 @@
 //   D[row = (reg&3) + 8*(reg>>2) + 4*(l>>5)][col = l&31], k accumulated in order with fmaf.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -177,5 +178,13 @@ static inline float *ds_dynamic_lds() { return emu::dynamic_lds(); }
 
 #define DS_LAUNCH_BIG_LDS(kernel, grid, block, lds_bytes, stream, ...) \
     emu::launch((int)(grid), (int)(block), (size_t)(lds_bytes), [=]() { kernel(__VA_ARGS__); }, true)
+
+// "compute units" of the emulated device: small, so that persistent kernels walk several tiles per workgroup in the
+// tests (DS_EMUL_CUS overrides)
+static inline int ds_cu_count() {
+    const char *e = getenv("DS_EMUL_CUS");
+    const int n = e ? atoi(e) : 2;
+    return n > 0 ? n : 2;
+}
 
 static inline int ds_last_launch_error() { return 0; }

@@ -191,7 +191,11 @@ def test_conv1_fp16_output():
     assert np.array_equal(y16, y32.astype(np.float16))
 
 
-@pytest.mark.parametrize("geom", [(2, 11, 32, 64), (1, 19, 16, 128), (1, 8, 32, 64), (1, 3, 16, 128)])
+# the emulated device has 2 "compute units" = 4 resident workgroups (tests/emul/ds_device.h): the 25- and 27-tile
+# cases make every persistent workgroup walk 6-7 tiles -- top, middle and bottom row blocks, several images, a ragged
+# last block -- and the 9-image case takes the XCD-dealt tile order with idle and unevenly loaded "XCDs"
+@pytest.mark.parametrize("geom", [(2, 11, 32, 64), (1, 19, 16, 128), (1, 8, 32, 64), (1, 3, 16, 128), (5, 37, 32, 64),
+                                  (9, 20, 16, 128)])
 @pytest.mark.parametrize("out", ["f16", "f32", "planes"])
 def test_conv_block_fused_equals_two_convolutions(geom, out):
     """ds_conv_block_f16 (both 3x3 layers of a BasicBlock in one kernel, the intermediate in LDS only) must be
@@ -224,6 +228,14 @@ def test_conv_block_fused_equals_two_convolutions(geom, out):
              ptr(folds[1][1]), ptr(got), b, h, w, c, oflag, None)
     assert np.isfinite(got.astype(np.float32)).all()
     assert np.array_equal(got, ref)
+
+
+def test_conv_block_xcd_dealt_tile_order(monkeypatch):
+    """With >= 8 images and a grid of 8 k workgroups the persistent block kernel deals images to "XCDs" (workgroup w
+    serves images b = w % 8 (mod 8)): 9 images on 8 workgroups -- XCD 0 walks two images, the others one."""
+    monkeypatch.setenv("DS_EMUL_CUS", "4")
+    test_conv_block_fused_equals_two_convolutions((9, 20, 16, 128), "f16")
+    test_conv_block_fused_equals_two_convolutions((17, 9, 32, 64), "planes")
 
 
 def test_conv_block_unsupported_geometries():
