@@ -32,7 +32,17 @@ struct BlockK {
     unsigned y_bytes, x_bytes, y_plane_stride;
     const int *lens;                    // MASKED: rows of each image that belong to its utterance (zero-padded batches)
     int xcd_slots;                      // > 0: workgroups per XCD (grid = 8 * xcd_slots): image b is served by XCD b % 8
+#ifdef DS_F16_PROBE                     // tools/block_phase_probe.py builds: s_memtime stamps of the phases of each tile
+    long long *probe;
+#endif
 };
+
+#ifdef DS_F16_PROBE
+// stamp i of the workgroup's tile number `tile_no` (only tiles 0..3 are recorded): probe[(wg * 4 + tile_no) * 8 + i]
+#define DS_BLK_STAMP(i) do { if (p.probe && threadIdx.x == 0 && tile_no < 4) p.probe[((size_t)blockIdx.x * 4 + tile_no) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DS_BLK_STAMP(i) ((void)0)
+#endif
 
 #ifndef DS_BLOCK_RING
 #define DS_BLOCK_RING 6
@@ -87,9 +97,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int C = p.C;
-    const int RSB = C * 2 + 16;                                      // bytes per intermediate record
-    const int n_chunks = C / BK_CK;
+    constexpr int C = WM == 2 ? 64 : 128;                            // the two supported stages (checked by the host)
+    constexpr int RSB = C * 2 + 16;                                  // bytes per intermediate record
+    constexpr int n_chunks = C / BK_CK;
     const int n_base = wn * NSUB * 32;
     size_t lane_w = ((size_t)(n_base + l31) * 16 + 8 * lhi);
     const size_t w_kc_stride = (size_t)NT * C * 16, w_tap_stride = (size_t)C * 16;
@@ -165,13 +175,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(p.wa, 0, d) + (size_t)ns * 32 * 16);
 
-    f32x16 acc[MSA][NSUB];
-#pragma unroll
-    for (int ms = 0; ms < MSB; ++ms)
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+    f32x16 acc[MSA][NSUB];          // never cleared: the first unit of each layer accumulates into a literal zero
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     f32x4 st[NIT];
     int b = 0, r0 = 0;
@@ -184,7 +189,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
         for (int it = 0; it < NIT; ++it) st[it] = ds_buffer_load_f32x4(xbuf, g_rel[it] - x_lo);
     }
 
-    for (; t_cur < t_end; t_cur += t_step) {
+    int tile_no = 0;
+    (void)tile_no;
+    for (; t_cur < t_end; t_cur += t_step, ++tile_no) {
+        DS_BLK_STAMP(0);
         // every filter-fragment address below is tile-invariant; hoisted out of this loop they would be ~70 live 64-bit
         // values (spilled, and reloaded from scratch between the MFMAs): keep them derived where they are used
         DS_OPAQUE_VGPR(lane_w);
@@ -193,10 +201,6 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
             const int len = p.lens[b];
             h_valid = len < p.H ? len : p.H;
         }
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns)                            // (rows 0 .. MSB-1 were cleared by the epilogue)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[MSA - 1][ns][r] = 0.0f;
         // ---- (1) halo columns of both input buffers, the first chunk's pixels -> buffer 0 ----
         ds_lds_barrier();                       // the previous tile's epilogue has finished with the LDS (its stores to
                                                 // HBM stay in flight: only LDS traffic is waited for)
@@ -208,11 +212,12 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
 #pragma unroll
         for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off[it]) = st[it];
         ds_lds_barrier();
+        DS_BLK_STAMP(1);
 
         // ---- (2) first convolution: the MFMA stream of conv_mfma_f16_kernel (double-buffered tile, one side operation
         // per MFMA); its last chunk's ring refills already fetch the second layer's first filter fragments ----
-        auto run_chunk = [&](auto last_tag, int chunk, const char *buf, char *obuf) __attribute__((always_inline)) {
-            constexpr bool LAST = decltype(last_tag)::value;
+        auto run_chunk = [&](auto first_tag, auto last_tag, int chunk, const char *buf, char *obuf) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
             f16x8 a[2][MSA];
 #pragma unroll
             for (int ms = 0; ms < MSA; ++ms) {
@@ -233,15 +238,20 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
 #pragma unroll
                 for (int q = 0; q < NMFA; ++q) {
                     const int ms = q / NSUB, ns = q % NSUB;
-                    acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
+                    acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], (FIRST && u == 0) ? zero16 : acc[ms][ns]);
                     if (q & 1) {
                         const int lm = q >> 1;
+#ifndef DS_ABL_NO_AFRAG
                         if (lm < MSA && more) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + a_off[lm]);
+#endif
                     } else {
                         const int e = q >> 1;
                         if (e < NSUB) {
+#ifndef DS_ABL_NO_REFILL
                             bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+#endif
                         } else if constexpr (!LAST) {
+#ifndef DS_ABL_NO_STAGE
                             const int s = e - NSUB;
                             if (u < UL) {
                                 const int it = u * SPU + s;
@@ -250,18 +260,22 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                                 const int it = (u - (NU - UL)) * SPU + s;
                                 if (it < NIT) *(f32x4 *)(obuf + l_off[it]) = st[it];
                             }
+#endif
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
-        for (int i = 0; i + 1 < n_chunks; ++i) {
+        run_chunk(std::true_type{}, std::false_type{}, 0, lds, lds + tileA_bytes);
+        ds_lds_barrier();
+        for (int i = 1; i + 1 < n_chunks; ++i) {
             char *b0 = lds + (i & 1) * tileA_bytes, *b1 = lds + ((i & 1) ^ 1) * tileA_bytes;
-            run_chunk(std::false_type{}, i, b0, b1);
+            run_chunk(std::false_type{}, std::false_type{}, i, b0, b1);
             ds_lds_barrier();
         }
-        run_chunk(std::true_type{}, n_chunks - 1, lds + ((n_chunks - 1) & 1) * tileA_bytes, lds);
+        run_chunk(std::false_type{}, std::true_type{}, n_chunks - 1, lds + ((n_chunks - 1) & 1) * tileA_bytes, lds);
+        DS_BLK_STAMP(2);
 
         // ---- (3) hand-over: bn1 + clip, rounded to fp16, into the intermediate tile [ROWS_A][pitch] of C-channel
         // records.  Columns 0 and W + 1 and the rows outside the image are the second convolution's zero padding. ----
@@ -286,24 +300,31 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                 const int m = (wm * MSA + ms) * 32 + lpix;
                 const int i = m >> WSH, c = m & (W - 1);
                 const int row = r0 - 1 + i;                              // image row of this intermediate pixel
-                const bool inside = row >= 0 && row < h_valid;
+                const unsigned keep = (row >= 0 && row < h_valid) ? 0xFFFFFFFFu : 0u;   // outside the image: zero padding
                 char *rec = lds + (i * pitch + c + 1) * RSB;
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        f16x4 h;
+                        // two channels per v_pk_fma_f32 (the same fma per channel as the unfused epilogue), clip in f32,
+                        // one packed conversion per pair
+                        ds_u32x2 hb;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float t = fminf(fmaxf(acc[ms][ns][4 * g + j] * sca[ns][g][j] + sha[ns][g][j], 0.0f), 20.0f);
-                            h[j] = inside ? (_Float16)t : (_Float16)0.0f;
-                            if (ms < MSB) acc[ms][ns][4 * g + j] = 0.0f;     // the second layer starts at zero
+                        for (int j2 = 0; j2 < 2; ++j2) {
+                            const ds_f32x2 v = {acc[ms][ns][4 * g + 2 * j2], acc[ms][ns][4 * g + 2 * j2 + 1]};
+                            const ds_f32x2 sc2 = {sca[ns][g][2 * j2], sca[ns][g][2 * j2 + 1]};
+                            const ds_f32x2 sh2 = {sha[ns][g][2 * j2], sha[ns][g][2 * j2 + 1]};
+                            ds_f32x2 t = v * sc2 + sh2;          // (contracted to one fma per channel, like the scalar form)
+                            t[0] = fminf(fmaxf(t[0], 0.0f), 20.0f);
+                            t[1] = fminf(fmaxf(t[1], 0.0f), 20.0f);
+                            hb[j2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, ds_f16x2)) & keep;
                         }
-                        *(f16x4 *)(rec + (n_base + ns * 32 + 8 * g + 4 * lhi) * 2) = h;
+                        *(ds_u32x2 *)(rec + (n_base + ns * 32 + 8 * g + 4 * lhi) * 2) = hb;
                     }
             }
             ds_lds_barrier();                       // the intermediate tile is complete
         }
+        DS_BLK_STAMP(3);
 
         // ---- (4) second convolution: fragments straight from the intermediate tile, all chunks resident.  The ring
         // runs on into the next tile's first layer; the LAST chunk's spare slots request the residual rows of the
@@ -328,8 +349,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
             __builtin_amdgcn_sched_barrier(0);
             // LASTB is a compile-time property: a load behind a run-time condition would be branched around and waited
             // for on the spot
-            auto run_b = [&](auto last_tag, int chunk) __attribute__((always_inline)) {
-                constexpr bool LASTB = decltype(last_tag)::value;
+            auto run_b = [&](auto first_tag, auto last_tag, int chunk) __attribute__((always_inline)) {
+                constexpr bool FIRSTB = decltype(first_tag)::value, LASTB = decltype(last_tag)::value;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int cur = u & 1, slot = u % RU;
@@ -347,14 +368,18 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
 #pragma unroll
                     for (int q = 0; q < NMFB; ++q) {
                         const int ms = q / NSUB, ns = q % NSUB;
-                        acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], acc[ms][ns]);
+                        acc[ms][ns] = ds_mfma_32x32x16_f16(bq[slot][ns], a[cur][ms], (FIRSTB && u == 0) ? zero16 : acc[ms][ns]);
                         if (q & 1) {
                             const int lm = q >> 1;
+#ifndef DS_ABL_NO_AFRAG
                             if (lm < MSB) a[cur ^ 1][lm] = *(const f16x8 *)(nfrag + b_off[lm]);
+#endif
                         } else {
                             const int e = q >> 1;
                             if (e < NSUB) {
+#ifndef DS_ABL_NO_REFILL
                                 bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+#endif
                             } else if constexpr (LASTB) {                // residual rows -> registers, units NU-2-ULR ..
                                 const int ri = (u - (NU - 2 - ULR)) * SPUB + (e - NSUB);
                                 if (u >= NU - 2 - ULR && ri < NRES) {
@@ -369,13 +394,16 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                     }
                 }
             };
-            for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) run_b(std::false_type{}, chunk);
-            run_b(std::true_type{}, n_chunks - 1);
+            run_b(std::true_type{}, std::false_type{}, 0);
+            for (int chunk = 1; chunk + 1 < n_chunks; ++chunk) run_b(std::false_type{}, std::false_type{}, chunk);
+            run_b(std::false_type{}, std::true_type{}, n_chunks - 1);
         }
 
+        DS_BLK_STAMP(4);
         // ---- (5) epilogue of the block: bn2 + residual (the block's own input) + clip, as conv_mfma_f16_kernel.  At
         // its head the NEXT tile's first input chunk is requested: it arrives while this tile is written out. ----
         ds_lds_barrier();                           // every wave is done reading the intermediate tile
+        DS_BLK_STAMP(5);
         int nb = b, nr0 = r0;
         {
             const bool has_next = t_cur + t_step < t_end;
@@ -400,65 +428,68 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[ms][ns][4 * g + j];
-                        acc[ms][ns][4 * g + j] = 0.0f;                   // ready for the next tile's first layer
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
                     *(f32x4 *)(dst + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
                 }
         };
-        put_tile(0);
+        // element offset of (pixel, first channel) = pixel * y_mul + y_add: channels-last, or 16-channel planes
+        const unsigned y_mul = p.y_plane_stride ? 16u : (unsigned)C;
+        const unsigned y_add = p.y_plane_stride ? (unsigned)(col >> 4) * p.y_plane_stride + (unsigned)(col & 15) : (unsigned)col;
+        // one pass over the sub-tiles per output type (the choice is made once per tile, not once per store)
+        auto write_out = [&](auto f32_tag) __attribute__((always_inline)) {
+            constexpr bool OUT32 = decltype(f32_tag)::value;
+            put_tile(0);
 #pragma unroll
-        for (int ms = 0; ms < MSB; ++ms) {
-            const int cb = ms & 1;
-            ds_wave_sync();
-            const float *src = tb + cb * (32 * TP);
-            f32x4 tv[NRI][2];
+            for (int ms = 0; ms < MSB; ++ms) {
+                const int cb = ms & 1;
+                ds_wave_sync();
+                const float *src = tb + cb * (32 * TP);
+                f32x4 tv[NRI][2];
 #pragma unroll
-            for (int k = 0; k < NRI; ++k)
+                for (int k = 0; k < NRI; ++k)
 #pragma unroll
-                for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
-            if (ms + 1 < MSB) put_tile(ms + 1);
+                    for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
+                if (ms + 1 < MSB) put_tile(ms + 1);
 #pragma unroll
-            for (int k = 0; k < NRI; ++k) {
-                const f16x8 r8 = __builtin_bit_cast(f16x8, resv[ms][k]);
-                f32x4 o[2];
-#pragma unroll
-                for (int hq = 0; hq < 2; ++hq)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = tv[k][hq][j] * sc[hq][j] + sh[hq][j];
-                        t += (float)r8[4 * hq + j];
-                        o[hq][j] = fminf(fmaxf(t, 0.0f), 20.0f);
-                    }
-                const int m = (wm * MSB + ms) * 32 + k * PPI + my_p;
-                if (MASKED) {
-                    const bool kept = m < lin_kept;
+                for (int k = 0; k < NRI; ++k) {
+                    const f16x8 r8 = __builtin_bit_cast(f16x8, resv[ms][k]);
+                    const int m = (wm * MSB + ms) * 32 + k * PPI + my_p;
+                    const float keep = (!MASKED || m < lin_kept) ? 20.0f : 0.0f;     // MASKED rows past the extent: clip to [0, 0]
+                    f32x4 o[2];
 #pragma unroll
                     for (int hq = 0; hq < 2; ++hq)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[hq][j] = kept ? o[hq][j] : 0.0f;
-                }
-                // element offset of (pixel row, first channel): channels-last, or 16-channel planes
-                const unsigned off = (unsigned)(lin_base + m);
-                const unsigned vo = m >= lin_valid ? DS_BUFFER_OOB
-                                    : p.y_plane_stride ? (unsigned)(col >> 4) * p.y_plane_stride + off * 16u + (unsigned)(col & 15)
-                                                       : off * (unsigned)C + (unsigned)col;
-                if (out32) {
-                    const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
-                    ds_buffer_store_f32x4(ybuf, bo, o[0]);
-                    ds_buffer_store_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
-                } else {
-                    f16x8 h;
+                        for (int j2 = 0; j2 < 2; ++j2) {
+                            // two channels per packed instruction: fma (bn2), add (residual), then the clip per channel
+                            const ds_f32x2 v = {tv[k][hq][2 * j2], tv[k][hq][2 * j2 + 1]};
+                            const ds_f32x2 s2 = {sc[hq][2 * j2], sc[hq][2 * j2 + 1]}, h2 = {sh[hq][2 * j2], sh[hq][2 * j2 + 1]};
+                            const ds_f16x2 rh = {r8[4 * hq + 2 * j2], r8[4 * hq + 2 * j2 + 1]};
+                            ds_f32x2 t = v * s2 + h2;
+                            t = t + __builtin_convertvector(rh, ds_f32x2);
+                            o[hq][2 * j2] = fminf(fmaxf(t[0], 0.0f), keep);
+                            o[hq][2 * j2 + 1] = fminf(fmaxf(t[1], 0.0f), keep);
+                        }
+                    const unsigned vo = m < lin_valid ? (unsigned)(lin_base + m) * y_mul + y_add : DS_BUFFER_OOB;
+                    if constexpr (OUT32) {
+                        const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
+                        ds_buffer_store_f32x4(ybuf, bo, o[0]);
+                        ds_buffer_store_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
+                    } else {
+                        ds_u32x4 hb;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        h[j] = (_Float16)o[0][j];
-                        h[4 + j] = (_Float16)o[1][j];
+                        for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                            for (int j2 = 0; j2 < 2; ++j2)
+                                hb[2 * hq + j2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                                                                                   ds_f32x2{o[hq][2 * j2], o[hq][2 * j2 + 1]}, ds_f16x2));
+                        ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, hb));
                     }
-                    ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
                 }
             }
-        }
+        };
+        if (out32) write_out(std::true_type{});
+        else write_out(std::false_type{});
+        DS_BLK_STAMP(6);
         b = nb;
         r0 = nr0;
     }
@@ -472,6 +503,12 @@ static size_t block_lds_bytes(int W, int C, int waves) {
 }
 
 }  // namespace
+
+#ifdef DS_F16_PROBE
+static long long *g_blk_probe = nullptr;
+extern "C" void ds_block_set_probe(long long *buf) { g_blk_probe = buf; }
+#endif
+
 
 // 1 if ds_conv_block_f16 handles this block geometry (the shallow stages: W = 32 with 64 channels, W = 16 with 128)
 extern "C" int ds_conv_block_f16_supported(int B, int H, int W, int C) {
@@ -504,6 +541,9 @@ static int conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_
     k.y_bytes = (unsigned)(n * ((flags & DS_EPI_OUT_F32) ? 4 : 2));
     k.y_plane_stride = (flags & DS_EPI_OUT_PLANES16) ? (unsigned)((long long)B * H * W * 16) : 0u;
     k.lens = lens;
+#ifdef DS_F16_PROBE
+    k.probe = g_blk_probe;
+#endif
     // persistent workgroups: as many as the chip holds at once (two 2-wave workgroups per CU: one wave per SIMD, 65 KB
     // of LDS each); batches of >= 8 images that fill them are dealt to the XCDs by image (see the kernel)
     const int resident = 2 * ds_cu_count();

@@ -56,6 +56,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // to 2^-17 |x|), each pair packed into one dword with ONE packed conversion (v_cvt_pk_bf16_f32); same bits as the
 // scalar (__bf16)v / (__bf16)(v - (float)hi) sequence
 typedef float ds_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ds_f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 ds_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ds_split_bf16x2(float a, float b, unsigned &hi, unsigned &lo) {
     const ds_bf16x2 h = __builtin_convertvector(ds_f32x2{a, b}, ds_bf16x2);
