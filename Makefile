@@ -16,7 +16,7 @@ all: $(LIB)
 # the fp16 convolution's chunk body is one fully unrolled stream of up to 500 MFMAs with a side operation after
 # each; above the default size limit `#pragma unroll` silently stops unrolling, and the register arrays indexed by
 # the loop counter (filter ring, fragment buffers) would then live in scratch memory
-$(OBJD)/conv_mfma_f16_k%.o $(OBJD)/conv_block_f16.o: FLAGS += -mllvm -pragma-unroll-threshold=1000000
+$(OBJD)/conv_mfma_f16_k%.o $(OBJD)/conv_mfma_f16_pk%.o $(OBJD)/conv_block_f16.o: FLAGS += -mllvm -pragma-unroll-threshold=1000000
 
 $(OBJD)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJD)

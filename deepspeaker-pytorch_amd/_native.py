@@ -15,6 +15,7 @@ DS_EPI_AFFINE, DS_EPI_RESIDUAL, DS_EPI_CLIP, DS_EPI_STATS, DS_EPI_OUT_F32, DS_EP
 DS_EPI_OUT_PLANES16, DS_CONV_IN_PLANES16 = 256, 512
 DS_CONV_HINT_SINGLE_BUFFER = 64
 DS_CONV_HINT_CHUNK16 = 128
+DS_CONV_HINT_NO_PERSIST = 1024
 DS_CONV_CK = 8
 
 

@@ -6,7 +6,7 @@
 #include <algorithm>
 #include "ds_common.h"
 
-#include "conv_mfma_f16_kernel.h"
+#include "conv_mfma_f16_pkernel.h"
 
 namespace {
 
@@ -210,6 +210,31 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
     return DS_OK;
 }
 
+// The persistent kernel (conv_mfma_f16_pkernel.h) takes the common geometry: double-buffered tile, an M tile that is
+// one block of rows of one image or a run of whole images, staging items within the register budget (no split-K: the
+// caller checks).  On success the plan's grid / nit / lin are those of the persistent launch.
+static bool plan_persistent(PlanH &pl, const ds_conv_shape *s) {
+    const ConvKH &k = pl.k;
+    if (!pl.db || !(k.NI == 1 || k.segs_per_img == 1)) return false;
+    const TileCfgH &cf = kCfgH[pl.cfg];
+    int e_rows = k.rows_in;
+    if (k.NI > 1) {
+        const int lo = k.dh_min < 0 ? -k.dh_min : 0, hi = std::min(k.H - k.dh_min, k.rows_in);
+        e_rows = hi > lo ? hi - lo : 1;
+    }
+    const int nit_p = ds_ceil_div(k.NI * e_rows * s->W * (pl.ck / 8), cf.NTHR);
+    // more than 8 items per thread: only as a row block whose width divides the pixels a pass of the workgroup covers
+    // (the kernel then derives every item's offsets from the first one's: LIN in conv_mfma_f16_pkernel.h)
+    const int pix_per_pass = cf.NTHR / (pl.ck / 8);
+    const int lin = k.NI == 1 && pix_per_pass % s->W == 0;
+    if (nit_p > 16 || (nit_p > 8 && !lin)) return false;
+    pl.lin = lin;
+    pl.nit = nit_p;
+    const int resident = (256 / cf.NTHR) * ds_cu_count();        // one wave per SIMD
+    if (pl.grid > resident) pl.grid = resident;
+    return true;
+}
+
 }  // namespace
 
 extern "C" int ds_pack_conv_weight_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, void *stream) {
@@ -250,9 +275,21 @@ extern "C" int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flag
     int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER),
                       (flags & (DS_CONV_IN_PLANES16 | DS_CONV_HINT_CHUNK16)) != 0);
     if (rc != DS_OK) return rc;
+    if (s->KS == 5 && pl.ck == 32 && !(flags & (DS_CONV_HINT_SINGLE_BUFFER | DS_CONV_HINT_NO_PERSIST))) {   // as ds_conv_fwd_f16
+        PlanH p32 = pl, p16;
+        if (plan_persistent(p32, s) && p32.nit > 8 && plan_f16(p16, s, true, true) == DS_OK && p16.ck == 16) {
+            PlanH q = p16;
+            if (plan_persistent(q, s) && q.nit <= 8) pl = p16;
+        }
+    }
     const TileCfgH &cf = kCfgH[pl.cfg];
     out8[0] = cf.MT; out8[1] = cf.NTILE; out8[2] = pl.k.RT; out8[3] = pl.k.NI;
-    out8[4] = pl.grid; out8[5] = (int)pl.lds_bytes; out8[6] = cf.NTHR; out8[7] = pl.db * 1000 + (pl.ck == 16 ? 100 : 0) + pl.nit;
+    const int tiles = pl.grid;                                   // out8[4]: tiles (= workgroups of the one-tile kernel)
+    const bool pers = !(flags & DS_CONV_HINT_NO_PERSIST) && plan_persistent(pl, s);
+    out8[4] = tiles; out8[5] = (int)pl.lds_bytes; out8[6] = cf.NTHR;
+    // out8[7]: 10000 if the persistent kernel takes this plan (large launches; small ones may still be split-K)
+    //          + 1000 if double-buffered + 100 for 16-channel chunks + staging items per thread
+    out8[7] = (pers ? 10000 : 0) + pl.db * 1000 + (pl.ck == 16 ? 100 : 0) + pl.nit;
     return DS_OK;
 }
 
@@ -293,6 +330,17 @@ static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w
     DS_REQUIRE(!out_planes || !(flags & DS_EPI_OUT_F32), DS_ERR_UNSUPPORTED);
     int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER), in_planes || (flags & DS_CONV_HINT_CHUNK16) != 0);
     if (rc != DS_OK) return rc;
+    if (s->KS == 5 && pl.ck == 32 && !(flags & (DS_CONV_HINT_SINGLE_BUFFER | DS_CONV_HINT_NO_PERSIST))) {
+        // A 5x5 layer whose 32-channel chunks need more than 8 staging items per thread runs the persistent kernel with
+        // 16 items in flight -- past what the register file holds next to the 160 accumulators (a few are spilled and
+        // reloaded between the MFMAs).  The same layer in 16-channel chunks needs half the items: measured 187 vs
+        // 200 us on the 128 -> 256 layer of the bench (tools/f16_layer_ab.py).  Same arithmetic, same results.
+        PlanH p32 = pl, p16;
+        if (plan_persistent(p32, s) && p32.nit > 8 && plan_f16(p16, s, true, true) == DS_OK && p16.ck == 16) {
+            PlanH q = p16;
+            if (plan_persistent(q, s) && q.nit <= 8) pl = p16;
+        }
+    }
     DS_REQUIRE(!in_planes || pl.ck == 16, DS_ERR_UNSUPPORTED);
     ConvKH &k = pl.k;
     k.x_pix_stride = in_planes ? 16 : s->Cin;
@@ -316,7 +364,12 @@ static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w
 #ifdef DS_F16_PROBE
     k.probe = g_f16_probe;
 #endif
-    if (s->KS == 3) { if (pl.db) ds_f16_launch_k3db(pl, stream); else ds_f16_launch_k3sb(pl, stream); }
+    const bool persistent = k.n_splits == 1 && !(flags & DS_CONV_HINT_NO_PERSIST) && plan_persistent(pl, s);
+    if (persistent) {
+        if (s->KS == 3) ds_f16_launch_pk3(pl, stream);
+        else if (pl.ck == 16) ds_f16_launch_pk5c16(pl, stream);
+        else ds_f16_launch_pk5(pl, stream);
+    } else if (s->KS == 3) { if (pl.db) ds_f16_launch_k3db(pl, stream); else ds_f16_launch_k3sb(pl, stream); }
     else if (pl.ck == 16) ds_f16_launch_k5c16(pl, stream);
     else            { if (pl.db) ds_f16_launch_k5db(pl, stream); else ds_f16_launch_k5sb(pl, stream); }
     rc = ds_last_launch_error();

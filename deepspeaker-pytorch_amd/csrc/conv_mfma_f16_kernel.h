@@ -22,6 +22,14 @@
 // all 64 banks with one ds_read_b128 each.
 constexpr int ds_f16_record_bytes(int ck) { return ck * 2 + 16; }
 
+// filter ring depth in (k-step, tap) units for the 3x3 / 5x5 kernels with 32-channel chunks (must divide 18 / 50)
+#ifndef DS_F16_RING_K3
+#define DS_F16_RING_K3 6
+#endif
+#ifndef DS_F16_RING_K5
+#define DS_F16_RING_K5 5
+#endif
+
 struct ConvKH {
     const _Float16 *x;              // [B, H, W, Cin] fp16 channels-last
     const _Float16 *w;              // packed [Cin/16][tap][Cout][16]
@@ -61,6 +69,7 @@ struct ConvKH {
 
 struct PlanH {
     int cfg, grid, n_mtiles, nit, db, ck;
+    int lin = 0;                    // persistent kernel: staging offsets derived from the first item's (row blocks)
     size_t lds_bytes;
     ConvKH k;
 };
@@ -87,12 +96,6 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     constexpr int IPP = CKH / 8;                    // 16-byte staging items per pixel
     constexpr int PSH = ds_f16_record_bytes(CKH);
     constexpr int NU = KPT * NT;                    // (k-step, tap) units per chunk
-#ifndef DS_F16_RING_K3
-#define DS_F16_RING_K3 6
-#endif
-#ifndef DS_F16_RING_K5
-#define DS_F16_RING_K5 5
-#endif
     constexpr int RU = (KS == 3) ? (KPT == 2 ? DS_F16_RING_K3 : 9) : (KPT == 2 ? DS_F16_RING_K5 : 5);   // filter ring, in units; NU % RU == 0
     constexpr int NMF = MSUB * NSUB;                // MFMAs per unit
     constexpr bool PREF = DB || NIT <= 16;          // next chunk's pixels ride in registers through the taps

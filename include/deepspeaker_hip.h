@@ -55,6 +55,8 @@ extern "C" {
                                     record is one line, of which a chunk would use a quarter)                       */
 #define DS_CONV_HINT_SINGLE_BUFFER 64  /* fp16 convolution: plan with one LDS pixel tile (tuning / test hint)  */
 #define DS_CONV_HINT_CHUNK16      128  /* fp16 5x5 convolution: plan with 16-channel chunks (tuning / test hint)  */
+#define DS_CONV_HINT_NO_PERSIST  1024  /* fp16 convolution: one tile per workgroup even where the persistent kernel
+                                        * applies (tuning / test hint: the two kernels are bit-identical)          */
 
 #define DS_CONV_CK      8   /* input-channel chunk of the packed weight layout */
 

@@ -69,6 +69,49 @@ def test_conv_f16_raw(case):
     assert rel_err(y, ref) < 2e-6, describe(lib, case)
 
 
+# Larger batches of the bench geometries: on the emulated device (2 "compute units" = 2-4 resident workgroups) every
+# persistent workgroup walks many tiles -- top / middle / bottom row blocks, ragged last tiles, several n tiles.
+PERSIST_CASES = [
+    (3, 64, 64, 27, 32, 3, 1),               # row blocks of one image (linear item offsets), ragged last block
+    (9, 32, 128, 20, 8, 3, 1),               # one image per tile
+    (11, 64, 128, 10, 4, 3, 1),              # several whole images per tile (item tables), ragged last tile
+    (3, 64, 128, 43, 16, 5, 2),              # 5x5 stride 2 row blocks, odd height
+    (7, 32, 256, 9, 8, 5, 2),                # 5x5 stride 2, multi-image tiles, two n tiles
+    (2, 32, 128, 100, 4, 3, 1),              # a tall narrow map: 32-row blocks
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES)
+@pytest.mark.parametrize("hint", [0, "chunk16"])
+def test_conv_f16_persistent_equals_one_tile_kernel(case, hint):
+    """conv_mfma_f16_pkernel (persistent workgroups) against conv_mfma_f16_kernel (one tile per workgroup): bit-identical
+    raw accumulators, and bit-identical fp16 output of the full epilogue."""
+    from deepspeaker_pytorch_amd._native import DS_CONV_HINT_NO_PERSIST
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    if hint == "chunk16" and k != 5:
+        pytest.skip("16-channel chunks exist for the 5x5 layers only")
+    hf = DS_CONV_HINT_CHUNK16 if hint else 0
+    out8 = (ctypes.c_int * 8)()
+    lib.call("ds_conv_f16_plan_describe_hinted", ctypes.byref(ConvShape(b, h, w, ci, co, k, s)), hf, out8)
+    taken = out8[7] >= 10000
+    assert taken, list(out8)
+    rs = np.random.RandomState(17 + sum(case))
+    x = (np.abs(rs.randn(b, ci, h, w)) * 2).astype(np.float16).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, co).astype(np.float32)
+    shift = rs.randn(co).astype(np.float32)
+    ho, wo = O.conv_out_size(h, k, s, k // 2), O.conv_out_size(w, k, s, k // 2)
+    res = (np.abs(rs.randn(b, co, ho, wo)) * 8).astype(np.float16).astype(np.float32)
+    for flags, args in ((DS_EPI_OUT_F32, ()), (DS_EPI_AFFINE | DS_EPI_RESIDUAL | DS_EPI_CLIP, (scale, shift, res)),
+                        (DS_EPI_AFFINE | DS_EPI_CLIP, (scale, shift))):
+        ya = run_conv_f16(lib, x, wt, s, flags | hf, *args)
+        yb = run_conv_f16(lib, x, wt, s, flags | hf | DS_CONV_HINT_NO_PERSIST, *args)
+        assert np.isfinite(ya).all() and np.array_equal(ya, yb), (flags, list(out8))
+    ref = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    assert rel_err(run_conv_f16(lib, x, wt, s, DS_EPI_OUT_F32 | hf), ref) < 2e-6
+
+
 @pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[3]])
 def test_conv_f16_epilogue(case):
     """affine + residual + clip, fp16 store (round to nearest even of the f32 epilogue value)"""
