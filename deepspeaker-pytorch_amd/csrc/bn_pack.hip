@@ -297,6 +297,25 @@ extern "C" int ds_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H
     return ds_last_launch_error();
 }
 
+// Scheduling slots of the persistent kernels (ds_device.h).  The emulator build has no HIP runtime: host memory.
+unsigned *ds_sched_slot() {
+    static unsigned *slots = nullptr;
+    static unsigned seq = 0;
+    if (!slots) {
+#ifdef DS_EMULATED
+        static unsigned host_slots[DS_SCHED_SLOTS * DS_SCHED_WORDS];
+        slots = host_slots;
+#else
+        void *p = nullptr;
+        if (hipMalloc(&p, DS_SCHED_SLOTS * DS_SCHED_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, DS_SCHED_SLOTS * DS_SCHED_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
+        slots = (unsigned *)p;
+#endif
+    }
+    const unsigned k = __atomic_fetch_add(&seq, 1u, __ATOMIC_RELAXED) % DS_SCHED_SLOTS;
+    return slots + (size_t)k * DS_SCHED_WORDS;
+}
+
 extern "C" int ds_version(void) { return 300; }   // 300: round-3 ABI (+ split grouped BatchNorm backward for data parallelism, grouped f64 sums)
 
 extern "C" const char *ds_error_string(int code) {

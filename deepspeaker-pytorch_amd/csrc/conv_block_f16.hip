@@ -32,6 +32,8 @@ struct BlockK {
     unsigned y_bytes, x_bytes, y_plane_stride;
     const int *lens;                    // MASKED: rows of each image that belong to its utterance (zero-padded batches)
     int xcd_slots;                      // > 0: workgroups per XCD (grid = 8 * xcd_slots): image b is served by XCD b % 8
+    unsigned *sched;                    // tile-scheduling slot (ds_device.h): next[queue], done
+    int sched_lds;                      // byte offset of the LDS word tile indices are passed through
 #ifdef DS_F16_PROBE                     // tools/block_phase_probe.py builds: s_memtime stamps of the phases of each tile
     long long *probe;
 #endif
@@ -113,9 +115,16 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
     // that XCD serves images b = 8 j + (w % 8), so the row blocks of an image share one L2.
     const int xcd = (int)blockIdx.x & 7, slot0 = (int)blockIdx.x >> 3;
     const int my_imgs = p.xcd_slots > 0 ? (p.B - xcd + 7) / 8 : 0;
+    // the first tile of a workgroup is its (per-queue) index; every further one is drawn from the queue's counter, one
+    // tile ahead of its use (t_next is known at the top of tile t_cur)
     int t_cur = p.xcd_slots > 0 ? slot0 : (int)blockIdx.x;
-    const int t_step = p.xcd_slots > 0 ? p.xcd_slots : (int)gridDim.x;
+    const int t_static = p.xcd_slots > 0 ? p.xcd_slots : (int)gridDim.x;     // tiles handed out by index
     const int t_end = p.xcd_slots > 0 ? my_imgs * p.tiles_per_img : p.n_tiles;
+    unsigned *const q_next = p.sched + (p.xcd_slots > 0 ? xcd : 0);
+    int *const sched_word = (int *)(lds + p.sched_lds);
+    if (tid == 0) *sched_word = t_static + (int)ds_atomic_inc(q_next);
+    __syncthreads();
+    int t_next = ds_uniform(*sched_word);
     const float rcp_tpi = 1.0f / (float)p.tiles_per_img;
     auto tile_of = [&](int t, int &b, int &r0) {
         const int im = ds_div_small(t, p.tiles_per_img, rcp_tpi);
@@ -191,8 +200,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
 
     int tile_no = 0;
     (void)tile_no;
-    for (; t_cur < t_end; t_cur += t_step, ++tile_no) {
+    for (; t_cur < t_end; ++tile_no) {
         DS_BLK_STAMP(0);
+        int t_drawn = 0;                        // the tile after next, drawn now, published before the epilogue's barrier
+        if (tid == 0) t_drawn = t_static + (int)ds_atomic_inc(q_next);
         // every filter-fragment address below is tile-invariant; hoisted out of this loop they would be ~70 live 64-bit
         // values (spilled, and reloaded from scratch between the MFMAs): keep them derived where they are used
         DS_OPAQUE_VGPR(lane_w);
@@ -402,13 +413,15 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
         DS_BLK_STAMP(4);
         // ---- (5) epilogue of the block: bn2 + residual (the block's own input) + clip, as conv_mfma_f16_kernel.  At
         // its head the NEXT tile's first input chunk is requested: it arrives while this tile is written out. ----
+        if (tid == 0) *sched_word = t_drawn;
         ds_lds_barrier();                           // every wave is done reading the intermediate tile
         DS_BLK_STAMP(5);
+        const int t_after = ds_uniform(*sched_word);
         int nb = b, nr0 = r0;
         {
-            const bool has_next = t_cur + t_step < t_end;
+            const bool has_next = t_next < t_end;
             if (has_next) {
-                tile_of(t_cur + t_step, nb, nr0);
+                tile_of(t_next, nb, nr0);
                 stage_window(nb, nr0, xbuf, x_lo);
             } else {
                 xbuf = ds_make_buffer(p.x, 0u);     // nothing in range: the loads return zeros
@@ -492,6 +505,12 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
         DS_BLK_STAMP(6);
         b = nb;
         r0 = nr0;
+        t_cur = t_next;
+        t_next = t_after;
+    }
+    // the last workgroup to leave hands the slot back zeroed (no counter is touched after a workgroup's own `done`)
+    if (tid == 0 && ds_atomic_inc(p.sched + DS_SCHED_DONE) == gridDim.x - 1) {
+        for (int i = 0; i <= DS_SCHED_DONE; ++i) p.sched[i] = 0u;
     }
 }
 
@@ -550,6 +569,9 @@ static int conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_
     int grid = k.n_tiles < resident ? k.n_tiles : resident;
     k.xcd_slots = 0;
     if (B >= 8 && grid == resident && resident % 8 == 0) k.xcd_slots = resident / 8;
+    k.sched = ds_sched_slot();
+    DS_REQUIRE(k.sched != nullptr, DS_ERR_UNSUPPORTED);
+    k.sched_lds = (int)block_lds_bytes(W, C, 2) - 16;
     if (C == 64) {          // W = 32: 2 x 1 waves, 12 x 32 x 4 items over 128 threads
         if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 12, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);
         else DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 12>), grid, 128, block_lds_bytes(W, C, 2), stream, k);

@@ -56,6 +56,8 @@ struct ConvKH {
     int tiles, n_splits, chunks_per_split;
     float *partial;
     unsigned partial_elems;
+    unsigned *sched;                // persistent kernel: tile-scheduling slot (ds_device.h)
+    int sched_lds;                  // ... and the byte offset of the LDS word tile indices are passed through
 #ifdef DS_F16_PROBE                 // tools/f16_phase_probe.py builds: s_memtime stamps of the phases of each workgroup
     long long *probe;
 #endif

@@ -178,8 +178,14 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         ta.lin_valid = rowblock ? (p.Ho - sblk * p.RT < p.RT ? p.Ho - sblk * p.RT : p.RT) * p.Wo : live * pix_per_seg;
     };
 
+    // the first tile of a workgroup is its index; every further one is drawn from the slot's counter, one tile ahead of
+    // its use (t_next is known at the top of tile t_cur: the filter ring runs on into its fragments)
     int t_cur = (int)blockIdx.x;
-    const int t_step = (int)gridDim.x, t_end = p.tiles;
+    const int t_static = (int)gridDim.x, t_end = p.tiles;
+    int *const sched_word = (int *)(lds + p.sched_lds);
+    if (tid == 0) *sched_word = t_static + (int)ds_atomic_inc(p.sched);
+    __syncthreads();
+    int t_next = ds_uniform(*sched_word);
     TileAt ta = {0, 0, 0, 0};
     const char *xb_base = (const char *)p.x;
     unsigned xb_bytes = 0, x_lo = 0;
@@ -204,7 +210,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     f32x16 acc[MSUB][NSUB];         // never cleared: the first unit of a tile accumulates into a literal zero
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    for (; t_cur < t_end; t_cur += t_step) {
+    while (t_cur < t_end) {
+        int t_drawn = 0;                        // the tile after next, drawn now, published before the epilogue's barrier
+        if (tid == 0) t_drawn = t_static + (int)ds_atomic_inc(p.sched);
         // every filter-fragment address below is tile-invariant; hoisted out of this loop they would be dozens of live
         // 64-bit values (spilled, and reloaded from scratch between the MFMAs): keep them derived where they are used
         DS_OPAQUE_VGPR(lane_w);
@@ -218,8 +226,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         TileAt tn = ta;
         const char *nb_base = xb_base;
         unsigned nb_bytes = 0, n_lo = 0;
-        const bool has_next = t_cur + t_step < t_end;
-        if (has_next) tile_at(t_cur + t_step, tn, nb_base, nb_bytes, n_lo);
+        const bool has_next = t_next < t_end;
+        if (has_next) tile_at(t_next, tn, nb_base, nb_bytes, n_lo);
         size_t lane_wn = ((size_t)(tn.tile_n * NTILE + wn * NSUB * 32 + l31) * 16 + 8 * lhi);
         DS_OPAQUE_VGPR(lane_wn);
 
@@ -324,7 +332,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
 
         // ---- (3) epilogue (see conv_mfma_f16_kernel.h: transposed accumulators turned around through wave-private LDS
         // buffers, whole pixel rows stored).  At its head the NEXT tile's first input chunk is requested. ----
+        if (tid == 0) *sched_word = t_drawn;
         ds_lds_barrier();                       // every wave is done reading the pixel tile
+        const int t_after = ds_uniform(*sched_word);
         // (16 items in flight through the epilogue do not fit the register file next to it: those kernels request the
         // next chunk at the epilogue's end instead -- it then has the tile-top barrier and the halo zeroing to arrive in)
         constexpr bool EARLY_PREFETCH = NIT <= 8;
@@ -419,6 +429,13 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         xb_bytes = nb_bytes;
         x_lo = n_lo;
         lane_w = lane_wn;
+        t_cur = t_next;
+        t_next = t_after;
+    }
+    // the last workgroup to leave hands the slot back zeroed (no counter is touched after a workgroup's own `done`)
+    if (tid == 0 && ds_atomic_inc(p.sched + DS_SCHED_DONE) == gridDim.x - 1) {
+        p.sched[0] = 0u;
+        p.sched[DS_SCHED_DONE] = 0u;
     }
 }
 

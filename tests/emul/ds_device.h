@@ -188,4 +188,10 @@ static inline int ds_cu_count() {
     return n > 0 ? n : 2;
 }
 
+// dynamic tile scheduling of the persistent kernels (see csrc/ds_device.h): blocks run on several OS threads here
+constexpr int DS_SCHED_SLOTS = 64, DS_SCHED_WORDS = 16, DS_SCHED_DONE = 8;
+static inline unsigned ds_atomic_inc(unsigned *p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
+unsigned *ds_sched_slot();          // bn_pack.hip
+static inline int ds_uniform(int v) { return v; }
+
 static inline int ds_last_launch_error() { return 0; }

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <functional>
 
+#define DS_EMULATED 1
 #define __global__
 #define __device__
 #define __host__
