@@ -304,11 +304,12 @@ __global__ void __launch_bounds__(256) avgpool_time_bwd_kernel(const float *gpoo
 //      conflict-free padded columns out), so every candidate element is read from L2 once per 8 anchors
 //      and the anchor values are LDS broadcasts.  Per-tile winners go to a workspace; a second kernel
 //      folds the tiles in ascending order.  Fixed scan / reduction order => deterministic.
-constexpr int MINE_A = 8;          // anchors per workgroup
+constexpr int MINE_A_MAX = 8;      // anchors per workgroup: 8, or 4 / 2 when 8 would leave the chip under-filled
 constexpr int MINE_K = 32;         // dimensions per staged slab
 constexpr int MINE_C = 256;        // candidates per workgroup
 constexpr int MINE_P = MINE_K + 4;  // candidate-tile row pitch in floats (16-byte aligned, conflict-free)
 
+template <int MINE_A>
 __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor, const float *d_p,
                                                             const long long *anchor_label, const float *cand,
                                                             const long long *cand_label, float *partial,
@@ -361,15 +362,23 @@ __global__ void __launch_bounds__(256) mine_semihard_kernel(const float *anchor,
             const f32x4 c = *(const f32x4 *)(ctile + tid * MINE_P + k);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const f32x4 a03 = *(const f32x4 *)(arow + (k0 + k + u) * MINE_A);
-                const f32x4 a47 = *(const f32x4 *)(arow + (k0 + k + u) * MINE_A + 4);
                 const f32x2 cc = {c[u], c[u]};
-                const f32x2 d0 = f32x2{a03[0], a03[1]} - cc, d1 = f32x2{a03[2], a03[3]} - cc;
-                const f32x2 d2 = f32x2{a47[0], a47[1]} - cc, d3 = f32x2{a47[2], a47[3]} - cc;
-                acc2[0] = d0 * d0 + acc2[0];
-                acc2[1] = d1 * d1 + acc2[1];
-                acc2[2] = d2 * d2 + acc2[2];
-                acc2[3] = d3 * d3 + acc2[3];
+                const float *ar = arow + (k0 + k + u) * MINE_A;
+                if constexpr (MINE_A >= 4) {
+                    const f32x4 a03 = *(const f32x4 *)ar;
+                    const f32x2 d0 = f32x2{a03[0], a03[1]} - cc, d1 = f32x2{a03[2], a03[3]} - cc;
+                    acc2[0] = d0 * d0 + acc2[0];
+                    acc2[1] = d1 * d1 + acc2[1];
+                } else {
+                    const f32x2 d0 = *(const f32x2 *)ar - cc;
+                    acc2[0] = d0 * d0 + acc2[0];
+                }
+                if constexpr (MINE_A == 8) {
+                    const f32x4 a47 = *(const f32x4 *)(ar + 4);
+                    const f32x2 d2 = f32x2{a47[0], a47[1]} - cc, d3 = f32x2{a47[2], a47[3]} - cc;
+                    acc2[2] = d2 * d2 + acc2[2];
+                    acc2[3] = d3 * d3 + acc2[3];
+                }
             }
         }
     }
@@ -476,12 +485,24 @@ extern "C" int ds_mine_semihard_f32(const float *anchor, const float *d_p, const
     DS_REQUIRE(N > 0 && M > 0 && D > 0 && D <= 8192, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(D % 4 == 0 && DS_ALIGNED16(cand) && DS_ALIGNED16(anchor), DS_ERR_ALIGNMENT);
     const float eps = (float)(1e-4 / (double)D);
-    const size_t tile_words = 256 * MINE_P > 4 * MINE_A * 256 ? 256 * MINE_P : 4 * MINE_A * 256;
-    const size_t lds = ((size_t)MINE_A * D + tile_words) * 4;
+    const int n_ctiles = ds_ceil_div(M, MINE_C);
+    // 8 anchors per workgroup re-use every staged candidate slab 8 times; when that leaves fewer workgroups than the chip
+    // has CUs (256 anchors x 768 candidates: 96), 4 or 2 anchors per workgroup fill it instead (same sums, same order)
+    int A = MINE_A_MAX;
+    while (A > 2 && ds_ceil_div(N, A) * n_ctiles < ds_cu_count()) A /= 2;
+    const size_t tile_words = 256 * MINE_P > 4 * A * 256 ? 256 * MINE_P : 4 * A * 256;
+    const size_t lds = ((size_t)A * D + tile_words) * 4;
     DS_REQUIRE(lds <= 64 * 1024, DS_ERR_BAD_SHAPE);
-    const int n_agroups = ds_ceil_div(N, MINE_A), n_ctiles = ds_ceil_div(M, MINE_C);
-    DS_LAUNCH(mine_semihard_kernel, n_agroups * n_ctiles, 256, lds, stream, anchor, d_p, anchor_label, cand,
-              cand_label, workspace, N, M, D, eps, n_agroups);
+    const int n_agroups = ds_ceil_div(N, A);
+    if (A == 8)
+        DS_LAUNCH(mine_semihard_kernel<8>, n_agroups * n_ctiles, 256, lds, stream, anchor, d_p, anchor_label, cand, cand_label,
+                  workspace, N, M, D, eps, n_agroups);
+    else if (A == 4)
+        DS_LAUNCH(mine_semihard_kernel<4>, n_agroups * n_ctiles, 256, lds, stream, anchor, d_p, anchor_label, cand, cand_label,
+                  workspace, N, M, D, eps, n_agroups);
+    else
+        DS_LAUNCH(mine_semihard_kernel<2>, n_agroups * n_ctiles, 256, lds, stream, anchor, d_p, anchor_label, cand, cand_label,
+                  workspace, N, M, D, eps, n_agroups);
     int rc = ds_last_launch_error();
     if (rc) return rc;
     DS_LAUNCH(mine_merge_kernel, ds_ceil_div(N, 256), 256, 0, stream, (const float *)workspace, out_index, out_dist, N,
