@@ -36,8 +36,8 @@ PEAK_TFLOPS = {"f32": 157.3,                # MI355X_MICROARCH.md: v_mfma_f32_32
 KERNEL_NAME = {"f32": "conv_mfma_f32_kernel (implicit-GEMM 3x3/5x5, all tile shapes)",
                "bf16x3": "conv_mfma_bf16_kernel<X3=true> (3 bf16 MFMAs per product: hi*hi + hi*lo + lo*hi)",
                "bf16": "conv_mfma_bf16_kernel<X3=false>",
-               "f16": "conv_mfma_f16_kernel + conv_block3x3_f16_kernel (one v_mfma_f32_32x32x16_f16 per product, fp16 "
-                      "activations in HBM; the BasicBlocks of stages 1-2 as one kernel each)"}
+               "f16": "conv_mfma_f16_pkernel + conv_block3x3_f16_kernel (persistent workgroups; one v_mfma_f32_32x32x16_f16 per "
+                      "product, fp16 activations in HBM; the BasicBlocks of stages 1-2 as one kernel each)"}
 ARITH = {"f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations",
          "bf16x3": "split-operand bf16 MFMA: x = hi + lo (two bf16), product = hi*hi + hi*lo + lo*hi on "
                    "v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 activations; embeddings 6e-6 from the reference",

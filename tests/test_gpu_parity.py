@@ -378,10 +378,12 @@ def test_conv_backward_kernels_vs_oracle(dev, case):
     assert torch.equal(gw3, _wgrad(eng, shp, xh, gyh, (co, ci, k, k), x3=True))     # deterministic
 
 
-def test_mining_kernel_vs_oracle(dev):
+# (anchors, candidates): 8 / 4 / 2 anchors per workgroup (the launch picks what fills the chip); 256 x 6144 is the
+# cross-GPU search of BASELINE configs[2]: 256 local anchors against the all-gathered embeddings of 8 ranks
+@pytest.mark.parametrize("N,M", [(64, 1536), (256, 768), (256, 6144), (300, 70000 // 64), (5, 257)])
+def test_mining_kernel_vs_oracle(dev, N, M):
     from deepspeaker_pytorch_amd.mining import mine_semihard_negatives
-    rs = np.random.RandomState(9)
-    N, M = 64, 1536
+    rs = np.random.RandomState(9 + N + M)
     a = rs.randn(N, 512).astype(np.float32)
     p = a + rs.randn(N, 512).astype(np.float32) * 0.9
     cand = rs.randn(M, 512).astype(np.float32)

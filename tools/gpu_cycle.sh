@@ -22,6 +22,8 @@ for w in $WHAT; do
     dpprof) (cd /tmp && export TMPDIR=/tmp && MASTER_ADDR=127.0.0.1 MASTER_PORT=29572 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/dpprof -- python $R/bench.py --train --force-collectives --steps 6 --warmup 2 --repeats 0 --no-cpu-baseline > $OUT/dpprof.log 2>&1); echo "dpprof rc=$?"
           python tools/dp_gaps.py $(find $OUT/dpprof -name "*.db") > $OUT/dp_gaps.md 2>$OUT/dp_gaps.err; head -3 $OUT/dp_gaps.md; python tools/timeline.py $(find $OUT/dpprof -name "*.db") adagrad | head -12 ;;
     slots) for c in 4 8 16 32; do timeout 300 python bench.py --no-secondary --no-cpu-baseline --refine-slots $c --repeats 2 > $OUT/slots_$c.json 2> $OUT/slots_$c.err; python -c "import json;d=json.load(open('$OUT/slots_$c.json'));print('slots',$c,d['value'],d['ms_per_step'],d['repeats_ms_per_step'],d['roofline']['achieved'],d['refine'])"; done ;;
+    extras) timeout 300 python tools/mine_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/mine_probe.txt
+            timeout 300 python tools/latency_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.txt ;;
     pmc) timeout 1200 tools/pmc_run.sh $TAG/pmc --no-secondary; python tools/pmc_summary.py $OUT/pmc kernel 52 > $OUT/pmc_summary.md 2> $OUT/pmc_summary.err; head -60 $OUT/pmc_summary.md ;;
     *) echo "unknown step $w" ;;
   esac
