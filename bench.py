@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--refine-slots", type=int, default=0,
                     help="smallest number of near-tie re-embedding slots of the fp16 path (0: the library default, "
                          "mining.REFINE_CAP_MIN); the policy grows them from observed counts either way")
+    ap.add_argument("--ablate", default="", help="diagnosis only (the line is then NOT the contract's workload): comma list of "
+                    "'refine' (filter without the near-tie re-embedding) and 'mine' (no semi-hard search)")
     ap.add_argument("--repeats", type=int, default=3,
                     help="after the contract's timed region (W warm-up + K steps -> `value`), time the same K-step region "
                          "this many more times and report median / min / max ms per step (box-to-box and DVFS spread)")
@@ -127,6 +129,7 @@ def main():
                          "backward, gradient all-reduce, fused Adagrad): the step with collectives on its critical path")
     args = ap.parse_args()
 
+    ablate = set(a for a in args.ablate.split(",") if a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,9 +266,11 @@ def main():
                     h_lab = dist.all_gather_into_tensor(lab_glob, labels_loc, async_op=True)
                 # filter (train_triplet.py:251-262) with the near ties of the fp16 forward re-embedded at f32-class
                 # precision; the loss call below re-uses the same distance pass
-                sel = select_triplets(*embs, margin=0.1, model=model, inputs=data)
+                sel = select_triplets(*embs, margin=0.1, model=None if "refine" in ablate else model, inputs=data)
                 loss = loss_fn.forward(*embs)
-                if multi:
+                if "mine" in ablate:
+                    mined = None
+                elif multi:
                     with torch.cuda.stream(side_stream_of(dev)):    # the SIDE stream waits for the gathers: this one
                         h_emb.wait()                                # never stalls on xGMI
                         h_lab.wait()
@@ -280,7 +285,7 @@ def main():
 
         elapsed, prof, again = timed(step, steps, warmup, repeats)
         refine = None
-        if precision == "f16":
+        if precision == "f16" and "refine" not in ablate:
             # what the near-tie refinement did in the steps just timed (read AFTER the timed regions: the step itself
             # never synchronises; an overflow would re-embed the whole batch when the selection is read)
             last = sels[-steps:]
@@ -421,7 +426,7 @@ def main():
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic",
+            "data": "synthetic" + (" (ABLATED: " + ",".join(sorted(ablate)) + " -- not the contract workload)" if ablate else ""),
             "config": {"workload": "BASELINE configs[1]: full DeepSpeaker ResCNN (64/128/256/512) eval forward + "
                                    "triplet loss + filter (near ties refined) + semi-hard negative search over the "
                                    "(all-gathered) batch, 256 triplets = 768 x [1,160,64] utterances per GPU per step",
