@@ -284,6 +284,25 @@ def main():
             return loss, sel, mined
 
         elapsed, prof, again = timed(step, steps, warmup, repeats)
+        # The same kernels with NOTHING else on the chip: forwards only, back to back (no loss / filter / refinement /
+        # search, hence no side stream).  Inside the step the near-tie refinement and the semi-hard search of step k run
+        # on a side stream next to the forward of step k + 1 and take CUs from it, so the per-launch durations measured
+        # above include that contention; this is the rate of the kernels themselves (reported as roofline.isolated,
+        # never as `value`).
+        isolated = None
+        if repeats > 0 and not multi and not args.split_apn:
+            with torch.no_grad():
+                for _ in range(3):
+                    model(data_all)
+                fence()
+                eng.profile = []
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    model(data_all)
+                fence()
+                iso_ms = (time.perf_counter() - t0) / 10 * 1e3
+                iso_prof, eng.profile = eng.profile, None
+            isolated = (iso_ms, iso_prof)
         refine = None
         if precision == "f16" and "refine" not in ablate:
             # what the near-tie refinement did in the steps just timed (read AFTER the timed regions: the step itself
@@ -294,7 +313,7 @@ def main():
             refine = {"band": REFINE_BAND, "slots": [s_.amb_cap for s_ in last][-1], "near_ties_mean": round(sum(ties) / len(ties), 2),
                       "near_ties_max": max(ties), "overflow_steps": sum(int(s_.refine_overflow) for s_ in last),
                       "steps": len(last), "calls_total": pol.calls, "overflows_total": pol.overflows}
-        return elapsed, prof, again, refine
+        return elapsed, prof, again, refine, isolated
 
     def measure_train(precision, steps, warmup, repeats=0):
         """The training step of the triplet regime (train_triplet.py:215-224): train-mode forwards of a / p / n
@@ -403,14 +422,14 @@ def main():
             dist.destroy_process_group()
         return
 
-    elapsed, prof, again, refine = measure(args.precision, args.steps, args.warmup, args.repeats)
+    elapsed, prof, again, refine, isolated = measure(args.precision, args.steps, args.warmup, args.repeats)
 
     secondary = {}
     if world == 1 and not args.no_secondary:
         for prec in ("bf16x3", "f32"):                              # untimed comparisons: the f32-class paths
             if prec != args.precision:
                 k2 = max(3, args.steps // 2)
-                e2, p2, _, _ = measure(prec, k2, 2)
+                e2, p2, _, _, _ = measure(prec, k2, 2)
                 secondary[prec] = (e2, p2, k2)
         kt = max(3, args.steps // 4)
         et, _, _, _ = measure_train("bf16x3", kt, 2)
@@ -444,6 +463,14 @@ def main():
                                           "max": round(max(again), 3), "n": len(again)}
         if refine is not None:
             out["refine"] = refine
+        if isolated is not None:
+            iso_ms, iso_prof = isolated
+            ir = roofline_of(args.precision, iso_prof, 10)
+            out["roofline"]["isolated"] = {
+                "what": "the same launches with nothing else on the chip (10 forwards back to back, no side stream)",
+                "forward_ms": round(iso_ms, 3), "achieved": ir["achieved"], "frac": ir["frac"],
+                "conv_ms_per_forward": ir["conv_ms_per_step"], "by_layer_tflops": ir["by_layer_tflops"],
+                "worst_kernel": ir.get("worst_kernel")}
         for prec, (e2, p2, k2) in secondary.items():
             out[prec + "_path"] = {"value": round(emb_per_step * k2 / e2, 1), "unit": "embeddings/s", "steps": k2,
                                    "roofline": roofline_of(prec, p2, k2)}

@@ -396,8 +396,12 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                                 if (u >= NU - 2 - ULR && ri < NRES) {
                                     const int rms = ri / NRI, rk = ri % NRI;
                                     const int m = (wm * MSB + rms) * 32 + rk * PPI + my_p;
+#ifdef DS_ABL_NO_RES
+                                    resv[rms][rk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
                                     resv[rms][rk] = ds_buffer_load_f32x4(rbuf, m < lin_valid ? (unsigned)((lin_base + m) * C + col) * 2u
                                                                                             : DS_BUFFER_OOB);
+#endif
                                 }
                             }
                         }
@@ -495,6 +499,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                             for (int j2 = 0; j2 < 2; ++j2)
                                 hb[2 * hq + j2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
                                                                                    ds_f32x2{o[hq][2 * j2], o[hq][2 * j2 + 1]}, ds_f16x2));
+#ifdef DS_ABL_NO_STORE
+                        if (hb[0] == 0x12345678u)               // (keeps the values live)
+#endif
                         ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, hb));
                     }
                 }

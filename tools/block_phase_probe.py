@@ -22,7 +22,7 @@ OUT = os.path.join(ROOT, "tools", "_ab", f"libds_blockprobe_{NAME}.so")
 def build():
     objd = os.path.join(ROOT, "tools", "_ab", f"obj_blockprobe_{NAME}")
     os.makedirs(objd, exist_ok=True)
-    srcs = [os.path.join(CSRC, "conv_block_f16.hip")]       # self-contained; filters are packed by the stock library
+    srcs = [os.path.join(CSRC, f) for f in ("conv_block_f16.hip", "bn_pack.hip")]   # (bn_pack: the scheduling slots); filters are packed by the stock library
 
     def cc(s):
         o = os.path.join(objd, os.path.basename(s)[:-4] + ".o")
