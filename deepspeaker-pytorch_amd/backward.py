@@ -62,21 +62,21 @@ def _bn_bwd_group(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
         return gy, gz, gg, gb
     if not dp:
         for g in range(G):
-            mean, invstd, _ = stats[g]
+            mean, invstd = stats[g][0], stats[g][1]
             eng.lib.call("ds_bn_bwd_f32", eng._p(m(g1, g)), eng._p(m(g2, g)), eng._p(m(act, g)), eng._p(m(z, g)),
                          eng._p(mean), eng._p(invstd), eng._p(gamma.detach()), eng._p(m(gy, g)), eng._p(partial[g]),
                          eng._p(coef[g]), eng._p(gg_all[g]), eng._p(gb_all[g]), eng._p(m(gz, g)), n_pix, c, st)
     else:
         sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=dev)
         for g in range(G):
-            mean, invstd, _ = stats[g]
+            mean, invstd = stats[g][0], stats[g][1]
             eng.lib.call("ds_bn_bwd_reduce_f32", eng._p(m(g1, g)), eng._p(m(g2, g)), eng._p(m(act, g)), eng._p(m(z, g)),
                          eng._p(mean), eng._p(invstd), eng._p(m(gy, g)), eng._p(partial[g]), n_pix, c, st)
             eng.lib.call("ds_partial_sum_f64", eng._p(partial[g]), rows, eng._p(sums[g]), c, st)
         sums[:, 2 * c] = float(n_pix)
         reducer.all_reduce_sum_(sums)                               # every member of this layer in ONE collective
         for g in range(G):
-            mean, invstd, _ = stats[g]
+            mean, invstd = stats[g][0], stats[g][1]
             eng.lib.call("ds_bn_bwd_apply_f32", eng._p(sums[g]), 0, eng._p(m(gy, g)), eng._p(m(z, g)), eng._p(mean),
                          eng._p(invstd), eng._p(gamma.detach()), eng._p(coef[g]), eng._p(gg_all[g]), eng._p(gb_all[g]),
                          eng._p(m(gz, g)), n_pix, c, st)
@@ -92,7 +92,7 @@ def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     dgamma / dbeta then already are the global gradients."""
     if isinstance(stats, list):
         return _bn_bwd_group(eng, g1, g2, act, z, stats, gamma, reducer)
-    mean, invstd, _ = stats
+    mean, invstd = stats[0], stats[1]
     c = z.shape[-1]
     n_pix = z.numel() // c
     dev = z.device
@@ -118,6 +118,54 @@ def _bn_bwd(eng: Engine, g1, g2, act, z, stats, gamma, reducer=None):
     eng.lib.call("ds_bn_bwd_f32", eng._p(g1), eng._p(g2), eng._p(act), eng._p(z), eng._p(mean), eng._p(invstd),
                  eng._p(gamma.detach()), eng._p(gy), eng._p(partial), eng._p(coef), eng._p(gg), eng._p(gb),
                  eng._p(gz), n_pix, c, eng._stream(z))
+    return gy, gz, gg, gb
+
+
+FUSE_DGRAD_BN_BWD = True       # module switch for A/B runs and tests of the unfused sequence
+
+
+def _dgrad_bn_bwd(eng: Engine, shp: ConvShape, gz_up, bank_bf16, g2, z, stats, gamma, reducer=None):
+    """`_dgrad` of a 3x3 layer followed by `_bn_bwd` of the BatchNorm + clipped-ReLU layer it feeds, with the first half
+    of the latter inside the data-gradient kernel's epilogue (ds_conv_dgrad_bnbwd_bf16): the gradient never makes the
+    round trip through HBM between the two, and the mask comes from the layer's own pre-activation `z` instead of a
+    third tensor.  Returns (gy, gz, dgamma, dbeta) like `_bn_bwd`, or None where the fused kernel does not apply (a tile
+    of the launch would straddle two members, statistics not laid out as tables): the caller then runs the two steps."""
+    if not FUSE_DGRAD_BN_BWD or bank_bf16 is None:
+        return None
+    members = stats if isinstance(stats, list) else [stats]
+    G = len(members)
+    c = z.shape[-1]
+    step = c * 4
+    if any(len(m_) < 4 for m_ in members):
+        return None
+    if not all(members[g][k].data_ptr() == members[0][k].data_ptr() + g * step for g in range(G) for k in range(4)):
+        return None
+    rows = eng.lib.raw("ds_conv_dgrad_bnbwd_bf16_rows")(ctypes.byref(shp), G)
+    if rows <= 0:
+        return None
+    dev = z.device
+    n_pix = (z.numel() // c) // G
+    st = eng._stream(z)
+    mean, invstd, sc, sh = members[0]
+    gy, gz = torch.empty_like(z), torch.empty_like(z)
+    partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=dev)
+    coef = torch.empty((G, 3 * c), dtype=torch.float32, device=dev)
+    member_sums = torch.empty((2, G, c), dtype=torch.float32, device=dev)
+    gg, gb = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
+    eng.lib.call("ds_conv_dgrad_bnbwd_bf16", ctypes.byref(shp), eng._p(gz_up), eng._p(bank_bf16[0]), eng._p(bank_bf16[1]),
+                 eng._p(g2), eng._p(z), eng._p(mean), eng._p(invstd), eng._p(sc), eng._p(sh), G, eng._p(gy),
+                 eng._p(partial), st)
+    if reducer is not None and reducer.active:
+        sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=dev)
+        eng.lib.call("ds_partial_sum_f64_group", eng._p(partial), rows, eng._p(sums), n_pix, c, G, st)
+        reducer.all_reduce_sum_(sums)                               # every member of this layer in ONE collective
+        eng.lib.call("ds_bn_bwd_group_apply_f32", eng._p(sums), eng._p(gy), eng._p(z), eng._p(mean), eng._p(invstd),
+                     eng._p(gamma.detach()), eng._p(coef), eng._p(member_sums), eng._p(gg), eng._p(gb), eng._p(gz),
+                     n_pix, c, G, st)
+    else:
+        eng.lib.call("ds_bn_bwd_group_finish_f32", eng._p(partial), rows, eng._p(gy), eng._p(z), eng._p(mean),
+                     eng._p(invstd), eng._p(gamma.detach()), eng._p(coef), eng._p(member_sums), eng._p(gg), eng._p(gb),
+                     eng._p(gz), n_pix, c, G, st)
     return gy, gz, gg, gb
 
 
@@ -289,18 +337,26 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         grads[f"model.layer{i}.0.conv2.weight"] = lane.run(
             lambda gz=gz: _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3), x3=x3,
                                  out=buckets.views[f"model.layer{i}.0.conv2.weight"]), gz)
-        g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad, pw.stages[s].l_conv2_dgrad_bf16 if x3 else None)
-        # y = clip(bn1(conv1(r)))                  (model.py:69-71)
+        # y = clip(bn1(conv1(r)))                  (model.py:69-71): conv2's data gradient + bn1's backward
         name = f"model.layer{i}.0.bn1"
-        _, gz, gg, gbeta = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
+        bank = pw.stages[s].l_conv2_dgrad_bf16 if x3 else None
+        fused = _dgrad_bn_bwd(eng, shp3, gz, bank, None, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
+        if fused is None:
+            g_y = _dgrad(eng, shp3, gz, pw.stages[s].l_conv2_dgrad, bank)
+            fused = _bn_bwd(eng, g_y, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
+        _, gz, gg, gbeta = fused
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv1.weight"] = lane.run(
             lambda gz=gz: _wgrad(eng, shp3, a_act, gz, (c, c, 3, 3), x3=x3,
                                  out=buckets.views[f"model.layer{i}.0.conv1.weight"]), gz)
-        g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad, pw.stages[s].l_conv1_dgrad_bf16 if x3 else None)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv-path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
-        _, gz, gg, gbeta = _bn_bwd(eng, g_r, g_out, a_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
+        bank = pw.stages[s].l_conv1_dgrad_bf16 if x3 else None
+        fused = _dgrad_bn_bwd(eng, shp3, gz, bank, g_out, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
+        if fused is None:
+            g_r = _dgrad(eng, shp3, gz, pw.stages[s].l_conv1_dgrad, bank)
+            fused = _bn_bwd(eng, g_r, g_out, a_act, saved.raws[name], saved.stats[name], bn_weights[name], reducer)
+        _, gz, gg, gbeta = fused
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
         shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)

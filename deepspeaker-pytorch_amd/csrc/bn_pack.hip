@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *x, const flo
         const int c4 = (int)(i % cvec);
         f32x4 v = ((const f32x4 *)x)[i];
         const f32x4 sc = ((const f32x4 *)scale)[c4], sh = ((const f32x4 *)shift)[c4];
-        v = v * sc + sh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ds_bn_affine(v[j], sc[j], sh[j]);
         if (flags & DS_EPI_RESIDUAL) v += ((const f32x4 *)res)[i];
         if (flags & DS_EPI_CLIP) {
 #pragma unroll
@@ -751,6 +752,32 @@ extern "C" int ds_bn_bwd_group_apply_f32(const double *sums, const float *gy, co
     float *gg_m = member_sums, *gb_m = member_sums + (size_t)G * C;
     DS_LAUNCH(bn_bwd_from_sums_group_kernel, ds_ceil_div(C, 256) * G, 256, 0, stream, sums, gamma, invstd, gg_m, gb_m,
               coef, C, ds_ceil_div(C, 256));
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(bn_member_sum_kernel, ds_ceil_div(C, 256), 256, 0, stream, (const float *)gg_m, (const float *)gb_m, ggamma,
+              gbeta, G, C);
+    rc = ds_last_launch_error();
+    if (rc) return rc;
+    const long long n_vec_member = n_pix * (C / 4);
+    DS_LAUNCH(bn_bwd_apply_group_kernel, grid_for(n_vec_member * G), 256, 0, stream, gy, z, mean, invstd,
+              (const float *)coef, gz, n_vec_member, G, C);
+    return ds_last_launch_error();
+}
+
+// The second half of ds_bn_bwd_group_f32 alone, for partial sums that were produced elsewhere (the data-gradient kernel
+// whose epilogue is the reduction: ds_conv_dgrad_bnbwd_bf16): n_partial rows of [C][2] per member, consecutive.
+extern "C" int ds_bn_bwd_group_finish_f32(const float *partial, int n_partial, const float *gy, const float *z,
+                                          const float *mean, const float *invstd, const float *gamma, float *coef,
+                                          float *member_sums, float *ggamma, float *gbeta, float *gz, long long n_pix,
+                                          int C, int G, void *stream) {
+    DS_REQUIRE(partial && gy && z && mean && invstd && gamma && coef && member_sums && ggamma && gbeta && gz, DS_ERR_NULL);
+    DS_REQUIRE(n_partial > 0 && n_pix > 0 && G > 0 && G <= 64 && C >= 4 && (C % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(gy) && DS_ALIGNED16(z) && DS_ALIGNED16(gz) && DS_ALIGNED16(mean) && DS_ALIGNED16(invstd) &&
+                   DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
+    const int n_cgroups = ds_ceil_div(C, FOLD_C);
+    float *gg_m = member_sums, *gb_m = member_sums + (size_t)G * C;
+    DS_LAUNCH(bn_bwd_finalize_group_kernel, n_cgroups * G, 256, FOLD_R * FOLD_C * 2 * sizeof(double), stream, partial,
+              n_partial, (double)n_pix, gamma, invstd, gg_m, gb_m, coef, C, n_cgroups);
     int rc = ds_last_launch_error();
     if (rc) return rc;
     DS_LAUNCH(bn_member_sum_kernel, ds_ceil_div(C, 256), 256, 0, stream, (const float *)gg_m, (const float *)gb_m, ggamma,

@@ -248,6 +248,8 @@ extern "C" int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const vo
     pl.k.x = x; pl.k.w_hi = (const __bf16 *)w_hi; pl.k.w_lo = (const __bf16 *)w_lo; pl.k.y = y;
     pl.k.scale = scale; pl.k.shift = shift; pl.k.res = residual; pl.k.stats = stats_partial;
     pl.k.flags = flags;
+    pl.k.bn_z = pl.k.bn_mean = pl.k.bn_invstd = pl.k.bn_msc = pl.k.bn_msh = nullptr;
+    pl.k.bn_mtiles = 1;
     if (s->KS == 3) { if (x3) launch_b<3, true>(pl, stream); else launch_b<3, false>(pl, stream); }
     else            { if (x3) launch_b<5, true>(pl, stream); else launch_b<5, false>(pl, stream); }
     return ds_last_launch_error();
@@ -325,6 +327,8 @@ extern "C" int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const
         pl.k.scale = pl.k.shift = pl.k.res = nullptr;
         pl.k.stats = nullptr;
         pl.k.flags = 0;
+        pl.k.bn_z = pl.k.bn_mean = pl.k.bn_invstd = pl.k.bn_msc = pl.k.bn_msh = nullptr;
+        pl.k.bn_mtiles = 1;
         launch_b<3, true>(pl, stream);
         rc = ds_last_launch_error();
         if (rc) return rc;
@@ -332,3 +336,50 @@ extern "C" int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const
     return DS_OK;
 }
 
+
+// The 3x3 stride-1 data gradient FUSED with the first half of the BatchNorm backward of the layer it feeds
+// (autograd of clip(bn(conv(.))) under loss.backward(), reference train_triplet.py:223 over model.py:69-75,188-203):
+//   gy = (dgrad(gz_up) [+ g2]) * [0 < z * mask_scale + mask_shift < 20],  partial[tile] = { sum gy, sum gy * xhat }
+// `s` is the FORWARD shape of the convolution whose data gradient this is (as ds_conv_dgrad_bf16); z / gy / g2 are
+// [B,H,W,Cin]; the batch consists of G members with their own statistics (tables [G][Cin]); the M tiles of the launch
+// must not straddle members (ds_conv_dgrad_bnbwd_bf16_rows reports the partial rows per member, or an error).
+static int plan_bnbwd(PlanB &pl, const ds_conv_shape *s, int G) {
+    DS_REQUIRE(s, DS_ERR_NULL);
+    DS_REQUIRE(s->KS == 3 && s->stride == 1 && G > 0 && s->B % G == 0, DS_ERR_UNSUPPORTED);
+    ds_conv_shape t = *s;
+    t.Cin = s->Cout;
+    t.Cout = s->Cin;
+    int rc = plan_bf16(pl, &t, true);
+    if (rc != DS_OK) return rc;
+    const long long segs_per_member = (long long)(s->B / G) * pl.k.segs_per_img;
+    DS_REQUIRE(segs_per_member % pl.k.NI == 0, DS_ERR_UNSUPPORTED);
+    pl.k.bn_mtiles = (int)(segs_per_member / pl.k.NI);
+    return DS_OK;
+}
+
+extern "C" int ds_conv_dgrad_bnbwd_bf16_rows(const ds_conv_shape *s, int G) {
+    PlanB pl;
+    int rc = plan_bnbwd(pl, s, G);
+    return rc == DS_OK ? pl.k.bn_mtiles : rc;
+}
+
+extern "C" int ds_conv_dgrad_bnbwd_bf16(const ds_conv_shape *s, const float *gz_up, const void *w_hi, const void *w_lo,
+                                        const float *g2, const float *z, const float *mean, const float *invstd,
+                                        const float *mask_scale, const float *mask_shift, int G, float *gy,
+                                        float *partial, void *stream) {
+    DS_REQUIRE(s && gz_up && w_hi && w_lo && z && mean && invstd && mask_scale && mask_shift && gy && partial, DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(gz_up) && DS_ALIGNED16(w_hi) && DS_ALIGNED16(w_lo) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) &&
+                   DS_ALIGNED16(mean) && DS_ALIGNED16(invstd) && DS_ALIGNED16(mask_scale) && DS_ALIGNED16(mask_shift) &&
+                   (!g2 || DS_ALIGNED16(g2)), DS_ERR_ALIGNMENT);
+    PlanB pl;
+    int rc = plan_bnbwd(pl, s, G);
+    if (rc != DS_OK) return rc;
+    pl.k.x = gz_up; pl.k.w_hi = (const __bf16 *)w_hi; pl.k.w_lo = (const __bf16 *)w_lo; pl.k.y = gy;
+    pl.k.scale = pl.k.shift = nullptr;
+    pl.k.res = g2;
+    pl.k.stats = partial;
+    pl.k.flags = DS_EPI_STATS | (g2 ? DS_EPI_RESIDUAL : 0);
+    pl.k.bn_z = z; pl.k.bn_mean = mean; pl.k.bn_invstd = invstd; pl.k.bn_msc = mask_scale; pl.k.bn_msh = mask_shift;
+    ds_bf16_launch_k3x3g(pl, stream);
+    return ds_last_launch_error();
+}

@@ -28,6 +28,11 @@ struct ConvKB {
     int flags;
     unsigned y_bytes;               // size of y (and of the residual) in bytes, for the buffer descriptors
     int OS, OH0, OW0;               // output pixel (r, c) of the tile grid lands at (OS*r + OH0, OS*c + OW0) of y
+    // BNB epilogue (ds_conv_dgrad_bnbwd_bf16): this launch is a data gradient whose output is dL/d(activation) of a
+    // BatchNorm + clipped-ReLU layer; z = that layer's convolution output (same shape as y), tables [G][Cout] per
+    // member of the batch, bn_mtiles = M tiles per member
+    const float *bn_z, *bn_mean, *bn_invstd, *bn_msc, *bn_msh;
+    int bn_mtiles;
 };
 
 struct PlanB {
@@ -41,6 +46,7 @@ void ds_bf16_launch_k3x3(const PlanB &pl, void *stream);
 void ds_bf16_launch_k5x3(const PlanB &pl, void *stream);
 void ds_bf16_launch_k3x1(const PlanB &pl, void *stream);
 void ds_bf16_launch_k5x1(const PlanB &pl, void *stream);
+void ds_bf16_launch_k3x3g(const PlanB &pl, void *stream);      // 3x3 bf16x3 with the BatchNorm-backward epilogue
 
 #ifdef DS_BF16_KERNEL_TU
 namespace {
@@ -49,7 +55,9 @@ namespace {
 // PREF: the next chunk's pixels are loaded into registers BEFORE this chunk's matrix work and converted
 // / written to LDS after it (small tiles); otherwise they are loaded right after the barrier (big
 // tiles, where 16 slots would not fit next to the accumulators).
-template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3, int NIT, bool PREF>
+// BNB: the epilogue is the first half of a BatchNorm backward (see ConvKB): y = (acc [+ res]) * [0 < z*msc+msh < 20]
+// and the per-tile partial sums are { sum y, sum y * xhat }, xhat = (z - mean) * invstd, instead of { sum, sum sq }.
+template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3, int NIT, bool PREF, bool BNB = false>
 __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const ConvKB p) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = MSUB * WM * 32;
@@ -430,6 +438,17 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     float ps1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ps2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     unsigned voff[2][NRI];
     f32x4 resv[2][NRI];
+    f32x4 zv[BNB ? 2 : 1][BNB ? NRI : 1];
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 mu4 = zero4, is4 = zero4, msc4 = zero4, msh4 = zero4;
+    const ds_buffer zbuf = ds_make_buffer(BNB ? (const void *)p.bn_z : (const void *)p.y, BNB ? p.y_bytes : 0u);
+    if constexpr (BNB) {
+        const size_t mo = (size_t)(tile_m / p.bn_mtiles) * p.Cout + col;      // this tile's member of the batch
+        mu4 = *(const f32x4 *)(p.bn_mean + mo);
+        is4 = *(const f32x4 *)(p.bn_invstd + mo);
+        msc4 = *(const f32x4 *)(p.bn_msc + mo);
+        msh4 = *(const f32x4 *)(p.bn_msh + mo);
+    }
     auto fetch_rows = [&](int ms, int buf) {    // byte offsets and residual rows of sub-tile ms
 #pragma unroll
         for (int k = 0; k < NRI; ++k) {
@@ -438,6 +457,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         }
 #pragma unroll
         for (int k = 0; k < NRI; ++k) resv[buf][k] = ds_buffer_load_f32x4(rbuf, voff[buf][k]);
+        if constexpr (BNB) {
+#pragma unroll
+            for (int k = 0; k < NRI; ++k) zv[buf][k] = ds_buffer_load_f32x4(zbuf, voff[buf][k]);
+        }
     };
     fetch_rows(0, 0);
 #pragma unroll
@@ -461,6 +484,17 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = v[j];
+                if constexpr (BNB) {
+                    // the layer's clipped-ReLU mask from its own pre-activation (the fma bn_apply_kernel evaluates)
+                    const float zz = zv[cb][k][j];
+                    const float am = ds_bn_affine(zz, msc4[j], msh4[j]);
+                    t += resv[cb][k][j];
+                    t = (am > 0.0f && am < 20.0f) ? t : 0.0f;
+                    ps1[j] += live ? t : 0.0f;
+                    ps2[j] += live ? t * ((zz - mu4[j]) * is4[j]) : 0.0f;
+                    v[j] = t;
+                    continue;
+                }
                 if (flags & DS_EPI_STATS) {
                     ps1[j] += live ? t : 0.0f;
                     ps2[j] += live ? t * t : 0.0f;
@@ -503,39 +537,39 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
     }
 }
 
-template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3>
+template <int KS, int MSUB, int NSUB, int WM, int WN, bool X3, bool BNB = false>
 static void launch_nit_b(const PlanB &pl, void *stream) {
     if (pl.nit <= 4)
-        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 4, true>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 4, true, BNB>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
     else if (pl.nit <= 8)      // register-prefetch the next chunk where the accumulators leave room (MSUB <= 4)
-        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 8, (MSUB <= 4)>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 8, (MSUB <= 4), BNB>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
     else
-        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 16, false>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH((conv_mfma_bf16_kernel<KS, MSUB, NSUB, WM, WN, X3, 16, false, BNB>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
 }
 
-template <int KS, int MSUB, int WM, int WN>
+template <int KS, int MSUB, int WM, int WN, bool BNB = false>
 static void launch_big_b(const PlanB &pl, void *stream) {
     constexpr int NTHR = WM * WN * 64;
     if (pl.nit <= 8)
-        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 8, true>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 8, true, BNB>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
     else if (pl.nit <= 16)
-        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 16, true>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 16, true, BNB>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
     else
-        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 32, false>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((conv_mfma_bf16_kernel<KS, MSUB, 2, WM, WN, true, 32, false, BNB>), pl.grid, NTHR, pl.lds_bytes, stream, pl.k);
 }
 
-template <int KS, bool X3>
+template <int KS, bool X3, bool BNB = false>
 static void launch_b(const PlanB &pl, void *stream) {
-    if (pl.cfg == 0) launch_nit_b<KS, 2, 1, 2, 2, X3>(pl, stream);
-    else if (pl.cfg == 1) launch_nit_b<KS, 5, 1, 1, 4, X3>(pl, stream);
-    else if (pl.cfg == 2) launch_nit_b<KS, 4, 1, 2, 2, X3>(pl, stream);
+    if (pl.cfg == 0) launch_nit_b<KS, 2, 1, 2, 2, X3, BNB>(pl, stream);
+    else if (pl.cfg == 1) launch_nit_b<KS, 5, 1, 1, 4, X3, BNB>(pl, stream);
+    else if (pl.cfg == 2) launch_nit_b<KS, 4, 1, 2, 2, X3, BNB>(pl, stream);
     else if constexpr (X3) {                    // 160x64 register tiles, opt-in LDS sizes
-        if (pl.cfg == 3) launch_big_b<KS, 5, 1, 2>(pl, stream);
-        else if (pl.cfg == 4) launch_big_b<KS, 5, 1, 4>(pl, stream);
-        else if (pl.cfg == 5) launch_big_b<KS, 5, 2, 2>(pl, stream);
-        else if (pl.cfg == 6) launch_big_b<KS, 5, 2, 1>(pl, stream);
-        else if (pl.cfg == 7) launch_big_b<KS, 4, 1, 2>(pl, stream);
-        else launch_big_b<KS, 4, 1, 4>(pl, stream);
+        if (pl.cfg == 3) launch_big_b<KS, 5, 1, 2, BNB>(pl, stream);
+        else if (pl.cfg == 4) launch_big_b<KS, 5, 1, 4, BNB>(pl, stream);
+        else if (pl.cfg == 5) launch_big_b<KS, 5, 2, 2, BNB>(pl, stream);
+        else if (pl.cfg == 6) launch_big_b<KS, 5, 2, 1, BNB>(pl, stream);
+        else if (pl.cfg == 7) launch_big_b<KS, 4, 1, 2, BNB>(pl, stream);
+        else launch_big_b<KS, 4, 1, 4, BNB>(pl, stream);
     }
 }
 

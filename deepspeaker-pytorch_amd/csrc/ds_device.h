@@ -173,6 +173,11 @@ unsigned *ds_sched_slot();          // bn_pack.hip
 // a value every lane holds identically, as a scalar (tile indices read back from LDS)
 __device__ __forceinline__ int ds_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// BatchNorm's normalise-and-shift of one element, z * scale + shift as ONE fused multiply-add: the train-mode forward
+// (bn_apply_kernel) and the kernels that re-derive its clipped-ReLU mask from z in the backward pass (the BNB epilogue
+// of conv_mfma_bf16_kernel) must round identically.
+__device__ __forceinline__ float ds_bn_affine(float z, float scale, float shift) { return __builtin_fmaf(z, scale, shift); }
+
 static inline int ds_last_launch_error() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -76,7 +76,7 @@ class SavedForward:
     x: torch.Tensor
     acts: Dict[str, torch.Tensor] = field(default_factory=dict)      # post-activation tensors
     raws: Dict[str, torch.Tensor] = field(default_factory=dict)      # raw conv outputs (BN inputs)
-    stats: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = field(default_factory=dict)
+    stats: Dict[str, Tuple[torch.Tensor, ...]] = field(default_factory=dict)     # (mean, invstd, scale, shift), or a list of them per member
     pooled: Optional[torch.Tensor] = None
     fc_out: Optional[torch.Tensor] = None
     dims: List[Tuple[int, int]] = field(default_factory=list)
@@ -292,13 +292,16 @@ class Engine:
         the ranks first, so every rank normalises with the statistics of the global batch."""
         c = bn.weight.numel()
         dev = stats.device
-        if out is not None:                     # (mean, invstd) destinations, e.g. rows of a per-member table
-            mean, invstd = out
+        if out is not None:                     # (mean, invstd[, scale, shift]) destinations, e.g. rows of per-member tables
+            mean, invstd = out[0], out[1]
         else:
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty_like(mean)
-        scale = torch.empty(c, dtype=torch.float32, device=dev)
-        shift = torch.empty_like(scale)
+        if out is not None and len(out) == 4:
+            scale, shift = out[2], out[3]
+        else:
+            scale = torch.empty(c, dtype=torch.float32, device=dev)
+            shift = torch.empty_like(scale)
         if reducer is not None and reducer.active:
             sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
             self.lib.call("ds_partial_sum_f64", self._p(stats), stats.shape[0], self._p(sums), c, self._stream(stats))
@@ -654,19 +657,19 @@ class Engine:
             mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             a = self.bn_apply(z, sc, sh, None, DS_EPI_CLIP)
             if save:
-                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, (mean, invstd, sc), a
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, (mean, invstd, sc, sh), a
             name = f"model.layer{i}.0.bn1"
             z, st = conv_s(a, sw.l_conv1, sw.l_conv1_bf16, B, h, w, c, c, 3, 1)
             mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             y = self.bn_apply(z, sc, sh, None, DS_EPI_CLIP)
             if save:
-                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, (mean, invstd, sc), y
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, (mean, invstd, sc, sh), y
             name = f"model.layer{i}.0.bn2"
             z, st = conv_s(y, sw.l_conv2, sw.l_conv2_bf16, B, h, w, c, c, 3, 1)
             mean, invstd, sc, sh = self.bn_finalize(st, count, bns[name], reducer=reducer)
             a = self.bn_apply(z, sc, sh, a, DS_EPI_CLIP | DS_EPI_RESIDUAL)
             if save:
-                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, (mean, invstd, sc), a
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, (mean, invstd, sc, sh), a
                 saved.dims.append((h, w))
         e = self.tail(a, pw, saved)
         return e, saved
@@ -703,7 +706,7 @@ class Engine:
             layer (24 per step instead of 72).
 
         Returns ([embeddings per member], SavedForward of the concatenated batch; `stats[name]` is a list with one
-        (mean, invstd, scale) per member)."""
+        (mean, invstd, scale, shift) per member)."""
         if precision not in ("f32", "bf16x3"):
             raise ValueError("training runs in f32 or bf16x3")
         G = len(xs)
@@ -771,31 +774,29 @@ class Engine:
                                       self._stream(z))
                     sums[:, 2 * c] = float(count)
                 reducer.all_reduce_sum_(sums)                     # all members of this layer in ONE collective
-                # mean / invstd as rows of one [G][C] table each (as below): the backward pass stays grouped
-                mean_all = torch.empty((G, c), dtype=torch.float32, device=dev)
-                invstd_all = torch.empty((G, c), dtype=torch.float32, device=dev)
+                # mean / invstd / scale / shift as rows of one [G][C] table each (as below): the backward pass stays grouped
+                mean_all, invstd_all, sc_all, sh_all = torch.empty((4, G, c), dtype=torch.float32, device=dev).unbind(0)
                 for g in range(G):                                # running statistics update in call order
-                    mean, invstd = mean_all[g], invstd_all[g]
-                    sc, sh = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(2))
+                    mean, invstd, sc, sh = mean_all[g], invstd_all[g], sc_all[g], sh_all[g]
                     self.lib.call("ds_bn_stats_from_sums_f32", self._p(sums[g]), 0, self._p(bn.weight.detach()),
                                   self._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM, self._p(bn.running_mean),
                                   self._p(bn.running_var), self._p(mean), self._p(invstd), self._p(sc), self._p(sh), c,
                                   self._stream(z))
                     per.append((mean, invstd, sc, sh))
             else:
-                # the members' mean / invstd as rows of one [G][C] tensor each: the backward pass then runs every
-                # BatchNorm layer's reductions for all members in one launch (backward._bn_bwd_group)
-                mean_all = torch.empty((G, c), dtype=torch.float32, device=dev)
-                invstd_all = torch.empty((G, c), dtype=torch.float32, device=dev)
+                # the members' mean / invstd (and scale / shift) as rows of one [G][C] tensor each: the backward pass then
+                # runs every BatchNorm layer's reductions for all members in one launch (backward._bn_bwd_group), or
+                # inside the data-gradient kernel above it (backward._dgrad_bn_bwd)
+                mean_all, invstd_all, sc_all, sh_all = torch.empty((4, G, c), dtype=torch.float32, device=dev).unbind(0)
                 for g in range(G):                                # running statistics update in call order
-                    per.append(self.bn_finalize(sts[g], count, bn, out=(mean_all[g], invstd_all[g])))
+                    per.append(self.bn_finalize(sts[g], count, bn, out=(mean_all[g], invstd_all[g], sc_all[g], sh_all[g])))
             a = torch.empty_like(z)
             n_pix = member(z, 0).numel() // c
             for g in range(G):
                 self.lib.call("ds_bn_apply_f32", self._p(member(z, g)), self._p(per[g][2]), self._p(per[g][3]),
                               self._p(member(residual, g)) if residual is not None else None, self._p(member(a, g)),
                               n_pix, c, flags, self._stream(z))
-            return a, [(m, i, sc) for (m, i, sc, _) in per]
+            return a, list(per)
 
         h, w, cin = T, F, 1
         a = x

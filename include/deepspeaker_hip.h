@@ -285,6 +285,26 @@ int ds_bn_bwd_group_reduce_f32(const float *g1, const float *g2, const float *ac
 int ds_bn_bwd_group_apply_f32(const double *sums, const float *gy, const float *z, const float *mean,
                               const float *invstd, const float *gamma, float *coef, float *member_sums,
                               float *ggamma, float *gbeta, float *gz, long long n_pix, int C, int G, void *stream);
+/* The 3x3 stride-1 data gradient FUSED with the first half of the BatchNorm backward of the layer it feeds (autograd of
+ * y = clip(bn1(conv1(r))) / r = clip(bn(conv(x))) under loss.backward(), train_triplet.py:223 over model.py:69-75,187-189):
+ *   gy = (dgrad(gz_up) [+ g2]) * [0 < z * mask_scale + mask_shift < 20],  partial[row] = { sum gy, sum gy * xhat }
+ * i.e. ds_conv_dgrad_bf16 followed by the reduce kernel of ds_bn_bwd_group_f32, without the gradient's round trip
+ * through HBM and without reading the activation (the clipped-ReLU mask is re-derived from the layer's own
+ * pre-activation z with the very fma of ds_bn_apply_f32).  `s`: the FORWARD shape of the convolution whose data gradient
+ * this is; z / g2 / gy [B,H,W,Cin]; the batch = G members of B/G utterances with their own statistics, tables
+ * mean / invstd / mask_scale / mask_shift [G][Cin].  ds_conv_dgrad_bnbwd_bf16_rows: partial rows PER MEMBER (partial =
+ * G * rows * Cin * 2 floats), or DS_ERR_UNSUPPORTED when a tile of the launch would straddle two members (fall back to
+ * ds_conv_dgrad_bf16 + ds_bn_bwd_group_f32).  ds_bn_bwd_group_finish_f32 is the second half (coefficients, dgamma /
+ * dbeta added in member order, gz); data-parallel training puts ds_partial_sum_f64_group -> all-reduce ->
+ * ds_bn_bwd_group_apply_f32 in its place. */
+int ds_conv_dgrad_bnbwd_bf16_rows(const ds_conv_shape *s, int G);
+int ds_conv_dgrad_bnbwd_bf16(const ds_conv_shape *s, const float *gz_up, const void *w_hi, const void *w_lo,
+                             const float *g2, const float *z, const float *mean, const float *invstd,
+                             const float *mask_scale, const float *mask_shift, int G, float *gy, float *partial,
+                             void *stream);
+int ds_bn_bwd_group_finish_f32(const float *partial, int n_partial, const float *gy, const float *z, const float *mean,
+                               const float *invstd, const float *gamma, float *coef, float *member_sums, float *ggamma,
+                               float *gbeta, float *gz, long long n_pix, int C, int G, void *stream);
 /* forward counterpart: per-tile partial statistics of G members (n_partial rows of [C][2] each, consecutive)
  * -> sums [G][2C+1] float64 (count in the last slot of each row) in one launch */
 int ds_partial_sum_f64_group(const float *partial, int n_partial, double *sums, long long count, int C, int G,

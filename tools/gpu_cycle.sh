@@ -24,6 +24,9 @@ for w in $WHAT; do
     slots) for c in 4 8 16 32; do timeout 300 python bench.py --no-secondary --no-cpu-baseline --refine-slots $c --repeats 2 > $OUT/slots_$c.json 2> $OUT/slots_$c.err; python -c "import json;d=json.load(open('$OUT/slots_$c.json'));print('slots',$c,d['value'],d['ms_per_step'],d['repeats_ms_per_step'],d['roofline']['achieved'],d['refine'])"; done ;;
     extras) timeout 300 python tools/mine_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/mine_probe.txt
             timeout 300 python tools/latency_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.txt ;;
+    trainab) for i in 1 2; do for f in "" "--no-fuse-bn"; do echo "train_bench --grouped $f"; timeout 300 python tools/train_bench.py --grouped --steps 20 --warmup 5 $f 2>&1 | grep -v amdgpu.ids | tail -1; done; done | tee $OUT/train_ab.txt ;;
+    traintests) timeout 1200 python -m pytest tests/test_gpu_train_parity.py tests/test_gpu_parity.py tests/test_gpu_bench_cli.py -m gpu -x -q -s > $OUT/pytest_train.log 2>&1; echo "pytest(train) rc=$?"; tail -15 $OUT/pytest_train.log ;;
+    fwdstreams) timeout 300 python tools/train_fwd_streams.py 2>&1 | grep -v amdgpu.ids | tee $OUT/train_fwd_streams.txt ;;
     pmc) timeout 1200 tools/pmc_run.sh $TAG/pmc --no-secondary; python tools/pmc_summary.py $OUT/pmc kernel 52 > $OUT/pmc_summary.md 2> $OUT/pmc_summary.err; head -60 $OUT/pmc_summary.md ;;
     *) echo "unknown step $w" ;;
   esac

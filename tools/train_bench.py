@@ -22,11 +22,13 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
     ap.add_argument("--grouped", action="store_true", help="model.forward_triplet instead of three calls")
     ap.add_argument("--no-overlap", action="store_true", help="filter gradients on the main stream (A/B of backward._FilterGradLane)")
+    ap.add_argument("--no-fuse-bn", action="store_true", help="3x3 data gradients and the BatchNorm backward below them as separate launches (A/B of backward._dgrad_bn_bwd)")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side profile of the timed steps")
     args = ap.parse_args()
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
     from deepspeaker_pytorch_amd import backward
     backward.OVERLAP_FILTER_GRADIENTS = not args.no_overlap
+    backward.FUSE_DGRAD_BN_BWD = not args.no_fuse_bn
     from deepspeaker_pytorch_amd.synthetic import synthetic_state_dict
     dev = torch.device("cuda", 0)
     sd = synthetic_state_dict(0, 1211)
