@@ -202,10 +202,10 @@ class Engine:
     # ------------------------------------------------------------------ single launches
     def conv(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, cin: int, cout: int,
              ks: int, stride: int, scale=None, shift=None, residual=None, flags: int = 0,
-             want_stats: bool = False):
+             want_stats: bool = False, out=None):
         shp = ConvShape(B, H, W, cin, cout, ks, stride)
         ho, wo = conv_out(H, ks, stride), conv_out(W, ks, stride)
-        y = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=x.device)
+        y = out if out is not None else torch.empty((B, ho, wo, cout), dtype=torch.float32, device=x.device)
         stats = None
         if want_stats:
             rows = self.lib.raw("ds_conv_stats_rows")(ctypes.byref(shp))
@@ -226,11 +226,12 @@ class Engine:
         return y, stats
 
     def conv_bf16(self, x: torch.Tensor, w_pair, x3: bool, B: int, H: int, W: int, cin: int, cout: int, ks: int,
-                  stride: int, scale=None, shift=None, residual=None, flags: int = 0, want_stats: bool = False):
+                  stride: int, scale=None, shift=None, residual=None, flags: int = 0, want_stats: bool = False,
+                  out=None):
         """Forward convolution on the bf16 matrix cores; x3 = hi/lo split operands (f32-class accuracy)."""
         shp = ConvShape(B, H, W, cin, cout, ks, stride)
         ho, wo = conv_out(H, ks, stride), conv_out(W, ks, stride)
-        y = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=x.device)
+        y = out if out is not None else torch.empty((B, ho, wo, cout), dtype=torch.float32, device=x.device)
         stats = None
         if want_stats:
             rows = self.lib.raw("ds_conv_bf16_stats_rows")(ctypes.byref(shp), int(x3))
@@ -271,10 +272,10 @@ class Engine:
         return y
 
     def conv1(self, x: torch.Tensor, wp: torch.Tensor, B: int, H: int, W: int, scale=None, shift=None,
-              flags: int = 0, want_stats: bool = False, lowp: bool = False):
+              flags: int = 0, want_stats: bool = False, lowp: bool = False, out=None):
         ho, wo = conv_out(H, 5, 2), conv_out(W, 5, 2)
-        y = torch.empty((B, ho, wo, 64), dtype=torch.float16 if flags & DS_EPI_OUT_F16 else torch.float32,
-                        device=x.device)
+        y = out if out is not None else torch.empty((B, ho, wo, 64), dtype=torch.float16 if flags & DS_EPI_OUT_F16
+                                                    else torch.float32, device=x.device)
         stats = None
         if want_stats:
             rows = self.lib.raw("ds_conv5x5s2_c1_stats_rows")(B, H)
@@ -320,8 +321,8 @@ class Engine:
                       self._p(mean), self._p(invstd), self._p(scale), self._p(shift), c, self._stream(stats))
         return mean, invstd, scale, shift
 
-    def bn_apply(self, x: torch.Tensor, scale, shift, residual=None, flags: int = 0):
-        y = torch.empty_like(x)
+    def bn_apply(self, x: torch.Tensor, scale, shift, residual=None, flags: int = 0, out=None):
+        y = out if out is not None else torch.empty_like(x)
         c = x.shape[-1]
         self.lib.call("ds_bn_apply_f32", self._p(x), self._p(scale), self._p(shift), self._p(residual),
                       self._p(y), x.numel() // c, c, flags, self._stream(x))
@@ -727,6 +728,9 @@ class Engine:
         x3 = precision == "bf16x3"
         if x3 and pw.stages[0].l_conv1_bf16 is None:
             raise ValueError("pack_weights(..., with_bf16=True) is required for bf16x3")
+        # (save=False frees a layer's buffers while other members' streams may still read them: lock-step then)
+        if self.MEMBER_STREAMS and save and x.is_cuda and G > 1 and not (reducer is not None and reducer.active):
+            return self._forward_train_group_streams(x, G, pw, bns, save, x3)
         saved = SavedForward(x=x) if save else None
         dev = x.device
 
@@ -825,6 +829,93 @@ class Engine:
             if save:
                 saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, stt, a
                 saved.dims.append((h, w))
+        e = self.tail(a, pw, saved)
+        return [member(e, g) for g in range(G)], saved
+
+    MEMBER_STREAMS = True      # forward_train_group on a GPU, single process: one HIP stream per member (see below)
+    _member_streams: Dict[Tuple[torch.device, int], list] = {}
+
+    def _forward_train_group_streams(self, x, G: int, pw: PackedWeights, bns: Dict[str, BNParams], save: bool, x3: bool):
+        """forward_train_group with every member's chain -- convolution, statistics, normalise + clip, layer after
+        layer -- on a HIP stream of its own.  A train-mode layer is a matrix-core-bound convolution followed by
+        HBM-bound element-wise passes that need the whole member's statistics first; in lock-step over one batch the
+        chip alternates between the two.  Members are independent until the loss, so on separate streams one
+        member's BatchNorm passes run next to another member's convolution (measured on the 768-utterance step:
+        6.9 -> 6.2 ms per forward, tools/train_fwd_streams.py).  Same kernels on the same slices of the same buffers:
+        the saved state is the lock-step one (one activation buffer per layer, statistics as [G][C] tables), the
+        backward pass does not change.  The running statistics are updated in call order (a, p, n): a member's
+        finalize kernel waits for the previous member's of the same layer.  Everything that outlives the forward is
+        allocated on the caller's stream before the fork; the side streams only allocate what they consume
+        themselves.  Data-parallel training keeps the lock-step form (its all-reduce carries all members' sums)."""
+        B, _, T, F = x.shape
+        Bm = B // G
+        dev = x.device
+        cur = torch.cuda.current_stream(dev)
+        key = (dev, G)
+        if key not in Engine._member_streams:
+            Engine._member_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(G)]
+        streams = Engine._member_streams[key]
+        saved = SavedForward(x=x) if save else None
+        for st in streams:
+            st.wait_stream(cur)
+
+        def member(t, g):
+            return t[g * Bm:(g + 1) * Bm]
+
+        def layer(src, name, kind, sw_f32, sw_b, hh, ww, ci, co, residual):
+            """one convolution + BatchNorm(train) + clip layer of all members; returns (z, a, stats list)"""
+            ks, stride = (5, 2) if kind != "3x3" else (3, 1)
+            ho, wo = conv_out(hh, ks, stride), conv_out(ww, ks, stride)
+            z = torch.empty((B, ho, wo, co), dtype=torch.float32, device=dev)
+            a = torch.empty_like(z)
+            tables = torch.empty((4, G, co), dtype=torch.float32, device=dev)
+            mean_all, invstd_all, sc_all, sh_all = tables.unbind(0)
+            bn = bns[name]
+            count = Bm * ho * wo
+            flags = DS_EPI_CLIP | (DS_EPI_RESIDUAL if residual is not None else 0)
+            prev_done = None
+            per = []
+            for g in range(G):
+                with torch.cuda.stream(streams[g]):
+                    if kind == "c1":
+                        _, stp = self.conv1(member(src, g), sw_f32, Bm, hh, ww, want_stats=True, lowp=x3, out=member(z, g))
+                    elif x3:
+                        _, stp = self.conv_bf16(member(src, g), sw_b, True, Bm, hh, ww, ci, co, ks, stride,
+                                                want_stats=True, out=member(z, g))
+                    else:
+                        _, stp = self.conv(member(src, g), sw_f32, Bm, hh, ww, ci, co, ks, stride, want_stats=True,
+                                           out=member(z, g))
+                    if prev_done is not None:
+                        streams[g].wait_event(prev_done)          # running statistics: a, then p, then n
+                    out = (mean_all[g], invstd_all[g], sc_all[g], sh_all[g])
+                    self.bn_finalize(stp, count, bn, out=out)
+                    prev_done = torch.cuda.Event()
+                    prev_done.record(streams[g])
+                    self.bn_apply(member(z, g), sc_all[g], sh_all[g], member(residual, g) if residual is not None else None,
+                                  flags, out=member(a, g))
+                    per.append(out)
+            return z, a, per, ho, wo
+
+        h, w, cin = T, F, 1
+        a = x
+        for s_, sw in enumerate(pw.stages):
+            i, c = s_ + 1, STAGE_CHANNELS[s_]
+            name = f"model.bn{i}"
+            z, a, stt, h, w = layer(a, name, "c1" if i == 1 else "5x5", sw.conv, sw.conv_bf16, h, w, cin, c, None)
+            cin = c
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, stt, a
+            name = f"model.layer{i}.0.bn1"
+            z, y, stt, _, _ = layer(a, name, "3x3", sw.l_conv1, sw.l_conv1_bf16, h, w, c, c, None)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, stt, y
+            name = f"model.layer{i}.0.bn2"
+            z, a, stt, _, _ = layer(y, name, "3x3", sw.l_conv2, sw.l_conv2_bf16, h, w, c, c, a)
+            if save:
+                saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, stt, a
+                saved.dims.append((h, w))
+        for st in streams:
+            cur.wait_stream(st)
         e = self.tail(a, pw, saved)
         return [member(e, g) for g in range(G)], saved
 
