@@ -189,8 +189,10 @@ def test_member_streams_forward_equals_three_calls_bitwise():
         # (not against the lock-step pass: its statistics differ in the last bit, which flips a clip mask or two --
         # 3e-3 on conv1's gradient at this size; the masked-oracle test above is where gradients are held tight)
         assert rel_l2(v, res["three_calls"][2][k]) < 2e-5, (k, rel_l2(v, res["three_calls"][2][k]))
+    # lock-step: statistics folded from differently shaped tiles -> last-bit differences in scale / shift, which the
+    # hi / lo operand split of the next layer turns into ~2^-16 per product (measured 4.6e-6 on the embeddings)
     for x_, y_ in zip(res["streams"][0], res["lock_step"][0]):
-        assert rel_err(x_.cpu().numpy(), y_.cpu().numpy()) < 1e-6
+        assert rel_err(x_.cpu().numpy(), y_.cpu().numpy()) < 2e-5
     for k, v in res["streams"][1].items():
         if v.is_floating_point():
-            assert rel_err(v.cpu().numpy(), res["lock_step"][1][k].cpu().numpy()) < 1e-6, k
+            assert rel_err(v.cpu().numpy(), res["lock_step"][1][k].cpu().numpy()) < 2e-5, k
