@@ -317,7 +317,7 @@ unsigned *ds_sched_slot() {
     return slots + (size_t)k * DS_SCHED_WORDS;
 }
 
-extern "C" int ds_version(void) { return 300; }   // 300: round-3 ABI (+ split grouped BatchNorm backward for data parallelism, grouped f64 sums)
+extern "C" int ds_version(void) { return 301; }   // 30x: round-3 ABI (300: split grouped BatchNorm backward for data parallelism, grouped f64 sums; 301: + ds_conv_dgrad_bnbwd_bf16, ds_bn_bwd_group_finish_f32)
 
 extern "C" const char *ds_error_string(int code) {
     switch (code) {

@@ -60,7 +60,8 @@ extern "C" {
 
 #define DS_CONV_CK      8   /* input-channel chunk of the packed weight layout */
 
-int ds_version(void);            /* 100: round 1; 200: round 2 (fp16 path, grouped BatchNorm backward, ds_bn_bwd_partial_rows takes C) */
+int ds_version(void);            /* 100: round 1; 200: round 2 (fp16 path, grouped BatchNorm backward, ds_bn_bwd_partial_rows takes C);
+                                    300 / 301: round 3 (persistent fp16 kernels, split grouped BatchNorm backward; + ds_conv_dgrad_bnbwd_bf16) */
 const char *ds_error_string(int code);
 
 /* ---- layout ---------------------------------------------------------------------------------- */
