@@ -1,15 +1,28 @@
 #!/bin/bash
-# TEST INFRASTRUCTURE: compile the unmodified kernel sources for the host emulator.
+# TEST INFRASTRUCTURE: compile the unmodified kernel sources for the host emulator (one object per source, in
+# parallel; only sources newer than their object are recompiled), then link them with the emulated runtime.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-CXX=${EMUL_CXX:-/opt/rocm/lib/llvm/bin/clang++}
-OUT="$HERE/_build"
-mkdir -p "$OUT"
-SRCS=("$ROOT/deepspeaker-pytorch_amd/csrc/"*.hip)
-ARGS=()
-for s in "${SRCS[@]}"; do ARGS+=(-x c++ "$s"); done
-"$CXX" ${EMUL_EXTRA} -std=c++17 -O2 -g -fPIC -shared -pthread -Wno-unused-function -Wno-unknown-attributes \
-    -I"$HERE" -I"$ROOT/deepspeaker-pytorch_amd/csrc" -I"$ROOT/include" \
-    -x c++ "$HERE/emu_runtime.cpp" "${ARGS[@]}" -o "$OUT/libdeepspeaker_emul.so"
+export CXX=${EMUL_CXX:-/opt/rocm/lib/llvm/bin/clang++}
+export OUT="$HERE/_build${EMUL_TAG:+_$EMUL_TAG}"
+export HERE ROOT EMUL_EXTRA
+mkdir -p "$OUT/obj"
+compile() {
+    src="$1"
+    obj="$OUT/obj/$(basename "${src%.*}").o"
+    newest=$(ls -t "$src" "$ROOT"/deepspeaker-pytorch_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/*.h "$HERE"/hip/*.h "$HERE/build_emul.sh" 2>/dev/null | head -1)
+    if [ -f "$obj" ] && [ "$obj" -nt "$newest" ]; then return 0; fi
+    "$CXX" ${EMUL_EXTRA} -std=c++17 -O2 -g -fPIC -pthread -Wno-unused-function -Wno-unknown-attributes \
+        -I"$HERE" -I"$ROOT/deepspeaker-pytorch_amd/csrc" -I"$ROOT/include" -x c++ -c "$src" -o "$obj"
+}
+export -f compile
+JOBS=${EMUL_JOBS:-$(( $(nproc) < 16 ? $(nproc) : 16 ))}
+ls "$ROOT"/deepspeaker-pytorch_amd/csrc/*.hip "$HERE/emu_runtime.cpp" | xargs -P "$JOBS" -I{} bash -c 'compile "$@"' _ {}
+# objects of sources that no longer exist must not be linked
+for o in "$OUT"/obj/*.o; do
+    b="$(basename "${o%.o}")"
+    [ -f "$ROOT/deepspeaker-pytorch_amd/csrc/$b.hip" ] || [ "$b" = emu_runtime ] || rm -f "$o"
+done
+"$CXX" -shared -pthread -o "$OUT/libdeepspeaker_emul.so" "$OUT"/obj/*.o
 echo "$OUT/libdeepspeaker_emul.so"
