@@ -23,6 +23,15 @@ namespace {
 
 constexpr int WB_C = 64;                     // channels per tile on both sides
 constexpr int WB_REC = 4 * WB_C + 64;        // bytes per pixel record: hi (128) | lo (128) | pad -> 80 dwords = 16 mod 64
+// staging slots (16 pixels each) of the two 3x3 instantiations: 128-pixel tiles, and 160-pixel ones for geometries
+// whose image (or a much larger part of it) then fits one tile -- measured per layer at 768 utterances
+// (tools/wgrad_ab.py): 64-pixel tiles 610 / 506 / 463 / 587 us, 128: 540 / 431 / 461 / 422, 160: 564 / 446 / 410 / 442
+#ifndef DS_WGRAD_GSL3
+#define DS_WGRAD_GSL3 8
+#define DS_WGRAD_XSL3 14
+#endif
+constexpr int WB_GSL3 = DS_WGRAD_GSL3, WB_XSL3 = DS_WGRAD_XSL3;
+constexpr int WB_GSL3_BIG = 10, WB_XSL3_BIG = 17;
 
 struct WgradKB {
     const float *x, *gz;
@@ -52,7 +61,10 @@ __device__ __forceinline__ bf16x8 frag_tr(const char *rec0, const char *rec1) {
 // contracted against 15 (10) taps instead of the 5 of a single kernel row.
 // Four waves as 2 (co) x 2 (ci), each owning a 32 x 32 block of every tap of the group; the accumulators take most
 // of the register file (one wave per SIMD).
-template <int TG, int KW>
+// GSL / XSL: staging slots per thread (float4 each) for the dY rows and the X halo tile -- the tile's size in registers:
+// 16 * GSL output pixels, 16 * XSL halo pixels.  A 3x3 (9 accumulators) has room for 8 + 14: 128-pixel tiles halve the
+// barriers, pipeline fills and halo rows per contracted pixel of the 64-pixel ones; a 5x5 group (15 accumulators) keeps 4 + 12.
+template <int TG, int KW, int GSL, int XSL>
 __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kernel(const WgradKB p) {
     constexpr bool GROUP = KW == 5;                     // kernel-row group of a 5x5 (see above)
     char *lds = (char *)ds_dynamic_lds();
@@ -81,7 +93,6 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
 
     const int pix_per_seg = p.RT * p.Wo;
     constexpr int QV = WB_C / 4;                        // float4 per staged pixel
-    constexpr int GSL = 4, XSL = 12;                    // staging slots per thread (the host plan keeps within)
 
     // ---- tile-invariant staging descriptors: per slot the float offset RELATIVE to the segment's origin and
     //      (segment << 16 | row); per tile only four numbers per segment change (segtab) ----
@@ -290,6 +301,7 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
 
 struct WgradPlanB {
     WgradKB k;                   // 5x5: the geometry of the three-row group; wgrad_group_rows() derives the other
+    bool big;                    // 3x3: the 160-pixel-tile instantiation
     int grid;
     size_t lds_bytes;
     long long partial_floats;
@@ -314,16 +326,43 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     k.KS = s->KS; k.IS = s->stride; k.pad = pad;
     k.k0 = 0;
     const int group_rows = 3;                             // kernel rows of the (larger) 5x5 group
-    // segment height / segments per tile: <= 64 output pixels (4 staging slots) and <= 192 halo pixels
-    // (12 slots) per tile
-    const int max_in_pix = 190;                           // 12 staging slots; (64 + 190) records = 80 KiB, one workgroup per CU
-    int best_rt = 0, best_ni = 1;
-    for (int rt = 1; rt <= k.Ho; ++rt) {
-        if (rt * k.Wo > 64) break;
-        const int rows_in = s->KS == 5 ? rt + group_rows - 1 : s->stride * (rt - 1) + s->KS;
-        const int cols_in = s->stride * (k.Wo - 1) + s->KS;
-        if (rows_in * cols_in > max_in_pix) break;
-        best_rt = rt;
+    // segment height / segments per tile: the kernel's staging slots bound the tile (16 pixels per slot): a 3x3 has
+    // 8 + 14 (128 output pixels, 222 halo pixels: 110 KiB of records, one workgroup per CU), a 5x5 group 4 + 12
+    int max_out_pix = 0, max_in_pix = 0, best_rt = 0, best_ni = 1;
+    // rows per segment: the most pixels per tile among the heights that waste the fewest rows in an image's last segment
+    auto search = [&](int mo, int mi) {
+        max_out_pix = mo; max_in_pix = mi;
+        best_rt = 0; best_ni = 1;
+        double best_fill = -1.0;
+        for (int rt = 1; rt <= k.Ho; ++rt) {
+            if (rt * k.Wo > max_out_pix) break;
+            const int rows_in = s->KS == 5 ? rt + group_rows - 1 : s->stride * (rt - 1) + s->KS;
+            const int cols_in = s->stride * (k.Wo - 1) + s->KS;
+            if (rows_in * cols_in > max_in_pix) break;
+            const int segs = ds_ceil_div(k.Ho, rt);
+            const int padded = (rt * k.Wo + 15) & ~15;
+            const double fill = (double)k.Ho * k.Wo / ((double)segs * padded) + 1e-6 * rt;
+            if (s->KS == 5 || fill > best_fill) { best_fill = fill; best_rt = rt; }
+        }
+        if (best_rt == 0) return 0;
+        const int segs_per_img = ds_ceil_div(k.Ho, best_rt);
+        const int rows_in = s->KS == 5 ? best_rt + group_rows - 1 : s->stride * (best_rt - 1) + s->KS;
+        const int seg_pix = rows_in * (s->stride * (k.Wo - 1) + s->KS);
+        while ((best_ni + 1) * best_rt * k.Wo <= max_out_pix && (best_ni + 1) * seg_pix <= max_in_pix &&
+               best_ni + 1 <= s->B * segs_per_img)
+            ++best_ni;
+        return best_ni * best_rt * k.Wo;                  // output pixels per tile
+    };
+    pl.big = false;
+    if (s->KS == 3) {
+        const int px_big = search(WB_GSL3_BIG * 16, WB_XSL3_BIG * 16 - 2);
+        const int px = search(WB_GSL3 * 16, WB_XSL3 * 16 - 2);
+        if (WB_GSL3 < WB_GSL3_BIG && 2 * px_big >= 3 * px) {           // worth the larger tile only if it is much larger
+            search(WB_GSL3_BIG * 16, WB_XSL3_BIG * 16 - 2);
+            pl.big = true;
+        }
+    } else {
+        search(64, 190);
     }
     DS_REQUIRE(best_rt > 0, DS_ERR_UNSUPPORTED);
     k.RT = best_rt;
@@ -332,8 +371,6 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     k.rows_in = s->KS == 5 ? best_rt + group_rows - 1 : s->stride * (best_rt - 1) + s->KS;   // 5x5: the rows of one residue
     k.cols_in = s->stride * (k.Wo - 1) + s->KS;
     k.seg_pix = k.rows_in * k.cols_in;
-    while ((best_ni + 1) * best_rt * k.Wo <= 64 && (best_ni + 1) * k.seg_pix <= max_in_pix && best_ni + 1 <= k.n_segs)
-        ++best_ni;
     k.NI = best_ni;
     k.P = (best_ni * best_rt * k.Wo + 15) & ~15;
     k.n_tiles = ds_ceil_div(k.n_segs, best_ni);
@@ -346,8 +383,8 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     k.S = S;
     pl.grid = base_blocks * S;
     pl.lds_bytes = ((size_t)k.P + (size_t)k.NI * k.seg_pix) * WB_REC + ((size_t)k.P + 8 * k.NI) * 4;
-    DS_REQUIRE(k.P * (WB_C / 4) <= 4 * 256 && k.NI <= 255 && s->stride * k.rows_in + s->KS < 4096 &&
-                   pl.lds_bytes <= 96 * 1024, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(k.P <= max_out_pix && k.NI * k.seg_pix <= max_in_pix + 2 && k.NI <= 255 &&
+                   s->stride * k.rows_in + s->KS < 4096 && pl.lds_bytes <= 150 * 1024, DS_ERR_UNSUPPORTED);
     pl.partial_floats = (long long)S * s->KS * s->KS * s->Cout * s->Cin;
     return DS_OK;
 }
@@ -369,17 +406,20 @@ extern "C" int ds_conv_wgrad_bf16(const ds_conv_shape *s, const float *x, const 
     if (rc != DS_OK) return rc;
     pl.k.x = x; pl.k.gz = gy; pl.k.partial = workspace;
     if (s->KS == 3) {
-        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<9, 3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        if (pl.big)
+            DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<9, 3, WB_GSL3_BIG, WB_XSL3_BIG>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        else
+            DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<9, 3, WB_GSL3, WB_XSL3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
     } else {
         // kernel rows 0, s, 2s (15 taps), then the remaining two (10 taps): same tiles, same splits, disjoint taps
-        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<15, 5>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<15, 5, 4, 12>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
         rc = ds_last_launch_error();
         if (rc) return rc;
         WgradKB k2 = pl.k;
         k2.k0 = s->stride == 2 ? 1 : 3;
         k2.rows_in = pl.k.RT + 1;
         k2.seg_pix = k2.rows_in * k2.cols_in;
-        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<10, 5>), pl.grid, 256, pl.lds_bytes, stream, k2);
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<10, 5, 4, 12>), pl.grid, 256, pl.lds_bytes, stream, k2);
     }
     rc = ds_last_launch_error();
     if (rc) return rc;
