@@ -846,7 +846,10 @@ class Engine:
         backward pass does not change.  The running statistics are updated in call order (a, p, n): a member's
         finalize kernel waits for the previous member's of the same layer.  Everything that outlives the forward is
         allocated on the caller's stream before the fork; the side streams only allocate what they consume
-        themselves.  Data-parallel training keeps the lock-step form (its all-reduce carries all members' sums)."""
+        themselves.  Data-parallel training keeps the lock-step form (its all-reduce carries all members' sums; giving
+        every member an all-reduce of its own from its own stream was measured: 23.0 ms against 20.2 ms lock-step with
+        one rank -- a process group runs its collectives on ONE internal stream, in issue order, each waiting for its
+        member's partial sums, so the three chains end up waiting for each other at every layer anyway)."""
         B, _, T, F = x.shape
         Bm = B // G
         dev = x.device
