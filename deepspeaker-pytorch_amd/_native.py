@@ -95,6 +95,8 @@ _SIGNATURES = {
     "ds_bn_bwd_group_apply_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "ds_conv_dgrad_bnbwd_bf16_rows": (c_int, [POINTER(ConvShape), c_int]),
     "ds_conv_dgrad_bnbwd_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "ds_conv_dgrad_s2_bnbwd_bf16_rows": (c_int, [POINTER(ConvShape), c_int]),
+    "ds_conv_dgrad_s2_bnbwd_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "ds_bn_bwd_group_finish_f32": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "ds_bn_stats_from_sums_f32": (c_int, [_P, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_bn_bwd_reduce_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),

@@ -169,6 +169,47 @@ def _dgrad_bn_bwd(eng: Engine, shp: ConvShape, gz_up, bank_bf16, g2, z, stats, g
     return gy, gz, gg, gb
 
 
+def _dgrad_s2_bn_bwd(eng: Engine, shp: ConvShape, gz_up, bank_bf16, act, z, stats, gamma, reducer=None):
+    """`_dgrad` of a 5x5 stride-2 layer followed by `_bn_bwd` of the BasicBlock output it feeds (bn2 + residual + clip of
+    the previous stage), fused like `_dgrad_bn_bwd` (ds_conv_dgrad_s2_bnbwd_bf16): the four parity-class launches mask
+    with the stored activation `act`, sum and write gy.  Returns (gy, gz, dgamma, dbeta) or None (not applicable)."""
+    if not FUSE_DGRAD_BN_BWD or bank_bf16 is None:
+        return None
+    members = stats if isinstance(stats, list) else [stats]
+    G = len(members)
+    c = z.shape[-1]
+    step = c * 4
+    if not all(members[g][k].data_ptr() == members[0][k].data_ptr() + g * step for g in range(G) for k in range(2)):
+        return None
+    rows = eng.lib.raw("ds_conv_dgrad_s2_bnbwd_bf16_rows")(ctypes.byref(shp), G)
+    if rows <= 0:
+        return None
+    dev = z.device
+    n_pix = (z.numel() // c) // G
+    st = eng._stream(z)
+    mean, invstd = members[0][0], members[0][1]
+    gy, gz = torch.empty_like(z), torch.empty_like(z)
+    partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=dev)
+    coef = torch.empty((G, 3 * c), dtype=torch.float32, device=dev)
+    member_sums = torch.empty((2, G, c), dtype=torch.float32, device=dev)
+    gg, gb = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
+    eng.lib.call("ds_conv_dgrad_s2_bnbwd_bf16", ctypes.byref(shp), eng._p(gz_up), eng._p(bank_bf16[0]),
+                 eng._p(bank_bf16[1]), eng._p(act), eng._p(z), eng._p(mean), eng._p(invstd), G, eng._p(gy),
+                 eng._p(partial), st)
+    if reducer is not None and reducer.active:
+        sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=dev)
+        eng.lib.call("ds_partial_sum_f64_group", eng._p(partial), rows, eng._p(sums), n_pix, c, G, st)
+        reducer.all_reduce_sum_(sums)
+        eng.lib.call("ds_bn_bwd_group_apply_f32", eng._p(sums), eng._p(gy), eng._p(z), eng._p(mean), eng._p(invstd),
+                     eng._p(gamma.detach()), eng._p(coef), eng._p(member_sums), eng._p(gg), eng._p(gb), eng._p(gz),
+                     n_pix, c, G, st)
+    else:
+        eng.lib.call("ds_bn_bwd_group_finish_f32", eng._p(partial), rows, eng._p(gy), eng._p(z), eng._p(mean),
+                     eng._p(invstd), eng._p(gamma.detach()), eng._p(coef), eng._p(member_sums), eng._p(gg), eng._p(gb),
+                     eng._p(gz), n_pix, c, G, st)
+    return gy, gz, gg, gb
+
+
 def _wgrad(eng: Engine, shp: ConvShape, x, gz, out_shape, fc_f: int = 0, x3: bool = False, out=None):
     """filter gradient into `out` (a contiguous view of a gradient bucket) or a fresh tensor"""
     if x3 and shp.KS in (3, 5) and shp.Cin % 64 == 0:      # split-operand bf16 matrix cores
@@ -323,6 +364,7 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
     g = torch.empty_like(out)
     lib.call("ds_avgpool_time_bwd_f32", eng._p(gpooled), eng._p(out), eng._p(g), B, hr, wc, c, st)
     g_is_masked = True
+    pre = None
     for s in reversed(range(n_stages)):
         i, c = s + 1, STAGE_CHANNELS[s]
         h, w = saved.dims[s]
@@ -331,8 +373,12 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
         shp3 = ConvShape(B, h, w, c, c, 3, 1)
         # out = clip(bn2(conv2(y)) + r)            (model.py:73-80)
         name = f"model.layer{i}.0.bn2"
-        g_out, gz, gg, gbeta = _bn_bwd(eng, g, None, None if g_is_masked else c_act, saved.raws[name],
-                                       saved.stats[name], bn_weights[name], reducer)
+        if pre is not None:       # the stage above already ran this step inside its 5x5 data gradient
+            g_out, gz, gg, gbeta = pre
+            pre = None
+        else:
+            g_out, gz, gg, gbeta = _bn_bwd(eng, g, None, None if g_is_masked else c_act, saved.raws[name],
+                                           saved.stats[name], bn_weights[name], reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv2.weight"] = lane.run(
             lambda gz=gz: _wgrad(eng, shp3, b_act, gz, (c, c, 3, 3), x3=x3,
@@ -365,8 +411,13 @@ def backward_train(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedW
             lambda gz=gz: _wgrad(eng, shp5, x_in, gz, (c, cin, 5, 5), x3=x3, out=buckets.views[f"model.conv{i}.weight"]), gz)
         lane.run(lambda: buckets.done(s))       # this stage's three filter gradients are enqueued: reduce them now
         if s > 0:
-            g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad, pw.stages[s].conv_dgrad_bf16 if x3 else None)   # unmasked: the next bn2 step masks it
-            g_is_masked = False
+            below = f"model.layer{s}.0.bn2"                 # out = clip(bn2(conv2(y)) + r) of the stage below
+            bank = pw.stages[s].conv_dgrad_bf16 if x3 else None
+            pre = _dgrad_s2_bn_bwd(eng, shp5, gz, bank, x_in, saved.raws[below], saved.stats[below], bn_weights[below],
+                                   reducer)
+            if pre is None:
+                g = _dgrad(eng, shp5, gz, pw.stages[s].conv_dgrad, bank)   # unmasked: the next bn2 step masks it
+                g_is_masked = False
     lane.join()
     buckets.finish()
     return grads

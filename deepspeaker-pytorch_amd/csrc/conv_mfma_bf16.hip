@@ -249,7 +249,7 @@ extern "C" int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const vo
     pl.k.scale = scale; pl.k.shift = shift; pl.k.res = residual; pl.k.stats = stats_partial;
     pl.k.flags = flags;
     pl.k.bn_z = pl.k.bn_mean = pl.k.bn_invstd = pl.k.bn_msc = pl.k.bn_msh = nullptr;
-    pl.k.bn_mtiles = 1;
+    pl.k.bn_mtiles = 1; pl.k.bn_rows_member = 0; pl.k.bn_row0 = 0;
     if (s->KS == 3) { if (x3) launch_b<3, true>(pl, stream); else launch_b<3, false>(pl, stream); }
     else            { if (x3) launch_b<5, true>(pl, stream); else launch_b<5, false>(pl, stream); }
     return ds_last_launch_error();
@@ -328,7 +328,7 @@ extern "C" int ds_conv_dgrad_bf16(const ds_conv_shape *s, const float *gy, const
         pl.k.stats = nullptr;
         pl.k.flags = 0;
         pl.k.bn_z = pl.k.bn_mean = pl.k.bn_invstd = pl.k.bn_msc = pl.k.bn_msh = nullptr;
-        pl.k.bn_mtiles = 1;
+        pl.k.bn_mtiles = 1; pl.k.bn_rows_member = 0; pl.k.bn_row0 = 0;
         launch_b<3, true>(pl, stream);
         rc = ds_last_launch_error();
         if (rc) return rc;
@@ -354,6 +354,8 @@ static int plan_bnbwd(PlanB &pl, const ds_conv_shape *s, int G) {
     const long long segs_per_member = (long long)(s->B / G) * pl.k.segs_per_img;
     DS_REQUIRE(segs_per_member % pl.k.NI == 0, DS_ERR_UNSUPPORTED);
     pl.k.bn_mtiles = (int)(segs_per_member / pl.k.NI);
+    pl.k.bn_rows_member = pl.k.bn_mtiles;
+    pl.k.bn_row0 = 0;
     return DS_OK;
 }
 
@@ -382,4 +384,74 @@ extern "C" int ds_conv_dgrad_bnbwd_bf16(const ds_conv_shape *s, const float *gz_
     pl.k.bn_z = z; pl.k.bn_mean = mean; pl.k.bn_invstd = invstd; pl.k.bn_msc = mask_scale; pl.k.bn_msh = mask_shift;
     ds_bf16_launch_k3x3g(pl, stream);
     return ds_last_launch_error();
+}
+
+// The same fusion for the 5x5 stride-2 data gradient, which feeds the activation of a BasicBlock's OUTPUT,
+// out = clip(bn2(conv2(y)) + r) (model.py:76-80): that clip's mask cannot be re-derived from z alone, so it is read from
+// the stored activation `act` ([B,H,W,Cin], the 5x5 layer's input); no second gradient is added.  Four parity-class
+// launches (ds_conv_dgrad_bf16) write interleaved pixels of gy and consecutive blocks of partial rows.
+static int plan_s2_class(PlanB &pl, const ds_conv_shape *s, int cls, int G, int &rows_member) {
+    const int ph = cls >> 1, pw = cls & 1;
+    const int Ho = (s->H - 1) / 2 + 1, Wo = (s->W - 1) / 2 + 1;          // dY grid
+    const int Hr = (s->H - ph + 1) / 2, Wc = (s->W - pw + 1) / 2;        // dX rows / columns of this parity
+    rows_member = 0;
+    if (Hr <= 0 || Wc <= 0) return DS_OK;
+    ds_conv_shape t = {s->B, Ho, Wo, s->Cout, s->Cin, 3, 1};
+    int rc = plan_bf16(pl, &t, true, 2, ph, pw, s->H, s->W, Hr, Wc);
+    if (rc != DS_OK) return rc;
+    const long long segs_per_member = (long long)(s->B / G) * pl.k.segs_per_img;
+    DS_REQUIRE(segs_per_member % pl.k.NI == 0, DS_ERR_UNSUPPORTED);
+    rows_member = (int)(segs_per_member / pl.k.NI);
+    pl.k.bn_mtiles = rows_member;
+    return DS_OK;
+}
+
+extern "C" int ds_conv_dgrad_s2_bnbwd_bf16_rows(const ds_conv_shape *s, int G) {
+    DS_REQUIRE(s, DS_ERR_NULL);
+    DS_REQUIRE(s->KS == 5 && s->stride == 2 && G > 0 && s->B % G == 0, DS_ERR_UNSUPPORTED);
+    int total = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        PlanB pl;
+        int rows = 0;
+        int rc = plan_s2_class(pl, s, cls, G, rows);
+        if (rc != DS_OK) return rc;
+        total += rows;
+    }
+    return total;
+}
+
+extern "C" int ds_conv_dgrad_s2_bnbwd_bf16(const ds_conv_shape *s, const float *gz_up, const void *w_hi, const void *w_lo,
+                                           const float *act, const float *z, const float *mean, const float *invstd,
+                                           int G, float *gy, float *partial, void *stream) {
+    DS_REQUIRE(s && gz_up && w_hi && w_lo && act && z && mean && invstd && gy && partial, DS_ERR_NULL);
+    DS_REQUIRE(s->KS == 5 && s->stride == 2 && G > 0 && s->B % G == 0, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(DS_ALIGNED16(gz_up) && DS_ALIGNED16(w_hi) && DS_ALIGNED16(w_lo) && DS_ALIGNED16(act) && DS_ALIGNED16(z) &&
+                   DS_ALIGNED16(gy) && DS_ALIGNED16(mean) && DS_ALIGNED16(invstd), DS_ERR_ALIGNMENT);
+    const int total = ds_conv_dgrad_s2_bnbwd_bf16_rows(s, G);
+    if (total <= 0) return total < 0 ? total : DS_ERR_UNSUPPORTED;
+    const size_t bank = (size_t)9 * s->Cout * s->Cin;
+    int row0 = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        PlanB pl;
+        int rows = 0;
+        int rc = plan_s2_class(pl, s, cls, G, rows);
+        if (rc != DS_OK) return rc;
+        if (rows == 0) continue;
+        pl.k.x = gz_up;
+        pl.k.w_hi = (const __bf16 *)w_hi + cls * bank;
+        pl.k.w_lo = (const __bf16 *)w_lo + cls * bank;
+        pl.k.y = gy;
+        pl.k.scale = pl.k.shift = nullptr;
+        pl.k.res = act;                                  // the mask's source (not added: bn_msc == nullptr)
+        pl.k.stats = partial;
+        pl.k.flags = DS_EPI_STATS | DS_EPI_RESIDUAL;
+        pl.k.bn_z = z; pl.k.bn_mean = mean; pl.k.bn_invstd = invstd; pl.k.bn_msc = pl.k.bn_msh = nullptr;
+        pl.k.bn_rows_member = total;
+        pl.k.bn_row0 = row0;
+        ds_bf16_launch_k3x3g(pl, stream);
+        rc = ds_last_launch_error();
+        if (rc) return rc;
+        row0 += rows;
+    }
+    return DS_OK;
 }

@@ -33,6 +33,10 @@ struct ConvKB {
     // member of the batch, bn_mtiles = M tiles per member
     const float *bn_z, *bn_mean, *bn_invstd, *bn_msc, *bn_msh;
     int bn_mtiles;
+    // bn_msc == nullptr: the mask comes from the layer's stored activation, passed as `res` (it is then NOT added):
+    // the layers whose activation had a residual added before the clip.  The partial rows of member m start at row
+    // m * bn_rows_member + bn_row0 (several launches -- the parity classes of a stride-2 data gradient -- share a table).
+    int bn_rows_member, bn_row0;
 };
 
 struct PlanB {
@@ -446,9 +450,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
         const size_t mo = (size_t)(tile_m / p.bn_mtiles) * p.Cout + col;      // this tile's member of the batch
         mu4 = *(const f32x4 *)(p.bn_mean + mo);
         is4 = *(const f32x4 *)(p.bn_invstd + mo);
-        msc4 = *(const f32x4 *)(p.bn_msc + mo);
-        msh4 = *(const f32x4 *)(p.bn_msh + mo);
+        if (p.bn_msc) {
+            msc4 = *(const f32x4 *)(p.bn_msc + mo);
+            msh4 = *(const f32x4 *)(p.bn_msh + mo);
+        }
     }
+    const bool mask_from_res = BNB && p.bn_msc == nullptr;
     auto fetch_rows = [&](int ms, int buf) {    // byte offsets and residual rows of sub-tile ms
 #pragma unroll
         for (int k = 0; k < NRI; ++k) {
@@ -487,8 +494,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                 if constexpr (BNB) {
                     // the layer's clipped-ReLU mask from its own pre-activation (the fma bn_apply_kernel evaluates)
                     const float zz = zv[cb][k][j];
-                    const float am = ds_bn_affine(zz, msc4[j], msh4[j]);
-                    t += resv[cb][k][j];
+                    const float rr = resv[cb][k][j];
+                    const float am = mask_from_res ? rr : ds_bn_affine(zz, msc4[j], msh4[j]);
+                    t += mask_from_res ? 0.0f : rr;
                     t = (am > 0.0f && am < 20.0f) ? t : 0.0f;
                     ps1[j] += live ? t : 0.0f;
                     ps2[j] += live ? t * ((zz - mu4[j]) * is4[j]) : 0.0f;
@@ -530,7 +538,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_mfma_bf16_kernel(const Conv
                 a1 += red[(k * NTILE + c) * 2 + 0];
                 a2 += red[(k * NTILE + c) * 2 + 1];
             }
-            float *dst = p.stats + ((size_t)tile_m * p.Cout + tile_n * NTILE + c) * 2;
+            size_t row = tile_m;
+            if constexpr (BNB) row = (size_t)(tile_m / p.bn_mtiles) * p.bn_rows_member + p.bn_row0 + tile_m % p.bn_mtiles;
+            float *dst = p.stats + (row * p.Cout + tile_n * NTILE + c) * 2;
             dst[0] = a1;
             dst[1] = a2;
         }

@@ -303,6 +303,14 @@ int ds_conv_dgrad_bnbwd_bf16(const ds_conv_shape *s, const float *gz_up, const v
                              const float *g2, const float *z, const float *mean, const float *invstd,
                              const float *mask_scale, const float *mask_shift, int G, float *gy, float *partial,
                              void *stream);
+/* the 5x5 stride-2 data gradient with the same fusion; it feeds a BasicBlock's OUTPUT out = clip(bn2(conv2(y)) + r)
+ * (model.py:76-80), whose mask needs the stored activation `act` (= the 5x5 layer's input, [B,H,W,Cin]); nothing is
+ * added.  Four parity-class launches write interleaved pixels of gy and consecutive blocks of the members' partial rows
+ * (ds_conv_dgrad_s2_bnbwd_bf16_rows: rows per member over all four). */
+int ds_conv_dgrad_s2_bnbwd_bf16_rows(const ds_conv_shape *s, int G);
+int ds_conv_dgrad_s2_bnbwd_bf16(const ds_conv_shape *s, const float *gz_up, const void *w_hi, const void *w_lo,
+                                const float *act, const float *z, const float *mean, const float *invstd, int G,
+                                float *gy, float *partial, void *stream);
 int ds_bn_bwd_group_finish_f32(const float *partial, int n_partial, const float *gy, const float *z, const float *mean,
                                const float *invstd, const float *gamma, float *coef, float *member_sums, float *ggamma,
                                float *gbeta, float *gz, long long n_pix, int C, int G, void *stream);

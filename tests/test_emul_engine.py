@@ -427,7 +427,8 @@ def test_fused_data_gradient_and_batchnorm_backward_equals_two_steps(grouped):
             eng.lib.trace = {}
             out[fuse] = backward.backward_train(eng, bn_w, pw, saved, ge, precision="bf16x3")
             assert eng.lib.trace.get("ds_conv_dgrad_bnbwd_bf16", 0) == (2 * n_stages if fuse else 0)
-            assert eng.lib.trace.get("ds_bn_bwd_group_finish_f32", 0) == (2 * n_stages if fuse else 0)
+            assert eng.lib.trace.get("ds_conv_dgrad_s2_bnbwd_bf16", 0) == (n_stages - 1 if fuse else 0)
+            assert eng.lib.trace.get("ds_bn_bwd_group_finish_f32", 0) == (3 * n_stages - 1 if fuse else 0)
     finally:
         backward.FUSE_DGRAD_BN_BWD = True
         eng.lib.trace = None

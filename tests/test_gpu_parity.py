@@ -437,8 +437,9 @@ def test_data_parallel_world1_nccl(dev, precision):
                 assert red.n_all_reduce == k * (2 * 12 + 5), red.n_all_reduce
                 # bf16x3: the reductions of 8 of the 12 layers run inside the data-gradient kernel above them
                 # (ds_conv_dgrad_bnbwd_bf16) wherever its tiles do not straddle members
-                fused = trace.get("ds_conv_dgrad_bnbwd_bf16", 0)
-                assert fused == 0 if precision == "f32" else fused in (8 * k, 6 * k, 4 * k), fused
+                # (and of 3 more inside the 5x5 stride-2 data gradient of the stage above: ds_conv_dgrad_s2_bnbwd_bf16)
+                fused = trace.get("ds_conv_dgrad_bnbwd_bf16", 0) + trace.get("ds_conv_dgrad_s2_bnbwd_bf16", 0)
+                assert fused == 0 if precision == "f32" else 4 * k <= fused <= 11 * k, fused
                 if grouped:     # the grouped launch sequence, split at the all-reduce -- no per-member fallback
                     assert trace.get("ds_bn_bwd_group_reduce_f32", 0) + fused == 12 and trace.get("ds_bn_bwd_group_apply_f32") == 12
                     assert "ds_bn_bwd_reduce_f32" not in trace
