@@ -123,8 +123,13 @@ class Engine:
         return out
 
     def pack_weights(self, sd: Dict[str, torch.Tensor], n_stages: int = 4,
-                     with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False) -> PackedWeights:
-        """OIHW / [out,in] parameters (reference shapes) -> kernel layouts."""
+                     with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False,
+                     f32_banks: bool = True) -> PackedWeights:
+        """OIHW / [out,in] parameters (reference shapes) -> kernel layouts.  `f32_banks=False`
+        (with_bf16): the f32 banks of the 3x3 / 5x5 layers are not built -- a bf16x3 training step re-packs every
+        filter after every optimizer step and never reads them (21 launches per step)."""
+        if not f32_banks and not with_bf16:
+            raise ValueError("f32_banks=False needs with_bf16=True")
         lib = self.lib
         stages = []
         for s in range(n_stages):
@@ -133,17 +138,19 @@ class Engine:
             self._check(w, f"model.conv{i}.weight")
             st = self._stream(w)
             co, ci = w.shape[0], w.shape[1]
-            pc = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+            pc = torch.empty(w.numel(), dtype=torch.float32, device=w.device) if (i == 1 or f32_banks) else None
             if i == 1:
                 lib.call("ds_pack_conv1_weight_f32", self._p(w), self._p(pc), co, st)
-            else:
+            elif f32_banks:
                 lib.call("ds_pack_conv_weight_f32", self._p(w), self._p(pc), co, ci, 5, 0, st)
             packs = []
             for j in (1, 2):
                 wl = sd[f"model.layer{i}.0.conv{j}.weight"].detach()
                 self._check(wl, f"model.layer{i}.0.conv{j}.weight")
-                pl = torch.empty(wl.numel(), dtype=torch.float32, device=wl.device)
-                lib.call("ds_pack_conv_weight_f32", self._p(wl), self._p(pl), co, co, 3, 0, st)
+                pl = None
+                if f32_banks:
+                    pl = torch.empty(wl.numel(), dtype=torch.float32, device=wl.device)
+                    lib.call("ds_pack_conv_weight_f32", self._p(wl), self._p(pl), co, co, 3, 0, st)
                 packs.append(pl)
             sw = StageWeights(pc, packs[0], packs[1])
             if with_f16:
@@ -164,7 +171,7 @@ class Engine:
                         sw.conv_dgrad_bf16 = (hi, lo)
                     sw.l_conv1_dgrad_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3, True)
                     sw.l_conv2_dgrad_bf16 = self._pack_bf16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3, True)
-            if with_dgrad:
+            if with_dgrad and f32_banks:
                 if i > 1:       # 5x5 stride 2: four parity-class banks (ds_conv_dgrad_f32)
                     sw.conv_dgrad = torch.empty_like(pc)
                     lib.call("ds_pack_conv_dgrad_s2_f32", self._p(w), self._p(sw.conv_dgrad), co, ci, st)

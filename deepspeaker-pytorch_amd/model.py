@@ -330,7 +330,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
     def forward(ctx, x, model, *params):
         eng = get_engine()
         prec = "bf16x3" if model.precision in ("bf16x3", "f16") else "f32"
-        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"))
+        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
         e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer, precision=prec)
         ctx.precision = prec
         model._bump_batches_tracked(1)        # nn.BatchNorm2d.train() bookkeeping, one launch
@@ -360,7 +360,7 @@ class _ResCNNTripletFn(torch.autograd.Function):
     def forward(ctx, xa, xp, xn, model, *params):
         eng = get_engine()
         prec = "bf16x3" if model.precision in ("bf16x3", "f16") else "f32"
-        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"))
+        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
         embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
                                               precision=prec)
         model._bump_batches_tracked(3)        # nn.BatchNorm2d.train() bookkeeping, one launch
@@ -499,18 +499,19 @@ class DeepSpeakerModel(nn.Module):
         sd["model.fc.bias"] = self.model.fc.bias
         return sd
 
-    def _packed(self, with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False):
+    def _packed(self, with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False, f32_banks: bool = True):
         """Kernel-layout copies of the filters for one set of consumers; one copy per variant is kept until a
         parameter changes (version counters), so alternating precisions do not re-pack."""
         sd = self._conv_fc_tensors()
         key = tuple((t.data_ptr(), t._version) for t in sd.values())
         if self._pack_key != key:
             self._pack_cache, self._pack_key = {}, key
-        variant = (with_dgrad, with_bf16, with_f16)
+        variant = (with_dgrad, with_bf16, with_f16, f32_banks)
         pw = self._pack_cache.get(variant)
         if pw is None:
             pw = self._pack_cache[variant] = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad,
-                                                                       with_bf16=with_bf16, with_f16=with_f16)
+                                                                       with_bf16=with_bf16, with_f16=with_f16,
+                                                                       f32_banks=f32_banks)
             pw.owner = id(self)         # lets the engine's plan cache drop this model's older generations
         return pw
 
