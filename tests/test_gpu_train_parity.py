@@ -196,3 +196,40 @@ def test_member_streams_forward_equals_three_calls_bitwise():
     for k, v in res["streams"][1].items():
         if v.is_floating_point():
             assert rel_err(v.cpu().numpy(), res["lock_step"][1][k].cpu().numpy()) < 2e-5, k
+
+
+@pytest.mark.parametrize("bm,frames", [(64, 160), (5, 37)])
+def test_fused_batchnorm_backward_reductions_equal_the_two_step_sequence(bm, frames):
+    """backward._dgrad_bn_bwd / _dgrad_s2_bn_bwd (the BatchNorm-backward reduction and the clipped-ReLU mask inside the
+    3x3 / 5x5-stride-2 data-gradient kernels' epilogues) against the separate data-gradient + reduction launches they
+    replace, on the GPU, for a batch of three members: the fused entry points are taken, and every gradient agrees to
+    the rounding of a differently ordered sum (the mask itself is bit-identical: same fma, same inputs).  (5, 37): odd
+    sizes -- ragged tiles, parity classes of different extents; there the planner decides which layers fuse."""
+    from deepspeaker_pytorch_amd import backward
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss, get_engine
+    sd = O.make_state_dict(seed=31, num_classes=16)
+    xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=bm, frames=frames)).cuda() for i in range(3)]
+    lib = get_engine().lib
+    out = {}
+    try:
+        for fuse in (True, False):
+            backward.FUSE_DGRAD_BN_BWD = fuse
+            m = build(sd, "bf16x3", 16)
+            lib.trace = {}
+            loss = TripletMarginLoss(0.1).forward(*m.forward_triplet(*xs))
+            loss.backward()
+            torch.cuda.synchronize()
+            n3, n5 = lib.trace.get("ds_conv_dgrad_bnbwd_bf16", 0), lib.trace.get("ds_conv_dgrad_s2_bnbwd_bf16", 0)
+            lib.trace = None
+            if fuse:
+                assert n3 >= 4 and n5 >= 1, (n3, n5)
+                print(f"\n[{3 * bm} x {frames} frames] fused reductions: {n3} of 8 3x3 layers, {n5} of 3 stride-2 layers")
+            else:
+                assert n3 == 0 and n5 == 0
+            out[fuse] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    finally:
+        backward.FUSE_DGRAD_BN_BWD = True
+        lib.trace = None
+    assert set(out[True]) == set(out[False]) and len(out[True]) == 38
+    for k, v in out[False].items():
+        assert rel_l2(out[True][k], v) < 1e-5, (k, rel_l2(out[True][k], v))
