@@ -149,7 +149,16 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3, int out_stride 
             const long long blocks = n_mt * (s->Cout / cf.NTILE), slots = 256ll * cf.wg_per_cu;
             if (blocks <= slots) eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, 256) * 256);
             else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
-            static const int pref[kNumCfgB] = {0, 2, 1, 8, 5, 6, 7, 4, 3};
+            // a launch with fewer waves than the chip has SIMDs leaves matrix cores idle: 256 two-wave workgroups (the
+            // 10x4 layers of one 256-utterance member) ran 156 us where 256 four-wave ones ran 128 (tools/conv_bf16_ab.py)
+            const long long waves = blocks * (cf.NTHR / 64);
+            if (waves < 1024) eff *= (double)waves / 1024.0;
+            // ties: 160x64 register tiles first; for 64 output channels the four-wave 256x64 tile beats the two-wave
+            // 320x64 one (same tool: 484 against 525 us at 768 utterances, 173 against 185 at 256)
+            int pref[kNumCfgB] = {0, 2, 7, 8, 5, 6, 1, 4, 3};
+#ifdef DS_BF16_PREF_TOP
+            pref[DS_BF16_PREF_TOP] = 9;                               // A/B builds (tools/conv_bf16_ab.py): another tie-break
+#endif
             eff += 1e-9 * rt + 1e-6 * pref[c];
             if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; }
         }

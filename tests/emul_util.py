@@ -27,7 +27,13 @@ def emul_lib():
     global _lib
     if _lib is None:
         if _stale():
-            subprocess.run([os.path.join(EMUL_DIR, "build_emul.sh")], check=True, capture_output=True)
+            # one builder at a time (pytest-xdist workers all arrive here with a stale library)
+            import fcntl
+            os.makedirs(os.path.join(EMUL_DIR, "_build"), exist_ok=True)
+            with open(os.path.join(EMUL_DIR, "_build", ".lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if _stale():
+                    subprocess.run([os.path.join(EMUL_DIR, "build_emul.sh")], check=True, capture_output=True)
         from deepspeaker_pytorch_amd._native import NativeLib
         _lib = NativeLib(EMUL_LIB)
     return _lib

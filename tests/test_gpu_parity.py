@@ -22,6 +22,13 @@ def dev():
     return torch.device("cuda", 0)
 
 
+@pytest.fixture(autouse=True)
+def _restore_engine_switches():
+    yield
+    from deepspeaker_pytorch_amd.engine import Engine
+    Engine.MEMBER_STREAMS = True
+
+
 def build_model(sd, n_stages=4, num_classes=16):
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel
     m = DeepSpeakerModel(512, num_classes, n_stages=n_stages)
@@ -417,9 +424,14 @@ def test_data_parallel_world1_nccl(dev, precision):
     sd = O.make_state_dict(seed=31, num_classes=16)
     xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=4)).cuda() for i in range(3)]
     lib = get_engine().lib
+    from deepspeaker_pytorch_amd.engine import Engine
     for grouped in (False, True):
         grads, losses, stats = [], [], []
         for dp in (False, True):
+            # the plain grouped step takes the lock-step forward here, like the data-parallel one: with one stream per
+            # member (the default without a reducer) the per-member launches may tile differently, the statistics then
+            # differ in the last bit, and one flipped clip mask is 4e-3 on conv1's gradient -- not what this test is about
+            Engine.MEMBER_STREAMS = False
             m = build_model(sd).train()
             m.precision = precision
             red = m.enable_data_parallel(force=True) if dp else None
@@ -446,6 +458,7 @@ def test_data_parallel_world1_nccl(dev, precision):
                     assert trace.get("ds_partial_sum_f64_group", 0) + trace.get("ds_partial_sum_f64", 0) // 3 == 12 + fused
                 else:
                     assert trace.get("ds_bn_bwd_reduce_f32", 0) + fused == 36 and trace.get("ds_bn_stats_from_sums_f32") == 36
+            Engine.MEMBER_STREAMS = True
             grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
             losses.append(float(loss))
             stats.append({k: v.clone() for k, v in m.state_dict().items() if "running" in k})
