@@ -736,8 +736,9 @@ class Engine:
         if x3 and pw.stages[0].l_conv1_bf16 is None:
             raise ValueError("pack_weights(..., with_bf16=True) is required for bf16x3")
         # (save=False frees a layer's buffers while other members' streams may still read them: lock-step then)
-        if self.MEMBER_STREAMS and save and x.is_cuda and G > 1 and not (reducer is not None and reducer.active):
-            return self._forward_train_group_streams(x, G, pw, bns, save, x3)
+        dp = reducer is not None and reducer.active
+        if self.MEMBER_STREAMS and save and x.is_cuda and G > 1 and (not dp or self.MEMBER_STREAMS_DP):
+            return self._forward_train_group_streams(x, G, pw, bns, save, x3, reducer if dp else None)
         saved = SavedForward(x=x) if save else None
         dev = x.device
 
@@ -842,7 +843,10 @@ class Engine:
     MEMBER_STREAMS = True      # forward_train_group on a GPU, single process: one HIP stream per member (see below)
     _member_streams: Dict[Tuple[torch.device, int], list] = {}
 
-    def _forward_train_group_streams(self, x, G: int, pw: PackedWeights, bns: Dict[str, BNParams], save: bool, x3: bool):
+    MEMBER_STREAMS_DP = True   # ... also under data parallelism (the members' streams meet at each layer's all-reduce)
+
+    def _forward_train_group_streams(self, x, G: int, pw: PackedWeights, bns: Dict[str, BNParams], save: bool, x3: bool,
+                                     reducer=None):
         """forward_train_group with every member's chain -- convolution, statistics, normalise + clip, layer after
         layer -- on a HIP stream of its own.  A train-mode layer is a matrix-core-bound convolution followed by
         HBM-bound element-wise passes that need the whole member's statistics first; in lock-step over one batch the
@@ -853,10 +857,12 @@ class Engine:
         backward pass does not change.  The running statistics are updated in call order (a, p, n): a member's
         finalize kernel waits for the previous member's of the same layer.  Everything that outlives the forward is
         allocated on the caller's stream before the fork; the side streams only allocate what they consume
-        themselves.  Data-parallel training keeps the lock-step form (its all-reduce carries all members' sums; giving
-        every member an all-reduce of its own from its own stream was measured: 23.0 ms against 20.2 ms lock-step with
-        one rank -- a process group runs its collectives on ONE internal stream, in issue order, each waiting for its
-        member's partial sums, so the three chains end up waiting for each other at every layer anyway)."""
+        themselves.  Data-parallel training (`reducer`): the members' streams meet at each layer's all-reduce, which
+        still carries all three members' sums in one collective (member 0's stream issues it after the other two have
+        folded their partial sums), and part again for their normalise + clip passes -- 20.55 -> 19.76 ms per step with
+        every collective forced on one rank (19.2 without collectives, same box).  (Measured and dropped: an all-reduce
+        per member from its own stream, 23.0 ms -- a process group runs its collectives on one internal stream in issue
+        order; HIP stream priorities to stagger the members, 29 ms.)"""
         B, _, T, F = x.shape
         Bm = B // G
         dev = x.device
@@ -866,6 +872,7 @@ class Engine:
             Engine._member_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(G)]
         streams = Engine._member_streams[key]
         saved = SavedForward(x=x) if save else None
+        keep = []                  # data-parallel: the layers' sum tables, alive until the streams have joined
         for st in streams:
             st.wait_stream(cur)
 
@@ -885,6 +892,48 @@ class Engine:
             flags = DS_EPI_CLIP | (DS_EPI_RESIDUAL if residual is not None else 0)
             prev_done = None
             per = []
+            if reducer is not None:
+                # data parallel: ONE all-reduce carries the three members' sums of this layer -- the members' streams
+                # meet there (member 0's stream issues it) and part again for their normalise + clip passes
+                sums = torch.empty((G, 2 * co + 1), dtype=torch.float64, device=dev)
+                keep.append(sums)
+                ready = []
+                for g in range(G):
+                    with torch.cuda.stream(streams[g]):
+                        if kind == "c1":
+                            _, stp = self.conv1(member(src, g), sw_f32, Bm, hh, ww, want_stats=True, lowp=x3, out=member(z, g))
+                        elif x3:
+                            _, stp = self.conv_bf16(member(src, g), sw_b, True, Bm, hh, ww, ci, co, ks, stride,
+                                                    want_stats=True, out=member(z, g))
+                        else:
+                            _, stp = self.conv(member(src, g), sw_f32, Bm, hh, ww, ci, co, ks, stride, want_stats=True,
+                                               out=member(z, g))
+                        self.lib.call("ds_partial_sum_f64_group", self._p(stp), stp.shape[0], self._p(sums[g]), count, co,
+                                      1, self._stream(z))
+                        ev = torch.cuda.Event()
+                        ev.record(streams[g])
+                        ready.append(ev)
+                with torch.cuda.stream(streams[0]):
+                    for ev in ready[1:]:
+                        streams[0].wait_event(ev)
+                    reducer.all_reduce_sum_(sums)
+                    reduced = torch.cuda.Event()
+                    reduced.record(streams[0])
+                for g in range(G):
+                    with torch.cuda.stream(streams[g]):
+                        streams[g].wait_event(reduced)
+                        if prev_done is not None:
+                            streams[g].wait_event(prev_done)      # running statistics: a, then p, then n
+                        self.lib.call("ds_bn_stats_from_sums_f32", self._p(sums[g]), 0, self._p(bn.weight.detach()),
+                                      self._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM, self._p(bn.running_mean),
+                                      self._p(bn.running_var), self._p(mean_all[g]), self._p(invstd_all[g]),
+                                      self._p(sc_all[g]), self._p(sh_all[g]), co, self._stream(z))
+                        prev_done = torch.cuda.Event()
+                        prev_done.record(streams[g])
+                        self.bn_apply(member(z, g), sc_all[g], sh_all[g],
+                                      member(residual, g) if residual is not None else None, flags, out=member(a, g))
+                        per.append((mean_all[g], invstd_all[g], sc_all[g], sh_all[g]))
+                return z, a, per, ho, wo
             for g in range(G):
                 with torch.cuda.stream(streams[g]):
                     if kind == "c1":

@@ -49,7 +49,6 @@ def test_bench_train_mode_collective_path():
     d = run_bench("--train", "--force-collectives", port=29544)
     assert d["unit"] == "utterances/s" and d["value"] > 1e3 and d["dtype"] == "bf16x3"
     assert d["all_reduce_per_step"] == 2 * 12 + 5 + 1, d["all_reduce_per_step"]
-    # measured 19.5 against 18.3 ms: 0.4 ms of collectives and partial-sum folds, 0.7 ms because the data-parallel forward
-    # runs its members in lock-step (one all-reduce carries all three members' sums) where the single-process forward
-    # gives each member a stream of its own (Engine._forward_train_group_streams)
-    assert d["ms_per_step"] < 1.12 * plain["ms_per_step"], (d["ms_per_step"], plain["ms_per_step"])
+    # measured 18.8 against 18.2 ms (the collectives of a group of one are latency only); the bound leaves room for
+    # box-to-box spread
+    assert d["ms_per_step"] < 1.10 * plain["ms_per_step"], (d["ms_per_step"], plain["ms_per_step"])

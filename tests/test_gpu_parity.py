@@ -409,8 +409,9 @@ def test_mining_kernel_vs_oracle(dev, N, M):
     assert torch.equal(idx2, idx) and torch.equal(dd2, dd) and torch.equal(mined.indices, idx)
 
 
+@pytest.mark.parametrize("streams", [False, True])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-def test_data_parallel_world1_nccl(dev, precision):
+def test_data_parallel_world1_nccl(dev, precision, streams):
     """Every data-parallel branch on RCCL with a single rank (Reducer(force=True)): float64 sums -> all-reduce ->
     *_from_sums kernels in the forward, the grouped BatchNorm backward split at its all-reduce, the gradient buckets
     reduced from inside the backward pass on the filter-gradient stream.  The step must equal the plain step and issue
@@ -428,10 +429,10 @@ def test_data_parallel_world1_nccl(dev, precision):
     for grouped in (False, True):
         grads, losses, stats = [], [], []
         for dp in (False, True):
-            # the plain grouped step takes the lock-step forward here, like the data-parallel one: with one stream per
-            # member (the default without a reducer) the per-member launches may tile differently, the statistics then
-            # differ in the last bit, and one flipped clip mask is 4e-3 on conv1's gradient -- not what this test is about
-            Engine.MEMBER_STREAMS = False
+            # both steps of a pair take the same forward -- lock-step over one batch, or one stream per member (under
+            # data parallelism the streams meet at each layer's all-reduce): the two forms may tile a layer differently,
+            # the statistics then differ in the last bit, and one flipped clip mask is 4e-3 on conv1's gradient
+            Engine.MEMBER_STREAMS = streams
             m = build_model(sd).train()
             m.precision = precision
             red = m.enable_data_parallel(force=True) if dp else None
@@ -455,7 +456,9 @@ def test_data_parallel_world1_nccl(dev, precision):
                 if grouped:     # the grouped launch sequence, split at the all-reduce -- no per-member fallback
                     assert trace.get("ds_bn_bwd_group_reduce_f32", 0) + fused == 12 and trace.get("ds_bn_bwd_group_apply_f32") == 12
                     assert "ds_bn_bwd_reduce_f32" not in trace
-                    assert trace.get("ds_partial_sum_f64_group", 0) + trace.get("ds_partial_sum_f64", 0) // 3 == 12 + fused
+                    # forward: one fold per layer for all members (lock-step) or one per layer and member (streams)
+                    assert (trace.get("ds_partial_sum_f64_group", 0) + trace.get("ds_partial_sum_f64", 0) // 3
+                            == (36 if streams else 12) + fused)
                 else:
                     assert trace.get("ds_bn_bwd_reduce_f32", 0) + fused == 36 and trace.get("ds_bn_stats_from_sums_f32") == 36
             Engine.MEMBER_STREAMS = True

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--grouped", action="store_true", help="model.forward_triplet instead of three calls")
     ap.add_argument("--no-overlap", action="store_true", help="filter gradients on the main stream (A/B of backward._FilterGradLane)")
     ap.add_argument("--no-fuse-bn", action="store_true", help="3x3 data gradients and the BatchNorm backward below them as separate launches (A/B of backward._dgrad_bn_bwd)")
+    ap.add_argument("--force-dp", action="store_true", help="every data-parallel branch with one rank (RCCL)")
+    ap.add_argument("--no-dp-streams", action="store_true", help="data-parallel forward in lock-step (A/B of Engine.MEMBER_STREAMS_DP)")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side profile of the timed steps")
     args = ap.parse_args()
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, TripletMarginLoss
@@ -35,6 +37,14 @@ def main():
     model = DeepSpeakerModel(512, 1211, precision=args.precision)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     model = model.to(dev).train()
+    from deepspeaker_pytorch_amd.engine import Engine
+    Engine.MEMBER_STREAMS_DP = not args.no_dp_streams
+    if args.force_dp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        model.enable_data_parallel(force=True)
     from deepspeaker_pytorch_amd.optim import create_optimizer
     opt = create_optimizer(model, 0.1)              # fused multi-tensor Adagrad (train_triplet.py:379-382)
     g = torch.Generator().manual_seed(5)
