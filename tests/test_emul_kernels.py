@@ -437,3 +437,37 @@ def test_conv_fwd_bf16(case, x3):
     tot = stats.astype(np.float64).sum(axis=0)
     np.testing.assert_allclose(tot[:, 0], z.sum(axis=(0, 2, 3)), rtol=2e-2 if not x3 else 1e-4,
                                atol=0.5 if not x3 else 1e-3)
+
+
+def test_bf16_planner_counts_waves_and_members():
+    """Host-side plans of the split-operand bf16 convolution at the training step's sizes (the planner is plain host code:
+    the emulated library runs it as is).  A launch with fewer waves than the chip has SIMDs is priced as such -- the 10x4
+    layers of ONE 256-utterance member get four-wave workgroups (256 two-wave ones ran 156 us, 256 four-wave ones 128) --
+    and the 64-channel 3x3 layers take the four-wave 256x64 tile (484 against 525 us at 768 utterances for the two-wave
+    320x64 one).  The fused data-gradient + BatchNorm-backward entry points report which geometries they take for a
+    batch of three members: tiles must not straddle members."""
+    lib = emul_lib()
+    out8 = (ctypes.c_int * 8)()
+
+    def plan(*shape):
+        lib.call("ds_conv_bf16_plan_describe", ctypes.byref(ConvShape(*shape)), 1, out8)
+        return {"tile": (out8[0], out8[1]), "ni": out8[3], "grid": out8[4], "threads": out8[6]}
+
+    one_member = plan(256, 10, 4, 512, 512, 3, 1)
+    assert one_member["threads"] == 256 and one_member["grid"] * (one_member["threads"] // 64) >= 1024, one_member
+    batch = plan(768, 10, 4, 512, 512, 3, 1)
+    assert batch["grid"] * (batch["threads"] // 64) >= 1024, batch
+    for b in (256, 768):
+        s1 = plan(b, 80, 32, 64, 64, 3, 1)
+        assert s1["tile"] == (256, 64) and s1["threads"] == 256, s1
+    rows = lib.raw("ds_conv_dgrad_bnbwd_bf16_rows")
+    rows5 = lib.raw("ds_conv_dgrad_s2_bnbwd_bf16_rows")
+    for h, w, c in ((80, 32, 64), (40, 16, 128), (20, 8, 256)):
+        assert rows(ctypes.byref(ConvShape(768, h, w, c, c, 3, 1)), 3) > 0, (h, w, c)
+        assert rows(ctypes.byref(ConvShape(768, h, w, c, c, 3, 1)), 1) > 0
+    assert rows5(ctypes.byref(ConvShape(768, 80, 32, 64, 128, 5, 2)), 3) > 0
+    # three 40-pixel images per tile straddle members of 256 utterances: the caller falls back to the two-step sequence
+    assert rows(ctypes.byref(ConvShape(768, 10, 4, 512, 512, 3, 1)), 3) < 0
+    assert rows(ctypes.byref(ConvShape(768, 10, 4, 512, 512, 3, 1)), 1) > 0
+    assert rows(ctypes.byref(ConvShape(768, 80, 32, 64, 64, 3, 1)), 5) < 0      # 768 utterances are not 5 members
+    assert rows5(ctypes.byref(ConvShape(768, 80, 32, 64, 128, 3, 1)), 3) < 0    # not a 5x5 stride-2 layer
