@@ -87,11 +87,70 @@ def cpu_baseline(sd_np, budget_s=9.0):
                     break
             by_batch[B] = (n / dt, n, reps, dt)
     v32, v256 = by_batch[32], by_batch[256]
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": round(v32[0], 1), "unit": "embeddings/s", "cores": cores, "host_cores": ncpu, "kind": "port",
+            "cpu_model": cpu_model,
             "value_b256": round(v256[0], 1),
             "sample": f"B=32: {v32[1]} utterances [1,{FRAMES},64] ({v32[2]} forwards, {v32[3]:.1f} s); B=256: {v256[1]} "
                       f"utterances ({v256[2]} forwards, {v256[3]:.1f} s); eval forward, fp32, torch {torch.__version__} CPU, "
                       f"{cores} threads (best of a scan over 8..128; the host has {ncpu})"}
+
+
+def _backend():
+    """"nccl" (= RCCL on ROCm); DS_BENCH_BACKEND=gloo only for the CPU test of the launch logic"""
+    return os.environ.get("DS_BENCH_BACKEND", "nccl")
+
+
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: spawn N ranks of this script under torch.distributed.run (the
+    command the driver would have used) and return its exit status.  Refuses up front when the host has fewer
+    devices than ranks, so that the failure is one clear line and not N stack traces."""
+    import socket
+    import subprocess
+    if _backend() == "nccl":
+        have = torch.cuda.device_count()
+        if have < n_gpus:
+            print(f"bench.py --gpus {n_gpus}: needs {n_gpus} devices, this host shows {have} "
+                  f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')})", file=sys.stderr)
+            return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print("[bench] no launcher (WORLD_SIZE unset): " + " ".join(cmd), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_selftest(rank, local_rank, world):
+    """--launch-selftest: the launch / rendezvous / one-line contract without the workload (what the CPU test of
+    the self-launcher runs under gloo, and a 10-second check of a new multi-GPU node under RCCL)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = _backend()
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group(backend)
+    assert dist.get_world_size() == world and dist.get_rank() == rank
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launch selftest", "n_gpus": world, "world_size": dist.get_world_size(),
+                          "rank_sum": float(t.item()), "backend": backend}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -127,14 +186,24 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (train-mode forward of the 768 utterances, triplet loss, "
                          "backward, gradient all-reduce, fused Adagrad): the step with collectives on its critical path")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="only rendezvous, one all-reduce and the one-line print (checks the launcher, not the kernels)")
     args = ap.parse_args()
 
     ablate = set(a for a in args.ablate.split(",") if a)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become the launcher (one rank per GPU), rank 0 of the children prints the line
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}: pass --gpus {world} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it spawns its own ranks)")
+    if args.launch_selftest:
+        return launch_selftest(rank, local_rank, world)
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: needs device {local_rank}, this host shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -211,9 +280,13 @@ def main():
             elapsed = float(t.item())
         return elapsed, t_enq
 
+    def pre_steps(warmup):
+        """untimed settle-in steps run BEFORE the W contract warm-ups (reported as `pre_steps` in the line)"""
+        return max(0, 30 - warmup)
+
     def timed(step, steps, warmup, repeats=0):
         eng.profile = []                        # warm-up with the event instrumentation on: the first
-        for _ in range(max(0, 30 - warmup)):    # timing events of a process cost ~40 ms to create; and a fresh
+        for _ in range(pre_steps(warmup)):      # timing events of a process cost ~40 ms to create; and a fresh
             step()                              # box needs ~0.2 s of work before clocks / caches settle (setup,
         fence()                                 # not part of the W contract warm-up steps that follow)
         eng.profile = []
@@ -405,7 +478,9 @@ def main():
             line = {
                 "metric": "training utterances/sec (64-fbank x 160-frame utterances)",
                 "value": round(emb_per_step * args.steps / elapsed, 1), "unit": "utterances/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "steps": args.steps, "warmup": args.warmup, "pre_steps": pre_steps(args.warmup),
+                "world_size": dist.get_world_size() if multi else 1,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": tprec, "data": "synthetic",
                 "config": {"workload": "triplet-regime training step (train_triplet.py:215-224): train-mode forward of "
                                        "256 triplets = 768 x [1,160,64] utterances per GPU, triplet loss, backward, "
@@ -443,7 +518,8 @@ def main():
         out = {
             "metric": "embeddings/sec (64-fbank x 160-frame utterances)",
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "warmup": args.warmup, "pre_steps": pre_steps(args.warmup),
+            "world_size": dist.get_world_size() if multi else 1, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic" + (" (ABLATED: " + ",".join(sorted(ablate)) + " -- not the contract workload)" if ablate else ""),
             "config": {"workload": "BASELINE configs[1]: full DeepSpeaker ResCNN (64/128/256/512) eval forward + "

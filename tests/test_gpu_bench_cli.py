@@ -52,3 +52,20 @@ def test_bench_train_mode_collective_path():
     # measured 18.8 against 18.2 ms (the collectives of a group of one are latency only); the bound leaves room for
     # box-to-box spread
     assert d["ms_per_step"] < 1.10 * plain["ms_per_step"], (d["ms_per_step"], plain["ms_per_step"])
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_is_a_clear_refusal():
+    """`python bench.py --gpus 2` without a launcher spawns its own ranks; on a box with one device it must say so in
+    one line (rc 2), not die inside the launcher."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has >= 2 devices: the launch would go through")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 2 and "needs 2 devices" in out.stderr and "Traceback" not in out.stderr
+
+
+def test_bench_line_reports_hidden_warmups_and_world():
+    d = run_bench(port=29546)
+    assert d["pre_steps"] == 29 and d["world_size"] == 1
