@@ -286,16 +286,18 @@ class _FilterGradLane:
 
 class _GradBuckets:
     """The filter / fc gradients of one backward pass, laid out as one flat buffer per stage (+ one for fc): the
-    gradient kernels write straight into views of their bucket, and under data parallelism each bucket's
-    all-reduce is launched the moment its last gradient kernel has been enqueued -- it then runs over xGMI while
-    the earlier stages' backward kernels execute.  BatchNorm affine gradients come out of the (already global)
-    statistic sums and are not reduced."""
+    gradient kernels write straight into views of their bucket.  Under data parallelism each bucket is summed over
+    the ranks either the moment its last gradient kernel has been enqueued -- it then travels over xGMI while the
+    earlier stages' backward kernels execute; needs the buckets' own communicator, Reducer(grad_comm="separate") --
+    or, on the shared communicator (default), right after the pass.  BatchNorm affine gradients come out of the
+    (already global) statistic sums and are not reduced."""
 
     def __init__(self, shapes: Dict[int, Dict[str, tuple]], device, reducer=None):
         self.reducer = reducer if (reducer is not None and reducer.active) else None
         self.views: Dict[str, torch.Tensor] = {}
         self.flat: Dict[int, torch.Tensor] = {}
         self.work = []
+        self.deferred = []              # buckets whose exchange waits for finish() (Reducer.overlap_gradients False)
         for b, names in shapes.items():
             n = sum(int(torch.Size(shp).numel()) for shp in names.values())
             flat = torch.empty(n, dtype=torch.float32, device=device)
@@ -307,12 +309,22 @@ class _GradBuckets:
                 off += k
 
     def done(self, bucket: int):
-        if self.reducer is not None:
+        """the bucket's last gradient kernel has been enqueued (on the current stream)"""
+        if self.reducer is None:
+            return
+        if self.reducer.overlap_gradients:      # own communicator: reduce now, under the earlier stages' kernels
             self.work.append(self.reducer.all_reduce_sum_(self.flat[bucket], async_op=True, gradients=True))
+        else:                                   # shared communicator: after the pass's last BatchNorm collective
+            self.deferred.append(bucket)
 
     def finish(self):
+        """called on the main stream after the filter-gradient stream has joined it"""
+        for b in self.deferred:
+            self.work.append(self.reducer.all_reduce_sum_(self.flat[b], async_op=True, gradients=True))
+        self.deferred = []
         for h in self.work:
-            h.wait()
+            if h is not None:
+                h.wait()
         self.work = []
 
 

@@ -5,6 +5,11 @@
 //   * OIHW -> packed filter layouts, NCHW <-> channels-last conversion
 #include <ds_device.h>
 #include "ds_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+#include <stdlib.h>
 
 namespace {
 
@@ -298,23 +303,71 @@ extern "C" int ds_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H
     return ds_last_launch_error();
 }
 
-// Scheduling slots of the persistent kernels (ds_device.h).  The emulator build has no HIP runtime: host memory.
-unsigned *ds_sched_slot() {
-    static unsigned *slots = nullptr;
-    static unsigned seq = 0;
-    if (!slots) {
+// Scheduling slots of the persistent kernels (ds_device.h): tile counters that must be private to whatever can be in
+// flight at the same time.
+//   * Eager launches take the next of DS_SCHED_RING slots of their own (device, stream): launches of one stream run in
+//     order, so the only launches that can ever share a slot are ones the stream itself serialises -- whatever other
+//     streams, graphs or processes' worth of persistent launches are enqueued in between (a process-wide round-robin,
+//     as before round 4, handed the slot of a kernel still queued on stream A to the 65th launch enqueued on stream B).
+//   * A launch that is being CAPTURED into a graph keeps a slot of its own for good: the node carries the pointer and
+//     can replay on any stream next to anything.
+// Slots are carved from per-device chunks (zeroed when allocated; a kernel leaves its slot zeroed).  Host side is
+// serialised by a mutex.  The emulator build has no HIP runtime: host memory.
+namespace {
+struct SchedPool {
+    std::mutex mu;
+    struct Chunk { unsigned *base; size_t used; };
+    std::map<int, std::vector<Chunk>> chunks;                               // device -> chunks
+    std::map<std::pair<int, void *>, std::pair<unsigned *, unsigned>> rings;  // (device, stream) -> (ring base, next)
+    static constexpr size_t CHUNK_SLOTS = 1024;                             // 64 KiB per chunk
+
+    unsigned *carve(int dev, size_t n_slots) {
+        auto &v = chunks[dev];
+        if (v.empty() || v.back().used + n_slots > CHUNK_SLOTS) {
+            const size_t bytes = CHUNK_SLOTS * DS_SCHED_WORDS * sizeof(unsigned);
 #ifdef DS_EMULATED
-        static unsigned host_slots[DS_SCHED_SLOTS * DS_SCHED_WORDS];
-        slots = host_slots;
+            void *p = calloc(1, bytes);
+            if (!p) return nullptr;
 #else
-        void *p = nullptr;
-        if (hipMalloc(&p, DS_SCHED_SLOTS * DS_SCHED_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, DS_SCHED_SLOTS * DS_SCHED_WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
-        slots = (unsigned *)p;
+            void *p = nullptr;      // (fails inside a stream capture: a capture's first persistent launch must have
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }    // been warmed up eagerly)
+            if (hipMemset(p, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipFree(p);
+                return nullptr;
+            }
 #endif
+            v.push_back({(unsigned *)p, 0});
+        }
+        unsigned *r = v.back().base + v.back().used * DS_SCHED_WORDS;
+        v.back().used += n_slots;
+        return r;
     }
-    const unsigned k = __atomic_fetch_add(&seq, 1u, __ATOMIC_RELAXED) % DS_SCHED_SLOTS;
-    return slots + (size_t)k * DS_SCHED_WORDS;
+};
+SchedPool &sched_pool() { static SchedPool p; return p; }
+}  // namespace
+
+unsigned *ds_sched_slot(void *stream) {
+    SchedPool &P = sched_pool();
+    int dev = 0;
+    bool capturing = false;
+#ifndef DS_EMULATED
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
+    else (void)hipGetLastError();
+#endif
+    std::lock_guard<std::mutex> lock(P.mu);
+    if (capturing) return P.carve(dev, 1);
+    auto key = std::make_pair(dev, stream);
+    auto it = P.rings.find(key);
+    if (it == P.rings.end()) {
+        unsigned *base = P.carve(dev, DS_SCHED_RING);
+        if (!base) return nullptr;
+        it = P.rings.emplace(key, std::make_pair(base, 0u)).first;
+    }
+    const unsigned k = it->second.second++ % DS_SCHED_RING;
+    return it->second.first + (size_t)k * DS_SCHED_WORDS;
 }
 
 extern "C" int ds_version(void) { return 301; }   // 30x: round-3 ABI (300: split grouped BatchNorm backward for data parallelism, grouped f64 sums; 301: + ds_conv_dgrad_bnbwd_bf16, ds_bn_bwd_group_finish_f32)

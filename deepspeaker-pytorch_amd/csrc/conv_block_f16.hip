@@ -576,7 +576,7 @@ static int conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_
     int grid = k.n_tiles < resident ? k.n_tiles : resident;
     k.xcd_slots = 0;
     if (B >= 8 && grid == resident && resident % 8 == 0) k.xcd_slots = resident / 8;
-    k.sched = ds_sched_slot();
+    k.sched = ds_sched_slot(stream);
     DS_REQUIRE(k.sched != nullptr, DS_ERR_UNSUPPORTED);
     k.sched_lds = (int)block_lds_bytes(W, C, 2) - 16;
     if (C == 64) {          // W = 32: 2 x 1 waves, 12 x 32 x 4 items over 128 threads

@@ -366,7 +366,7 @@ static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w
 #endif
     const bool persistent = k.n_splits == 1 && !(flags & DS_CONV_HINT_NO_PERSIST) && plan_persistent(pl, s);
     if (persistent) {
-        k.sched = ds_sched_slot();
+        k.sched = ds_sched_slot(stream);
         DS_REQUIRE(k.sched != nullptr, DS_ERR_UNSUPPORTED);
         k.sched_lds = (int)pl.lds_bytes - 16;       // the plan's LDS size ends with tables the persistent kernel does not use
         if (s->KS == 3) ds_f16_launch_pk3(pl, stream);

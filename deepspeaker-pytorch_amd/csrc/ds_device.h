@@ -162,14 +162,15 @@ static inline int ds_cu_count() {
 // a workgroup that starts late -- its CU was busy with another stream's kernel -- simply takes fewer tiles (a static
 // stride over the tiles makes the kernel as slow as its unluckiest workgroup: measured 302 -> 617 us on one launch next
 // to a side stream).  A slot is 16 words: next[0..7] (one queue per XCD, or only [0]), done at [8].  The last workgroup
-// to finish zeroes the slot again, so a slot needs no memset between launches; launches in flight at the same time get
-// different slots (a process-wide sequence number).  The slots are the ONE piece of device memory the library owns:
-// 64 x 64 bytes, allocated and zeroed on first use.
-constexpr int DS_SCHED_SLOTS = 64, DS_SCHED_WORDS = 16, DS_SCHED_DONE = 8;
+// to finish zeroes the slot again, so a slot needs no memset between launches.  Slots are private to what can run
+// concurrently: a ring per (device, stream) for eager launches -- a stream orders its own launches -- and a slot of its
+// own, for good, for every launch captured into a graph (ds_sched_slot, bn_pack.hip).  They are the ONE kind of device
+// memory the library owns: 64-byte slots carved from 64 KiB chunks allocated and zeroed on first use.
+constexpr int DS_SCHED_RING = 8, DS_SCHED_WORDS = 16, DS_SCHED_DONE = 8;
 __device__ __forceinline__ unsigned ds_atomic_inc(unsigned *p) {
     return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-unsigned *ds_sched_slot();          // bn_pack.hip
+unsigned *ds_sched_slot(void *stream);          // bn_pack.hip
 // a value every lane holds identically, as a scalar (tile indices read back from LDS)
 __device__ __forceinline__ int ds_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -30,10 +30,45 @@ import torch
 import torch.distributed as dist
 
 
-class Reducer:
-    """Thin handle on a process group (backend "nccl" = RCCL on ROCm; "gloo" in the CPU logic tests)."""
+class _Handles:
+    """wait() on several collective handles in issue order (what an rs_ag gradient exchange returns)"""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, force: bool = False):
+    def __init__(self, hs, after=None):
+        self.hs, self.after = [h for h in hs if h is not None], after
+
+    def wait(self):
+        for h in self.hs:
+            h.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
+
+
+class Reducer:
+    """Thin handle on a process group (backend "nccl" = RCCL on ROCm; "gloo" in the CPU logic tests).
+
+    Gradient exchange knobs (constructor arguments, else the environment, else the safe default):
+
+    * `grad_comm` / DS_GRAD_COMM = "shared" (default) | "separate".  A process group runs ALL its collectives in issue
+      order on one internal stream: with one communicator, a BatchNorm statistics all-reduce (main stream, critical
+      path) issued after a gradient-bucket all-reduce (filter-gradient stream) waits for that stream's kernels --
+      measured with one rank: 0 ms of overlap, +2.2 ms per step.  "separate" puts the buckets on a communicator of
+      their own (`dist.new_group`, or a pre-built `grad_group`) and reduces each bucket from inside the backward pass.
+      Two communicators driven concurrently from two streams of one device are only safe if every rank's device-side
+      launch order agrees; that has never run on more than one real GPU here, so it is OPT-IN.  "shared" keeps one
+      communicator and issues the buckets after the backward pass's last BatchNorm collective (no overlap with the
+      pass; one program-ordered sequence of collectives per rank -- cannot deadlock).
+    * `grad_reduce` / DS_GRAD_REDUCE = "allreduce" (default) | "rs_ag": the bucket exchange as ONE all-reduce
+      (whatever algorithm RCCL picks) or as an explicit reduce-scatter + all-gather pair (the direct
+      exchange that keeps all 7 xGMI links busy with 1/N-sized shards).  Same sums; A/B-able the day a node exists.
+
+    `dist.new_group` is a collective over the DEFAULT group: with grad_comm="separate" and no `grad_group`, every
+    rank of the job must construct its Reducer at the same point (enable_data_parallel), also ranks outside `group`.
+    """
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, force: bool = False,
+                 grad_comm: Optional[str] = None, grad_reduce: Optional[str] = None,
+                 grad_group: Optional[dist.ProcessGroup] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised: launch one process per GPU with "
                                "torch.distributed.run and call dist.init_process_group('nccl') first")
@@ -41,26 +76,64 @@ class Reducer:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         # `active`: take the data-parallel launch sequence (float64 sums -> all-reduce -> *_from_sums kernels, gradient
-        # buckets reduced from inside the backward pass, all-gather / reduce-scatter of embeddings).  A group of one
+        # buckets reduced by the backward pass, all-gather / reduce-scatter of embeddings).  A group of one
         # has nothing to exchange and skips it -- unless `force` (or DS_FORCE_COLLECTIVES=1) asks for the very same
         # sequence an N-rank job runs, collectives included: how the path is exercised on a single GPU.
         self.active = self.world > 1 or force or os.environ.get("DS_FORCE_COLLECTIVES", "0") == "1"
-        self.n_all_reduce = 0           # collectives issued so far (tests assert the per-step count)
-        # The gradient buckets travel on a communicator of their own.  A process group runs ALL its collectives in
-        # issue order on one internal stream: with a single group, a BatchNorm statistics all-reduce (issued from the
-        # main stream, on the critical path) queued behind the bucket all-reduce issued just before it from the
-        # filter-gradient stream -- i.e. behind that stream's gradient kernels -- and the two streams of the backward
-        # pass ran one after the other (measured: 0 ms of overlap, +2.2 ms per step).  Created collectively: every
-        # rank constructs its Reducer at the same point (enable_data_parallel).
+        self.n_all_reduce = 0           # gradient / statistics exchanges issued so far (tests assert the per-step count)
+        self.grad_comm = grad_comm or os.environ.get("DS_GRAD_COMM", "shared")
+        self.grad_reduce = grad_reduce or os.environ.get("DS_GRAD_REDUCE", "allreduce")
+        if self.grad_comm not in ("shared", "separate"):
+            raise ValueError(f"grad_comm / DS_GRAD_COMM must be 'shared' or 'separate', got {self.grad_comm!r}")
+        if self.grad_reduce not in ("allreduce", "rs_ag"):
+            raise ValueError(f"grad_reduce / DS_GRAD_REDUCE must be 'allreduce' or 'rs_ag', got {self.grad_reduce!r}")
         self.grad_group = group
-        if self.active:
+        if grad_group is not None:
+            self.grad_group, self.grad_comm = grad_group, "separate"
+        elif self.active and self.grad_comm == "separate":
             ranks = dist.get_process_group_ranks(group) if group is not None else None
             self.grad_group = dist.new_group(ranks=ranks)
+        # buckets are reduced from inside the backward pass (overlapped) only when they have their own communicator
+        self.overlap_gradients = self.grad_comm == "separate"
 
     def all_reduce_sum_(self, t: torch.Tensor, async_op: bool = False, gradients: bool = False):
         self.n_all_reduce += 1
+        if gradients and self.grad_reduce == "rs_ag" and self.world > 1:
+            return self._rs_ag_sum_(t, async_op)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.grad_group if gradients else self.group,
                                async_op=async_op)
+
+    def _rs_ag_sum_(self, flat: torch.Tensor, async_op: bool):
+        """In-place sum over the ranks of a flat bucket as reduce-scatter + all-gather (each rank reduces one 1/N
+        shard, then the shards are gathered back).  The bucket is padded to a multiple of the world size in a
+        staging buffer when needed."""
+        g, w = self.grad_group, self.world
+        n = flat.numel()
+        per = -(-n // w)
+        src = flat.reshape(-1)
+        staged = None
+        if per * w != n or not src.is_contiguous():
+            staged = torch.zeros(per * w, dtype=flat.dtype, device=flat.device)
+            staged[:n].copy_(src)
+            src = staged
+        shard = torch.empty(per, dtype=flat.dtype, device=flat.device)
+        if dist.get_backend(g) == "gloo":               # gloo (CPU logic tests) has no reduce-scatter
+            full = src.clone()
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=g)
+            shard.copy_(full[self.rank * per:(self.rank + 1) * per])
+            h1 = None
+        else:
+            h1 = dist.reduce_scatter_tensor(shard, src, op=dist.ReduceOp.SUM, group=g, async_op=async_op)
+        h2 = dist.all_gather_into_tensor(src, shard, group=g, async_op=async_op)
+        after = None
+        if staged is not None:
+            def after():
+                flat.reshape(-1).copy_(staged[:n])
+        if async_op:
+            return _Handles([h1, h2], after)
+        if after is not None:
+            after()
+        return None
 
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
         """[n, ...] on every rank -> [world*n, ...], rank-major (equal n on all ranks)."""

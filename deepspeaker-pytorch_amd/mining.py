@@ -264,12 +264,15 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     side = _side_stream(a.device) if side_stream else main
     # the f32-class path's packed filters / folded BatchNorm are built HERE, on the caller's stream, if they do not
     # exist yet: built inside the side-stream section, a later main-stream use would not be ordered after the packing
-    model._packed(with_bf16=True)
-    model._folded()
+    pw_ref = model._packed(with_bf16=True)
+    folded_ref = model._folded()
 
     def embed_all():
-        """the overflow action / the whole-batch tier: every triplet decided on f32-class embeddings"""
-        e = model.embed_reference(torch.cat(xs))
+        """the overflow action / the whole-batch tier: every triplet decided on f32-class embeddings.  Runs with the
+        packed filters and folded BatchNorm of THIS call (pinned above): an overflow is resolved when the selection
+        is read, possibly after an optimizer step or a train-mode forward has changed the model -- the replacement
+        must come from the weights that produced the embeddings it replaces."""
+        e = eng.forward_eval_planned(torch.cat(xs), pw_ref, folded_ref, precision="bf16x3")
         return eng.triplet_tail(*(r.contiguous() for r in e.split(n_trip)), margin)
 
     if side_stream:
@@ -290,7 +293,7 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
             for k, x in enumerate(xs):
                 eng.lib.call("ds_gather_rows_f32", eng._p(x), eng._p(t["amb_idx"]), eng._p(xr[k * cap:(k + 1) * cap]), cap,
                              rows, st)
-            e_ref = model.embed_reference(xr)
+            e_ref = eng.forward_eval_planned(xr, pw_ref, folded_ref, precision="bf16x3")
             d_p, d_n = t["d_p"].clone(), t["d_n"].clone()
             eng.lib.call("ds_refine_distances_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
                          eng._p(d_p), eng._p(d_n), a.shape[1], st)

@@ -470,8 +470,10 @@ class DeepSpeakerModel(nn.Module):
         mods = self._bn_modules()
         flat = getattr(self, "_nbt_flat", None)
         first = mods[0].num_batches_tracked
-        if (flat is None or flat.device != first.device or first.data_ptr() != flat.data_ptr()
-                or mods[-1].num_batches_tracked.data_ptr() != flat.data_ptr() + 8 * (len(mods) - 1)):
+        # every module's counter must still be ITS view (load_state_dict(assign=True), a manual buffer replacement or a
+        # partial _apply can re-assign any one of them; host-side pointer compares, no device work)
+        if (flat is None or flat.device != first.device
+                or any(m.num_batches_tracked.data_ptr() != flat.data_ptr() + 8 * i for i, m in enumerate(mods))):
             flat = torch.stack([m.num_batches_tracked.reshape(()) for m in mods]).to(torch.int64)
             for i, m in enumerate(mods):
                 m._buffers["num_batches_tracked"] = flat[i]
@@ -528,7 +530,8 @@ class DeepSpeakerModel(nn.Module):
         return self._fold_cache
 
     # ---- data-parallel training (new capability; the reference is single-GPU) ----
-    def enable_data_parallel(self, process_group=None, force: bool = False):
+    def enable_data_parallel(self, process_group=None, force: bool = False, grad_comm=None, grad_reduce=None,
+                             grad_group=None):
         """One process per GPU (torch.distributed backend "nccl" = RCCL).  From now on train-mode forwards and
         their backward use global-batch BatchNorm statistics (all-reduced over the ranks -- one collective per
         BatchNorm layer when the step goes through `forward_triplet`), and the backward pass all-reduces the
@@ -539,7 +542,9 @@ class DeepSpeakerModel(nn.Module):
         from .distributed import Reducer
         # force: run the data-parallel launch sequence (collectives included) even in a group of one -- the way the
         # path is exercised and timed on a single GPU (bench.py --force-collectives)
-        self._reducer = Reducer(process_group, force=force)
+        # grad_comm / grad_reduce / grad_group: how the gradient buckets travel (distributed.Reducer)
+        self._reducer = Reducer(process_group, force=force, grad_comm=grad_comm, grad_reduce=grad_reduce,
+                                grad_group=grad_group)
         return self._reducer
 
     def allreduce_gradients(self):

@@ -189,9 +189,9 @@ static inline int ds_cu_count() {
 }
 
 // dynamic tile scheduling of the persistent kernels (see csrc/ds_device.h): blocks run on several OS threads here
-constexpr int DS_SCHED_SLOTS = 64, DS_SCHED_WORDS = 16, DS_SCHED_DONE = 8;
+constexpr int DS_SCHED_RING = 8, DS_SCHED_WORDS = 16, DS_SCHED_DONE = 8;
 static inline unsigned ds_atomic_inc(unsigned *p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
-unsigned *ds_sched_slot();          // bn_pack.hip
+unsigned *ds_sched_slot(void *stream);          // bn_pack.hip
 static inline int ds_uniform(int v) { return v; }
 static inline float ds_bn_affine(float z, float scale, float shift) { return __builtin_fmaf(z, scale, shift); }
 

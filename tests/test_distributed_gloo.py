@@ -72,14 +72,14 @@ def _run(rank, world, mine, reducer, N_STAGES=2):
     return out
 
 
-def _worker(rank, world, port, mine, outdir, n_stages=2, force=False):
+def _worker(rank, world, port, mine, outdir, n_stages=2, force=False, grad_comm=None, grad_reduce=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _setup_paths()
     from deepspeaker_pytorch_amd.distributed import Reducer
-    out = _run(rank, world, mine, Reducer(force=force), n_stages)
+    out = _run(rank, world, mine, Reducer(force=force, grad_comm=grad_comm, grad_reduce=grad_reduce), n_stages)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -146,6 +146,38 @@ def test_forced_data_parallel_sequence_with_one_rank(tmp_path, mine):
     RCCL."""
     mp.spawn(_worker, args=(1, _free_port(), mine, str(tmp_path), 2, True), nprocs=1, join=True)
     _check_against_single_process(tmp_path, 1, mine, 2)
+
+
+@pytest.mark.parametrize("grad_comm,grad_reduce", [("separate", "allreduce"), ("shared", "rs_ag"), ("separate", "rs_ag")])
+def test_gradient_exchange_variants_are_the_same_step(tmp_path, grad_comm, grad_reduce):
+    """Reducer(grad_comm=..., grad_reduce=...): the buckets on their own communicator (reduced from inside the backward
+    pass) or on the shared one (after it), as one all-reduce or as reduce-scatter + all-gather (bucket sizes here are
+    not multiples of the world size: the padded staging path) -- every combination is the single-process step, with
+    the same number of exchanges."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), False, str(tmp_path), 2, False, grad_comm, grad_reduce), nprocs=world,
+             join=True)
+    _check_against_single_process(tmp_path, world, False, 2)
+
+
+def test_reducer_rejects_unknown_modes_and_defaults_to_the_safe_ones(tmp_path):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        _setup_paths()
+        from deepspeaker_pytorch_amd.distributed import Reducer
+        r = Reducer(force=True)
+        assert r.grad_comm == "shared" and r.grad_reduce == "allreduce" and not r.overlap_gradients
+        assert r.grad_group is r.group                      # no second communicator unless asked for
+        with pytest.raises(ValueError):
+            Reducer(grad_comm="both")
+        with pytest.raises(ValueError):
+            Reducer(grad_reduce="ring")
+        g = dist.new_group(ranks=[0])
+        r2 = Reducer(force=True, grad_group=g)              # a pre-built communicator is taken as is
+        assert r2.grad_group is g and r2.overlap_gradients
+    finally:
+        dist.destroy_process_group()
 
 
 def test_gradient_bucketing_names():

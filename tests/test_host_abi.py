@@ -113,3 +113,46 @@ def test_refine_policy_sizes_slots_from_history():
     for _ in range(RefinePolicy.HISTORY):                                       # the large counts age out
         pol.observe(1)
     assert pol.cap_for(256) == REFINE_CAP_MIN
+
+
+def test_batch_counters_survive_reassignment_of_any_module():
+    """`_bump_batches_tracked` keeps the twelve BatchNorm counters as views of one tensor; a counter that was re-assigned
+    (load_state_dict(assign=True), manual replacement) must be noticed whichever module it belongs to."""
+    import torch
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel
+    m = DeepSpeakerModel(512, 4)
+    m._bump_batches_tracked(1)
+    mods = m._bn_modules()
+    assert all(int(b.num_batches_tracked) == 1 for b in mods)
+    mods[5]._buffers["num_batches_tracked"] = torch.tensor(7, dtype=torch.int64)      # a MIDDLE module
+    m._bump_batches_tracked(3)
+    assert [int(b.num_batches_tracked) for b in mods] == [4] * 5 + [10] + [4] * 6
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)
+    m._bump_batches_tracked(1)
+    assert [int(b.num_batches_tracked) for b in m._bn_modules()] == [5] * 5 + [11] + [5] * 6
+
+
+def test_weight_init_statistics_match_the_reference_rule():
+    """a14 (reference model.py:114-120): conv weights ~ N(0, sqrt(2 / (k*k*out_channels))), BatchNorm weight 1 / bias 0.
+    The sample standard deviation of each filter bank must sit within 5 standard errors of the rule's."""
+    import math
+    import torch
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel
+    torch.manual_seed(123)
+    m = DeepSpeakerModel(512, 10)
+    checked = 0
+    for name, p in m.named_parameters():
+        if p.dim() == 4:
+            co, _, kh, kw = p.shape
+            std = math.sqrt(2.0 / (kh * kw * co))
+            n = p.numel()
+            got = float(p.detach().double().std())
+            assert abs(got - std) < 5 * std / math.sqrt(2 * n), (name, got, std)
+            assert abs(float(p.detach().double().mean())) < 5 * std / math.sqrt(n), name
+            checked += 1
+        elif ".bn" in name and name.endswith("weight"):
+            assert bool((p == 1).all()), name
+        elif ".bn" in name and name.endswith("bias"):
+            assert bool((p == 0).all()), name
+    assert checked == 12
