@@ -186,6 +186,12 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (train-mode forward of the 768 utterances, triplet loss, "
                          "backward, gradient all-reduce, fused Adagrad): the step with collectives on its critical path")
+    ap.add_argument("--grad-comm", default=None, choices=["shared", "separate"],
+                    help="--train: gradient buckets on the BatchNorm collectives' communicator, exchanged after the backward "
+                         "pass (default; one program-ordered collective sequence per rank), or on a communicator of their "
+                         "own, exchanged from inside the pass (overlapped; see distributed.Reducer)")
+    ap.add_argument("--grad-reduce", default=None, choices=["allreduce", "rs_ag"],
+                    help="--train: a bucket's exchange as one all-reduce or as reduce-scatter + all-gather")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only rendezvous, one all-reduce and the one-line print (checks the launcher, not the kernels)")
     args = ap.parse_args()
@@ -383,10 +389,23 @@ def main():
             last = sels[-steps:]
             ties = [s_.n_near_ties for s_ in last]
             pol = model._refine_policy
-            refine = {"band": REFINE_BAND, "slots": [s_.amb_cap for s_ in last][-1], "near_ties_mean": round(sum(ties) / len(ties), 2),
+            errs = [s_.observed_error[0] for s_ in last if s_.observed_error[0] is not None]
+            fallbacks = sum(int(s_.refine_overflow or s_.band_exceeded) for s_ in last)
+            refine = {"band": last[-1].band, "band_floor": REFINE_BAND, "band_observed_max": pol.err_max_window,
+                      "band_observed_max_timed_steps": max(errs, default=None), "band_samples_total": pol.err_samples,
+                      "band_violations_total": pol.band_violations,
+                      "slots": [s_.amb_cap for s_ in last][-1], "near_ties_mean": round(sum(ties) / len(ties), 2),
                       "near_ties_max": max(ties), "overflow_steps": sum(int(s_.refine_overflow) for s_ in last),
+                      "band_violation_steps": sum(int(s_.band_exceeded) for s_ in last),
                       "steps": len(last), "calls_total": pol.calls, "overflows_total": pol.overflows}
+            if fallbacks:
+                # a step whose near ties outnumbered its slots, or whose probes showed an error above half its band,
+                # re-embeds the whole batch when its selection is READ (after the timed region): say so in the line
+                refine["flag"] = (f"{fallbacks} of the {len(last)} timed steps fell back to a whole-batch f32-class "
+                                  "re-embedding at read time; that work is NOT inside `value`")
         return elapsed, prof, again, refine, isolated
+
+    red_modes = [None, None]
 
     def measure_train(precision, steps, warmup, repeats=0):
         """The training step of the triplet regime (train_triplet.py:215-224): train-mode forwards of a / p / n
@@ -394,7 +413,8 @@ def main():
         fused Adagrad (lr 0.1, lr_decay 1e-4: train_triplet.py:369-383)."""
         from deepspeaker_pytorch_amd.optim import create_optimizer
         model = load_model(precision).train()
-        red = model.enable_data_parallel(force=args.force_collectives) if multi else None
+        red = model.enable_data_parallel(force=args.force_collectives, grad_comm=args.grad_comm,
+                                         grad_reduce=args.grad_reduce) if multi else None
         opt = create_optimizer(model, 0.1, "adagrad", lr_decay=1e-4)
 
         def step(slot=0):
@@ -415,6 +435,7 @@ def main():
         elapsed, prof, again = timed(step, steps, warmup, repeats)
         per_step = None
         if red is not None:
+            red_modes[:] = [red.grad_comm, red.grad_reduce]
             n0 = red.n_all_reduce
             step()
             per_step = red.n_all_reduce - n0
@@ -489,6 +510,7 @@ def main():
             if ar_per_step is not None:
                 # 12 BatchNorm layers x {forward, backward} + 5 gradient buckets + the logged loss
                 line["all_reduce_per_step"] = ar_per_step
+                line["config"]["grad_comm"], line["config"]["grad_reduce"] = red_modes
             if again:
                 line["repeats_ms_per_step"] = {"median": round(float(np.median(again)), 3), "min": round(min(again), 3),
                                                "max": round(max(again), 3), "n": len(again)}

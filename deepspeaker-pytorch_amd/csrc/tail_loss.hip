@@ -142,11 +142,15 @@ __global__ void __launch_bounds__(256) triplet_filter_kernel(const float *d_p, c
 // ---- the whole scalar side of the triplet step in ONE single-workgroup pass over d_p / d_n ------------------
 // (model.py:27-33 and train_triplet.py:253-262): loss = mean hinge, the ordered filter {i : d_n - d_p < margin},
 // mean(d_n - d_p), and -- new -- the ordered list of NEAR TIES |d_n - d_p - margin| < band (at most amb_cap
-// entries; unused slots hold index 0 so that they stay valid gather indices; amb_count is the true count).
+// entries; amb_count is the true count).  Slots the near ties leave unused hold index 0 (a valid gather index), or,
+// with probe_base >= 0, PROBE triplets (probe_base + k) mod N, k = 0, 1, ...: the refinement re-embeds every slot
+// whether it is used or not, so the unused ones sample the error of the fp16 decision variable for free
+// (refine_distances_kernel reports it; mining.RefinePolicy sizes the band from it).
 // Fixed summation order, ordered block scans: deterministic.
 __global__ void __launch_bounds__(256) triplet_scan_kernel(const float *d_p, const float *d_n, float margin, float band,
                                                            float *loss, long long *idx, int *count, float *mean_diff,
-                                                           long long *amb_idx, int *amb_count, int amb_cap, int N) {
+                                                           long long *amb_idx, int *amb_count, int amb_cap, int N,
+                                                           int probe_base) {
     float *scratch = ds_dynamic_lds();
     int *iscratch = (int *)(scratch + 8);       // [2][4] wave totals
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,24 +200,44 @@ __global__ void __launch_bounds__(256) triplet_scan_kernel(const float *d_p, con
         loss[0] = htot / (float)N;
         if (amb_count) amb_count[0] = abase;
     }
+    if (amb_idx && probe_base >= 0)             // (abase is uniform; every near-tie slot was written above)
+        for (int s = abase + (int)threadIdx.x; s < amb_cap; s += 256) amb_idx[s] = (probe_base + (s - abase)) % N;
 }
 
 // Near-tie refinement: slot s < min(amb_count, cap) holds triplet i = amb_idx[s], whose three utterances were
 // re-embedded at f32-class precision into e_ref rows (s, cap + s, 2 cap + s); its distances are replaced.
+// PROBES: with err != nullptr (ONE workgroup then) EVERY slot is live (the scan filled the unused ones with probe
+// triplets) and err[0] = the largest |(d_n - d_p)_f32-class - (d_n - d_p)_before| over all slots -- the error the fp16
+// forward made on the filter's decision variable, sampled on near ties and probes alike; err[1] = the slot count.
 __global__ void __launch_bounds__(256) refine_distances_kernel(const float *e_ref, const long long *amb_idx,
                                                                const int *amb_count, int cap, float *d_p, float *d_n,
-                                                               int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int live_n = amb_count[0] < cap ? amb_count[0] : cap;
-    const int r = s < cap ? s : 0;
-    const float *a = e_ref + (size_t)r * D, *p = e_ref + (size_t)(cap + r) * D, *n = e_ref + (size_t)(2 * cap + r) * D;
-    const float sp = row_sqdist(a, p, D, lane);
-    const float sn = row_sqdist(a, n, D, lane);
-    if (s < live_n && lane == 0) {
-        const long long i = amb_idx[s];
-        d_p[i] = sqrtf(sp + eps);
-        d_n[i] = sqrtf(sn + eps);
+                                                               int D, float eps, float *err, const float *d_p0,
+                                                               const float *d_n0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int live_n = err ? cap : (amb_count[0] < cap ? amb_count[0] : cap);
+    float worst = 0.f;
+    for (int s = blockIdx.x * 4 + wave; s < cap; s += gridDim.x * 4) {
+        const float *a = e_ref + (size_t)s * D, *p = e_ref + (size_t)(cap + s) * D, *n = e_ref + (size_t)(2 * cap + s) * D;
+        const float sp = row_sqdist(a, p, D, lane);
+        const float sn = row_sqdist(a, n, D, lane);
+        if (s < live_n && lane == 0) {
+            const long long i = amb_idx[s];
+            const float dp = sqrtf(sp + eps), dn = sqrtf(sn + eps);
+            // "before" is read from the untouched originals: a probe may name the same triplet as a near tie (or the
+            // list may repeat an index), and another wave may already have patched d_p[i] / d_n[i]
+            if (err) worst = fmaxf(worst, fabsf((dn - dp) - (d_n0[i] - d_p0[i])));
+            d_p[i] = dp;
+            d_n[i] = dn;
+        }
+    }
+    if (err) {                                  // gridDim.x == 1
+        float *scratch = ds_dynamic_lds();
+        if (lane == 0) scratch[wave] = worst;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            err[0] = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+            err[1] = (float)cap;
+        }
     }
 }
 
@@ -596,9 +620,10 @@ extern "C" int ds_triplet_filter_f32(const float *d_p, const float *d_n, float m
 // The triplet step's loss side in two launches: distances (one wave per row), then ONE scan over the 2N scalars
 // for the loss, the filter, the mean difference and the near-tie list.  Shared by TripletMarginLoss.forward and
 // select_triplets, so the distances are computed once per step.
-extern "C" int ds_triplet_tail_f32(const float *a, const float *p, const float *n, float margin, float band,
-                                   float *d_p, float *d_n, float *loss, long long *idx, int *count, float *mean_diff,
-                                   long long *amb_idx, int *amb_count, int amb_cap, int N, int D, void *stream) {
+extern "C" int ds_triplet_tail_probe_f32(const float *a, const float *p, const float *n, float margin, float band,
+                                         float *d_p, float *d_n, float *loss, long long *idx, int *count, float *mean_diff,
+                                         long long *amb_idx, int *amb_count, int amb_cap, int probe_base, int N, int D,
+                                         void *stream) {
     DS_REQUIRE(a && p && n && d_p && d_n && loss && idx && count && mean_diff, DS_ERR_NULL);
     DS_REQUIRE(N > 0 && D > 0 && amb_cap >= 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(amb_cap == 0 || (amb_idx && amb_count), DS_ERR_NULL);
@@ -608,8 +633,15 @@ extern "C" int ds_triplet_tail_f32(const float *a, const float *p, const float *
     if (rc) return rc;
     DS_LAUNCH(triplet_scan_kernel, 1, 256, 64, stream, (const float *)d_p, (const float *)d_n, margin,
               amb_cap > 0 ? band : -1.0f, loss, idx, count, mean_diff, amb_cap > 0 ? amb_idx : (long long *)nullptr,
-              amb_cap > 0 ? amb_count : (int *)nullptr, amb_cap, N);
+              amb_cap > 0 ? amb_count : (int *)nullptr, amb_cap, N, amb_cap > 0 ? probe_base : -1);
     return ds_last_launch_error();
+}
+
+extern "C" int ds_triplet_tail_f32(const float *a, const float *p, const float *n, float margin, float band,
+                                   float *d_p, float *d_n, float *loss, long long *idx, int *count, float *mean_diff,
+                                   long long *amb_idx, int *amb_count, int amb_cap, int N, int D, void *stream) {
+    return ds_triplet_tail_probe_f32(a, p, n, margin, band, d_p, d_n, loss, idx, count, mean_diff, amb_idx, amb_count,
+                                     amb_cap, -1, N, D, stream);
 }
 
 // the scan alone, over distances that already exist (after ds_refine_distances_f32 patched the near ties)
@@ -618,18 +650,35 @@ extern "C" int ds_triplet_scan_f32(const float *d_p, const float *d_n, float mar
     DS_REQUIRE(d_p && d_n && loss && idx && count && mean_diff, DS_ERR_NULL);
     DS_REQUIRE(N > 0, DS_ERR_BAD_SHAPE);
     DS_LAUNCH(triplet_scan_kernel, 1, 256, 64, stream, d_p, d_n, margin, -1.0f, loss, idx, count, mean_diff,
-              (long long *)nullptr, (int *)nullptr, 0, N);
+              (long long *)nullptr, (int *)nullptr, 0, N, -1);
+    return ds_last_launch_error();
+}
+
+static int refine_distances(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
+                            float *d_n, int D, float *err, const float *d_p0, const float *d_n0, void *stream) {
+    DS_REQUIRE(e_ref && amb_idx && amb_count && d_p && d_n, DS_ERR_NULL);
+    DS_REQUIRE(cap > 0 && D > 0, DS_ERR_BAD_SHAPE);
+    const float eps = (float)(1e-4 / (double)D);
+    const int blocks = err ? 1 : ds_ceil_div(cap, 4);       // the error read-out folds inside one workgroup: no atomics
+    DS_LAUNCH(refine_distances_kernel, blocks, 256, 64, stream, e_ref, amb_idx, amb_count, cap, d_p, d_n, D, eps, err, d_p0,
+              d_n0);
     return ds_last_launch_error();
 }
 
 extern "C" int ds_refine_distances_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap,
                                        float *d_p, float *d_n, int D, void *stream) {
-    DS_REQUIRE(e_ref && amb_idx && amb_count && d_p && d_n, DS_ERR_NULL);
-    DS_REQUIRE(cap > 0 && D > 0, DS_ERR_BAD_SHAPE);
-    const float eps = (float)(1e-4 / (double)D);
-    DS_LAUNCH(refine_distances_kernel, ds_ceil_div(cap, 4), 256, 0, stream, e_ref, amb_idx, amb_count, cap, d_p, d_n, D,
-              eps);
-    return ds_last_launch_error();
+    return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, nullptr, nullptr, nullptr, stream);
+}
+
+// ... over ALL cap slots (near ties and the probe triplets ds_triplet_tail_probe_f32 put into the unused ones), also
+// reporting err[0] = max |change of d_n - d_p| and err[1] = the number of slots sampled (both float).  d_p / d_n are
+// patched; d_p_before / d_n_before are the unpatched distances the slots were chosen on (other buffers than d_p / d_n).
+extern "C" int ds_refine_distances_probe_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap,
+                                             float *d_p, float *d_n, const float *d_p_before, const float *d_n_before,
+                                             int D, float *err, void *stream) {
+    DS_REQUIRE(err && d_p_before && d_n_before, DS_ERR_NULL);
+    DS_REQUIRE(d_p_before != d_p && d_n_before != d_n, DS_ERR_UNSUPPORTED);
+    return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, err, d_p_before, d_n_before, stream);
 }
 
 // ---- softmax cross-entropy over the classifier logits (reference train_triplet.py:281-287:

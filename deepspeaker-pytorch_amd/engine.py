@@ -987,10 +987,11 @@ class Engine:
         self.lib.call("ds_pairwise_distance_f32", self._p(x1), self._p(x2), self._p(out), n, d, self._stream(x1))
         return out
 
-    def triplet_tail(self, a, p, n, margin: float, band: float = 0.0, amb_cap: int = 0) -> dict:
+    def triplet_tail(self, a, p, n, margin: float, band: float = 0.0, amb_cap: int = 0, probe_base: int = -1) -> dict:
         """The loss side of one triplet step (model.py:27-33, train_triplet.py:251-262) in two launches:
         distances, then one scan giving the loss, the ordered filter, mean(d_n - d_p) and (amb_cap > 0) the
-        near-tie list.  Nothing is cached between calls: buffers that are rewritten through raw pointers (a HIP
+        near-tie list (probe_base >= 0: the slots near ties leave unused hold the probe triplets probe_base, probe_base + 1,
+        ... mod N, see mining.RefinePolicy).  Nothing is cached between calls: buffers that are rewritten through raw pointers (a HIP
         graph's static output, a collective's destination) keep their address AND their torch version counter, so a
         result keyed on those would be served for new contents."""
         for t, nm in ((a, "anchor"), (p, "positive"), (n, "negative")):
@@ -1006,10 +1007,11 @@ class Engine:
                "mean_diff": torch.empty(1, dtype=torch.float32, device=dev),
                "amb_idx": torch.empty(amb_cap, dtype=torch.int64, device=dev) if amb_cap > 0 else None,
                "amb_count": torch.empty(1, dtype=torch.int32, device=dev) if amb_cap > 0 else None}
-        self.lib.call("ds_triplet_tail_f32", self._p(a), self._p(p), self._p(n), float(margin), float(band),
+        self.lib.call("ds_triplet_tail_probe_f32", self._p(a), self._p(p), self._p(n), float(margin), float(band),
                       self._p(out["d_p"]), self._p(out["d_n"]), self._p(out["loss"]), self._p(out["idx"]),
                       self._p(out["count"]), self._p(out["mean_diff"]), self._p(out["amb_idx"]),
-                      self._p(out["amb_count"]), int(amb_cap), rows, d, self._stream(a))
+                      self._p(out["amb_count"]), int(amb_cap), int(probe_base) if amb_cap > 0 else -1, rows, d,
+                      self._stream(a))
         return out
 
     def triplet_margin(self, a, p, n, margin: float):

@@ -12,13 +12,26 @@ import torch
 from .model import _require_cuda, get_engine
 
 
-# Near-tie refinement of the fp16 forward (precision "f16").  The fp16 path's embeddings are 3.7e-4 from the
-# reference, which moves d_n - d_p by up to ~6e-4 (measured at the 768-utterance bench configuration; rms 2e-4):
-# a triplet whose |d_n - d_p - margin| is below that can land on the other side of the filter.  Every triplet
-# inside REFINE_BAND is therefore re-embedded through the split-operand bf16 path (f32-class, 5e-6) and decided
-# on those distances; outside the band the fp16 decision is already the reference's.
+# Near-tie refinement of the fp16 forward (precision "f16").  The fp16 path's embeddings are a few 1e-4 from the
+# reference, which moves the filter's decision variable d_n - d_p by ~6e-4 at the random-init bench configuration
+# (rms 2e-4) -- and by more once the weights spread the embeddings apart: the error of a distance scales with the
+# distance.  A triplet whose |d_n - d_p - margin| is below that error can land on the other side of the filter.  Every
+# triplet inside a BAND around the boundary is therefore re-embedded through the split-operand bf16 path (f32-class,
+# 5e-6) and decided on those distances; outside the band the fp16 decision is already the reference's -- provided the
+# band really covers the error.  Round 4: the band is no longer a constant calibrated on one input distribution, it is
+# MEASURED, continuously and for free:
 #
-# How many triplets that is depends on the weights: ~1 per 256 at random init, but a triplet-trained network
+#   * the refinement forward re-embeds all its slots whether near ties fill them or not, so the scan puts PROBE
+#     triplets (a window that rotates through the batch from call to call) into the slots near ties leave unused;
+#   * the kernel that patches the distances reports max |(d_n - d_p)_f32-class - (d_n - d_p)_fp16| over all slots --
+#     the fp16 error on near ties and probes alike -- and the value travels back through pinned memory with the
+#     near-tie count (no synchronisation in the step);
+#   * `RefinePolicy.band_for()` = max(REFINE_BAND, BAND_SAFETY x the largest error seen in the last BAND_WINDOW calls);
+#   * a call whose own samples show an error above HALF the band it used is a band violation: its `TripletSelection`
+#     re-embeds the WHOLE batch at f32-class precision before it hands out anything, exactly like a slot overflow
+#     (`band_exceeded`, `refined_all`), and the next calls use the wider band.
+#
+# How many near ties there are depends on the weights: ~1 per 256 at random init, but a triplet-trained network
 # concentrates d_n - d_p AT the margin.  And a slot is not free: a re-embedded triplet is 3 utterances x 3 MFMAs per
 # product = 9 fp16 utterance-forwards of matrix work (measured on the 768-utterance step: 4 slots +0 %, 8 +4 %,
 # 16 +10 %, 32 +24 %).  The number of re-embedding slots is therefore neither a constant nor generous by default:
@@ -29,7 +42,11 @@ from .model import _require_cuda, get_engine
 #   * if a call still finds more near ties than it had slots for, its `TripletSelection` re-embeds the WHOLE batch at
 #     f32-class precision before it hands out anything (`refined_all`), and the policy has learned the new level.
 # So what an accessor returns is always decided on f32-class distances inside the band, whatever the weights are.
-REFINE_BAND = 1.25e-3       # 2x the largest observed |error| of d_n - d_p (6 sigma)
+REFINE_BAND = 1.25e-3       # the band's floor and starting value (2x the largest |error| of d_n - d_p at random init)
+BAND_SAFETY = 2.5           # band >= this x the largest error observed in the window
+BAND_VIOLATION = 0.5        # a call observing an error above this x its band falls back to the whole batch
+BAND_WINDOW = 512           # calls the observed-error maximum is taken over
+PROBE_STRIDE = 37           # the probe window moves by this many triplets per call
 REFINE_CAP_START = 32       # slots while the policy has no history (96 re-embedded rows)
 REFINE_CAP_MIN = 4          # smallest slot count once it has
 REFINE_CAP = REFINE_CAP_START
@@ -40,53 +57,79 @@ def _pow2ceil(v: int) -> int:
 
 
 class RefinePolicy:
-    """Host-side sizing of the near-tie refinement (one per model): slot count for the next call from the near-tie
-    counts observed so far.  Pure bookkeeping -- no device work, no synchronisation."""
+    """Host-side sizing of the near-tie refinement (one per model): slot count and band for the next call from the
+    near-tie counts and fp16 errors observed so far.  Pure bookkeeping -- no device work, no synchronisation."""
 
     HISTORY = 8
     RING = 256                          # pinned read-back slots (one per call in flight)
 
     WARM = 4                            # observed calls before the slot count may drop below cap_start
 
-    def __init__(self, cap_min: int = REFINE_CAP_MIN, cap_start: int = REFINE_CAP_START):
+    def __init__(self, cap_min: int = REFINE_CAP_MIN, cap_start: int = REFINE_CAP_START,
+                 band_floor: float = REFINE_BAND, band_safety: float = BAND_SAFETY):
         self.cap_min, self.cap_start = cap_min, max(cap_min, cap_start)
+        self.band_floor, self.band_safety = float(band_floor), float(band_safety)
         self.n_seen = 0
         self.seen = []                  # near-tie counts of the last HISTORY observed calls
+        self.errs = []                  # per-call max fp16 error of d_n - d_p, last BAND_WINDOW calls that sampled any
+        self.err_samples = 0            # slots sampled so far (near ties + probes)
+        self.err_max_ever = 0.0
+        self.band_violations = 0
         self.pending = []               # read-back records of calls whose count has not been taken in yet
         self.calls = self.overflows = 0
         self.max_seen = 0
-        self._ring = None
+        self._ring = self._ring_err = None
         self._next = 0
 
-    def observe(self, count: int):
+    def observe(self, count: int, err: float = None, n_samples: int = 0):
         self.seen = (self.seen + [int(count)])[-self.HISTORY:]
         self.max_seen = max(self.max_seen, int(count))
         self.n_seen += 1
+        if err is not None and n_samples > 0:
+            self.errs = (self.errs + [float(err)])[-BAND_WINDOW:]
+            self.err_samples += int(n_samples)
+            self.err_max_ever = max(self.err_max_ever, float(err))
 
-    def readback(self, amb_count: torch.Tensor) -> dict:
-        """Enqueue (on the current stream) the copy of a call's near-tie count into a pinned slot; the returned
-        record carries the event after which `value()` is valid."""
+    @property
+    def err_max_window(self) -> float:
+        return max(self.errs, default=0.0)
+
+    def band_for(self) -> float:
+        """The band of the next call: never below the floor, and BAND_SAFETY x the largest fp16 error of d_n - d_p
+        that any slot (near tie or probe) of the last BAND_WINDOW calls has shown."""
+        return max(self.band_floor, self.band_safety * self.err_max_window)
+
+    def readback(self, amb_count: torch.Tensor, err: torch.Tensor = None) -> dict:
+        """Enqueue (on the current stream) the copy of a call's near-tie count (and its observed error pair) into a
+        pinned slot; the returned record carries the event after which `value()` is valid."""
         if self._ring is None:
             self._ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+            self._ring_err = torch.zeros((self.RING, 2), dtype=torch.float32).pin_memory()
         slot = self._next % self.RING
         self._next += 1
         self._ring[slot:slot + 1].copy_(amb_count, non_blocking=True)
+        if err is not None:
+            self._ring_err[slot].copy_(err, non_blocking=True)
         rec = {"slot": slot, "serial": self._next, "event": torch.cuda.current_stream(amb_count.device).record_event(),
-               "device": amb_count, "taken": False}
+               "device": amb_count, "device_err": err, "taken": False}
         self.pending.append(rec)
         return rec
 
-    def value(self, rec: dict) -> int:
-        """The count of a finished call (its event must have completed)."""
+    def value(self, rec: dict):
+        """(near-tie count, observed error or None, slots sampled) of a finished call (its event must have completed)."""
         if self._next - rec["serial"] >= self.RING:     # the slot has been handed to a later call since
-            return int(rec["device"].item())
-        return int(self._ring[rec["slot"]])
+            cnt = int(rec["device"].item())
+            e = rec["device_err"].tolist() if rec["device_err"] is not None else None
+        else:
+            cnt = int(self._ring[rec["slot"]])
+            e = self._ring_err[rec["slot"]].tolist() if rec["device_err"] is not None else None
+        return (cnt, None, 0) if e is None else (cnt, float(e[0]), int(e[1]))
 
-    def take(self, rec: dict) -> int:
+    def take(self, rec: dict):
         v = self.value(rec)
         if not rec["taken"]:
             rec["taken"] = True
-            self.observe(v)
+            self.observe(*v)
         return v
 
     def poll(self):
@@ -115,12 +158,13 @@ class TripletSelection:
     `.n_correct` is what synchronises (the reference branches on the count, train_triplet.py:263).
 
     When the fp16 forward's near ties were refined, the refinement ran on a side stream: every accessor first makes
-    the CURRENT stream wait for it.  Accessors of a refined selection also check (one pinned int, after the side
-    stream's event) that the refinement had a slot for every near tie; if not, the whole batch is re-embedded at
-    f32-class precision first (`refined_all`), so what they return never rests on an undecided fp16 comparison."""
+    the CURRENT stream wait for it.  Accessors of a refined selection also check (pinned values, after the side
+    stream's event) that the refinement had a slot for every near tie AND that the fp16 error its slots observed stays
+    below half the band it used; if not, the whole batch is re-embedded at f32-class precision first (`refined_all`),
+    so what they return never rests on an undecided fp16 comparison."""
 
     def __init__(self, idx_full, count, d_p, d_n, mean_diff, loss=None, amb_count=None, amb_cap=0, ready=None,
-                 readback=None, fallback=None, policy=None):
+                 readback=None, fallback=None, policy=None, band=0.0):
         self._idx_full = idx_full    # int64 [N]; the first `count` entries are valid, ascending
         self._count = count          # int32 [1] on the device
         self._d_p = d_p              # [N]  (train_triplet.py:251)
@@ -129,23 +173,38 @@ class TripletSelection:
         self._loss = loss            # triplet loss on the same distances (train_triplet.py:275), 1-element tensor
         self._amb_count = amb_count  # near ties found (int32 [1]) when the fp16 forward was refined, else None
         self.amb_cap = amb_cap
+        self.band = band             # the band this call used
         self._ready = ready          # event on the refinement stream, or None
         self._readback = readback    # RefinePolicy.readback record of amb_count (pinned slot + its event)
         self._n_amb = None
+        self._err = None             # (max observed fp16 error of d_n - d_p over this call's slots, slots sampled)
         self._fallback = fallback    # () -> dict of replacement tensors: the whole batch at f32-class precision
         self._policy = policy
         self._resolved = fallback is None or readback is None
-        self.refined_all = False     # True once the overflow action has replaced the results
+        self.refined_all = False     # True once the overflow / band-violation action has replaced the results
+        self.band_exceeded = False   # True if this call's own samples showed an error above BAND_VIOLATION x its band
+
+    def _take(self):
+        if self._n_amb is None:
+            self._readback["event"].synchronize()
+            self._n_amb, err, n_s = self._policy.take(self._readback)
+            self._err = (err, n_s)
+        return self._n_amb
 
     def resolve(self):
-        """Make sure every near tie was decided at f32-class precision (see the class docstring).  Waits on the host
-        for the refinement's event -- the same wait any host-side read of the selection implies."""
+        """Make sure every near tie was decided at f32-class precision and that the band was wide enough (see the
+        class docstring).  Waits on the host for the refinement's event -- the same wait any host-side read of the
+        selection implies."""
         if not self._resolved:
             self._resolved = True
-            self._readback["event"].synchronize()
-            n_amb = self._n_amb = self._policy.take(self._readback)
-            if n_amb > self.amb_cap:
-                self._policy.overflows += 1
+            n_amb = self._take()
+            err = self._err[0]
+            self.band_exceeded = err is not None and err > BAND_VIOLATION * self.band
+            if n_amb > self.amb_cap or self.band_exceeded:
+                if n_amb > self.amb_cap:
+                    self._policy.overflows += 1
+                if self.band_exceeded:
+                    self._policy.band_violations += 1
                 t = self._fallback()
                 self._idx_full, self._count, self._d_p, self._d_n = t["idx"], t["count"], t["d_p"], t["d_n"]
                 self._mean_diff, self._loss = t["mean_diff"], t["loss"]
@@ -192,10 +251,15 @@ class TripletSelection:
         """near ties the fp16 forward left undecided (0 when nothing was refined); synchronises"""
         if self._amb_count is None:
             return 0
-        if self._n_amb is None:
-            self._readback["event"].synchronize()
-            self._n_amb = self._policy.take(self._readback)
-        return self._n_amb
+        return self._take()
+
+    @property
+    def observed_error(self):
+        """(largest |fp16 error of d_n - d_p| over this call's slots, slots sampled) or (None, 0); synchronises"""
+        if self._amb_count is None or self._readback is None:
+            return (None, 0)
+        self._take()
+        return self._err
 
     @property
     def refine_overflow(self) -> bool:
@@ -229,7 +293,7 @@ def refine_policy(model) -> RefinePolicy:
 
 
 def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tensor, margin: float,
-                    model=None, inputs=None, band: float = REFINE_BAND, cap: int = None,
+                    model=None, inputs=None, band: float = None, cap: int = None,
                     side_stream: bool = True) -> TripletSelection:
     """train_triplet.py:251-262.  With `model` (a DeepSpeakerModel in eval mode, precision "f16") and `inputs`
     (the three input batches the embeddings came from), near ties are re-embedded at f32-class precision first,
@@ -237,7 +301,9 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     host.  The re-embedding is a small-batch forward (latency-bound: a few workgroups walking the whole
     contraction), so by default it runs on a side stream next to whatever the caller enqueues next;
     `TripletSelection` orders its consumers after it.  `cap`: re-embedding slots; default: sized by the model's
-    `RefinePolicy` from the near-tie counts of earlier calls."""
+    `RefinePolicy` from the near-tie counts of earlier calls.  `band`: half-width of the near-tie band; default: the
+    policy's, i.e. measured (the slots near ties leave unused carry probe triplets whose fp16 error is read back; a
+    call that observes an error above half its band re-embeds the whole batch when the selection is read)."""
     _require_cuda(out_a, "select_triplets")
     eng = get_engine()
     a, p, n = (t.detach().contiguous() for t in (out_a, out_p, out_n))
@@ -258,8 +324,10 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     policy.poll()
     policy.calls += 1
     cap = policy.cap_for(n_trip) if cap is None else max(1, min(int(cap), n_trip))
+    band = policy.band_for() if band is None else float(band)
     whole = cap >= n_trip
-    t = eng.triplet_tail(a, p, n, margin, band=band, amb_cap=cap)
+    t = eng.triplet_tail(a, p, n, margin, band=band, amb_cap=cap,
+                         probe_base=-1 if whole else (policy.calls * PROBE_STRIDE) % n_trip)
     main = torch.cuda.current_stream(a.device)
     side = _side_stream(a.device) if side_stream else main
     # the f32-class path's packed filters / folded BatchNorm are built HERE, on the caller's stream, if they do not
@@ -282,8 +350,8 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
             for v in list(t.values()) + xs:         # main-stream memory the side stream reads
                 if isinstance(v, torch.Tensor):
                     v.record_stream(side)
-        rb = policy.readback(t["amb_count"])
         if whole:
+            rb = policy.readback(t["amb_count"])
             r = embed_all()
             idx, count, d_p, d_n, mean_diff, loss = r["idx"], r["count"], r["d_p"], r["d_n"], r["mean_diff"], r["loss"]
         else:
@@ -295,15 +363,17 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
                              rows, st)
             e_ref = eng.forward_eval_planned(xr, pw_ref, folded_ref, precision="bf16x3")
             d_p, d_n = t["d_p"].clone(), t["d_n"].clone()
-            eng.lib.call("ds_refine_distances_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
-                         eng._p(d_p), eng._p(d_n), a.shape[1], st)
+            err = torch.empty(2, dtype=torch.float32, device=a.device)
+            eng.lib.call("ds_refine_distances_probe_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
+                         eng._p(d_p), eng._p(d_n), eng._p(t["d_p"]), eng._p(t["d_n"]), a.shape[1], eng._p(err), st)
+            rb = policy.readback(t["amb_count"], err)
             idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
             mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])
             eng.lib.call("ds_triplet_scan_f32", eng._p(d_p), eng._p(d_n), float(margin), eng._p(loss), eng._p(idx),
                          eng._p(count), eng._p(mean_diff), d_p.numel(), st)
         ready = side.record_event()
     return TripletSelection(idx, count, d_p, d_n, mean_diff, loss, t["amb_count"], cap, ready if side_stream else None,
-                            readback=rb, fallback=None if whole else embed_all, policy=policy)
+                            readback=rb, fallback=None if whole else embed_all, policy=policy, band=band)
 
 
 class MinedNegatives:

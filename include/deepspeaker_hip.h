@@ -235,6 +235,20 @@ int ds_triplet_scan_f32(const float *d_p, const float *d_n, float margin, float 
                         float *mean_diff, int N, void *stream);
 int ds_refine_distances_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
                             float *d_n, int D, void *stream);
+/* Round 4: the same two calls with PROBES -- how the band of the near-tie refinement checks itself.  The refinement
+ * re-embeds all `cap` slots whether near ties fill them or not; ds_triplet_tail_probe_f32 puts the triplets
+ * (probe_base + k) mod N, k = 0, 1, ... into the slots the near ties leave unused (probe_base < 0: none, == ds_triplet_tail_f32),
+ * and ds_refine_distances_probe_f32 patches ALL cap slots and reports err[0] = max over the slots of
+ * |(d_n - d_p) at f32-class precision - (d_n - d_p) before| (the fp16 forward's error on the filter's decision variable,
+ * train_triplet.py:251-253) and err[1] = the number of slots sampled (as float); "before" is read from d_p_before /
+ * d_n_before, the unpatched distances the scan chose the slots on (buffers other than d_p / d_n).  One workgroup, no
+ * atomics. */
+int ds_triplet_tail_probe_f32(const float *a, const float *p, const float *n, float margin, float band, float *d_p,
+                              float *d_n, float *loss, long long *idx, int *count, float *mean_diff, long long *amb_idx,
+                              int *amb_count, int amb_cap, int probe_base, int N, int D, void *stream);
+int ds_refine_distances_probe_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
+                                  float *d_n, const float *d_p_before, const float *d_n_before, int D, float *err,
+                                  void *stream);
 
 
 /* ---- backward of the convolution stack (torch autograd of nn.Conv2d / nn.BatchNorm2d under

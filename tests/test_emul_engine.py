@@ -135,6 +135,52 @@ def test_triplet_tail_scan_and_refinement(N, cap):
     assert abs(float(loss2) - float(np.maximum(margin + dp2.numpy() - dn2.numpy(), 0).mean())) < 1e-6
 
 
+@pytest.mark.parametrize("N,cap,base", [(5, 8, 3), (256, 8, 250), (700, 16, 0), (40, 4, 7)])
+def test_triplet_tail_probe_slots_and_error_readout(N, cap, base):
+    """ds_triplet_tail_probe_f32: the slots near ties leave unused hold the probe triplets (base + k) mod N;
+    ds_refine_distances_probe_f32 patches EVERY slot and reports the largest |change of d_n - d_p| over them (read from the
+    unpatched distances, so a probe that repeats a near tie's index cannot see a half-patched pair) and the slot count."""
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(300 + N)
+    D = 64
+    a = rs.randn(N, D).astype(np.float32)
+    p = a + rs.randn(N, D).astype(np.float32) * 0.05
+    n = a + rs.randn(N, D).astype(np.float32) * 0.05
+    margin, band = 0.1, 0.01
+    t = eng.triplet_tail(*(torch.from_numpy(v) for v in (a, p, n)), margin, band=band, amb_cap=cap, probe_base=base)
+    t0 = eng.triplet_tail(*(torch.from_numpy(v) for v in (a, p, n)), margin, band=band, amb_cap=cap)
+    for k_ in ("d_p", "d_n", "loss", "count", "mean_diff", "amb_count"):        # probes change nothing but the unused slots
+        assert torch.equal(t[k_], t0[k_]), k_
+    amb_ref = np.where(np.abs(t["d_n"].numpy() - t["d_p"].numpy() - np.float32(margin)) < np.float32(band))[0]
+    k = min(cap, len(amb_ref))
+    slots = t["amb_idx"].numpy()
+    np.testing.assert_array_equal(slots[:k], amb_ref[:k])
+    np.testing.assert_array_equal(slots[k:], (base + np.arange(cap - k)) % N)
+    e_ref = rs.randn(3 * cap, D).astype(np.float32)
+    dp2, dn2 = t["d_p"].clone(), t["d_n"].clone()
+    err = torch.full((2,), -1.0)
+    eng.lib.call("ds_refine_distances_probe_f32", eng._p(torch.from_numpy(e_ref)), eng._p(t["amb_idx"]),
+                 eng._p(t["amb_count"]), cap, eng._p(dp2), eng._p(dn2), eng._p(t["d_p"]), eng._p(t["d_n"]), D, eng._p(err),
+                 None)
+    exp_p, exp_n = t["d_p"].numpy().copy(), t["d_n"].numpy().copy()
+    worst = 0.0
+    for s_ in range(cap):
+        i = slots[s_]
+        new_p = O.pairwise_distance(e_ref[s_:s_ + 1], e_ref[cap + s_:cap + s_ + 1])[0]
+        new_n = O.pairwise_distance(e_ref[s_:s_ + 1], e_ref[2 * cap + s_:2 * cap + s_ + 1])[0]
+        worst = max(worst, abs(float(np.float32(new_n) - np.float32(new_p)) - float(t["d_n"][i] - t["d_p"][i])))
+        exp_p[i], exp_n[i] = new_p, new_n           # (repeated indices: the last slot's values; all slots agree below)
+    assert int(err[1]) == cap and abs(float(err[0]) - worst) < 1e-5 * max(1.0, worst)
+    untouched = np.setdiff1d(np.arange(N), slots)
+    np.testing.assert_array_equal(dp2.numpy()[untouched], t["d_p"].numpy()[untouched])
+    if len(set(slots.tolist())) == cap:                         # no index twice: every patched value is determined
+        assert rel_err(dp2.numpy(), exp_p) < 1e-6 and rel_err(dn2.numpy(), exp_n) < 1e-6
+    # the same buffers as "before" and patched are refused
+    rc = eng.lib.raw("ds_refine_distances_probe_f32")(eng._p(torch.from_numpy(e_ref)), eng._p(t["amb_idx"]), eng._p(t["amb_count"]),
+                                                      cap, eng._p(dp2), eng._p(dn2), eng._p(dp2), eng._p(dn2), D, eng._p(err), None)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("N", [1, 5, 256, 700])
 def test_filter_sizes(N):
     eng = Engine(emul_lib())

@@ -115,6 +115,23 @@ def test_refine_policy_sizes_slots_from_history():
     assert pol.cap_for(256) == REFINE_CAP_MIN
 
 
+def test_refine_policy_band_follows_the_observed_error():
+    """The band of the near-tie refinement is measured, not a constant: never below the floor, BAND_SAFETY x the largest
+    fp16 error of d_n - d_p any slot showed in the window, and it comes back down when large errors age out."""
+    from deepspeaker_pytorch_amd.mining import BAND_SAFETY, BAND_WINDOW, REFINE_BAND, RefinePolicy
+    pol = RefinePolicy()
+    assert pol.band_for() == REFINE_BAND and pol.err_samples == 0
+    pol.observe(1, 2e-4, 30)
+    assert pol.band_for() == REFINE_BAND                               # 2.5 x 2e-4 is still under the floor
+    pol.observe(0, None, 0)                                            # a whole-batch call sampled nothing
+    assert pol.err_samples == 30 and len(pol.errs) == 1
+    pol.observe(2, 3e-3, 4)                                            # weights that spread the embeddings apart
+    assert abs(pol.band_for() - BAND_SAFETY * 3e-3) < 1e-12 and pol.err_max_ever == 3e-3 and pol.err_samples == 34
+    for _ in range(BAND_WINDOW):
+        pol.observe(1, 1e-4, 4)
+    assert pol.band_for() == REFINE_BAND and pol.err_max_ever == 3e-3  # aged out of the window, remembered in the record
+
+
 def test_batch_counters_survive_reassignment_of_any_module():
     """`_bump_batches_tracked` keeps the twelve BatchNorm counters as views of one tensor; a counter that was re-assigned
     (load_state_dict(assign=True), manual replacement) must be noticed whichever module it belongs to."""
