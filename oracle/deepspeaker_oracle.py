@@ -92,6 +92,50 @@ def make_input(seed: int, batch: int, frames: int = 160, scale: float = 1.0) -> 
     return (rs.randn(batch, 1, frames, 64) * scale).astype(np.float32)
 
 
+def make_speaker_corpus(seed: int, n_speakers: int, utts_per_speaker: int, frames: int = 160,
+                        scale: float = 12.0, mix: Tuple[float, float, float] = (0.7, 0.25, 0.65)) -> np.ndarray:
+    """Speaker-structured synthetic filterbank features [S, U, frames, 64] with the statistics SURVEY 8(d) gives for
+    real inputs: `20*log10` mel energies, per-bin mean-removed, NOT variance-scaled (audio_processing.py:17,29), i.e.
+    std ~ 10-20.  Speaker s has a smooth spectral envelope (what a speaker embedding can learn: the temporal mean of
+    an utterance recovers it), every utterance a smaller smooth offset of its own (session / channel), every frame
+    white noise on top; `mix` = weights of (speaker envelope, utterance offset, frame noise) -- a smaller first weight
+    makes the speakers harder to tell apart.  Frozen legacy RandomState stream."""
+    rs = np.random.RandomState(seed)
+
+    def smooth(v):
+        k = np.array([1, 4, 6, 4, 1], np.float64) / 16.0
+        for _ in range(3):
+            v = np.apply_along_axis(lambda r: np.convolve(np.pad(r, 2, mode="edge"), k, mode="valid"), -1, v)
+        return v / (v.std(axis=-1, keepdims=True) + 1e-12)
+
+    env = smooth(rs.randn(n_speakers, 64))                              # [S, 64]
+    off = smooth(rs.randn(n_speakers, utts_per_speaker, 64))            # [S, U, 64]
+    noise = rs.randn(n_speakers, utts_per_speaker, frames, 64)
+    x = mix[0] * env[:, None, None, :] + mix[1] * off[:, :, None, :] + mix[2] * noise
+    return (x * scale).astype(np.float32)
+
+
+def sample_triplets(seed: int, n_speakers: int, utts_per_speaker: int, n_triplets: int):
+    """(anchor, positive, negative) as (speaker, utterance) index pairs + the speaker ids (c1 of anchor / positive, c2 of
+    the negative): anchor and positive are two different utterances of one speaker, the negative belongs to another
+    speaker -- what DeepSpeakerDataset_dynamic.generate_triplets_call draws (DeepSpeakerDataset_dynamic.py:28-52),
+    without its never-the-last-utterance quirk."""
+    rs = np.random.RandomState(seed)
+    a = np.empty((n_triplets, 2), np.int64)
+    p, n = np.empty_like(a), np.empty_like(a)
+    for t in range(n_triplets):
+        c1 = rs.randint(0, n_speakers)
+        c2 = (c1 + 1 + rs.randint(0, n_speakers - 1)) % n_speakers
+        ua, up = rs.choice(utts_per_speaker, 2, replace=False)
+        a[t], p[t], n[t] = (c1, ua), (c1, up), (c2, rs.randint(0, utts_per_speaker))
+    return a, p, n, a[:, 0].copy(), n[:, 0].copy()
+
+
+def gather_utterances(corpus: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """[S, U, T, 64] corpus, [N, 2] (speaker, utterance) -> the model's input layout [N, 1, T, 64]"""
+    return np.ascontiguousarray(corpus[idx[:, 0], idx[:, 1]][:, None])
+
+
 # ----------------------------------------------------------------------------
 # forward primitives
 # ----------------------------------------------------------------------------

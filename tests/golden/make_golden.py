@@ -331,9 +331,129 @@ def make_cfg1_train():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: off the N(0,1) / random-init distribution, and more than one step deep
+# ---------------------------------------------------------------------------------------------------------------
+OFFDIST_CASES = {          # name: (torch generator seed, rows, frames, input scale)
+    "x15": (4321, 768, 160, 15.0),      # real features are 20*log10 mel energies, std ~ 10-20
+    "T100": (4322, 768, 100, 1.0),      # the two ends of BASELINE configs[4]'s length range at the bench batch
+    "T800": (4323, 384, 800, 1.0),      # (128 triplets: five times the frames per row)
+    "x15_T800": (4324, 96, 800, 15.0),
+}
+
+
+def offdist_inputs(name):
+    """the inputs of one off-distribution case, regenerated from its seed (tests rebuild them the same way)"""
+    seed, rows, frames, scale = OFFDIST_CASES[name]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(rows, 1, frames, 64, generator=g) * scale
+
+
+def make_offdist():
+    """The unmodified reference (eval) on the cfg1 parameters with inputs OFF the N(0,1) / 160-frame distribution the
+    fp16 path's tolerance and near-tie band were first measured on: embeddings, distances, loss and the filter's
+    selection per case (VERDICT r3 'next' #1 (a), (c))."""
+    sd = O.make_state_dict(seed=0, num_classes=1211)
+    m = build_ref(sd, 1211).eval()
+    out = {}
+    for name in OFFDIST_CASES:
+        x = offdist_inputs(name)
+        nt = x.shape[0] // 3
+        with torch.no_grad():
+            e = torch.cat([m(x[i:i + 32]) for i in range(0, x.shape[0], 32)])
+            a, p, n = e[:nt], e[nt:2 * nt], e[2 * nt:]
+            pd = ref.PairwiseDistance(2)
+            d_p, d_n = pd.forward(a, p), pd.forward(a, n)
+            loss = ref.TripletMarginLoss(0.1).forward(a, p, n)
+        allm = (d_n - d_p < 0.1).numpy().flatten()
+        out[f"{name}_emb"], out[f"{name}_d_p"], out[f"{name}_d_n"] = e.numpy(), d_p.numpy(), d_n.numpy()
+        out[f"{name}_loss"] = loss.numpy()
+        out[f"{name}_selected"] = np.where(allm == 1)[0].astype(np.int64)
+        out[f"{name}_input_digest"] = np.array([float(x.double().sum()), float(x.double().abs().sum()), float(x[-1, 0, -1, -1])])
+        gap = np.abs(d_n.numpy() - d_p.numpy() - 0.1)
+        print(f"offdist {name}: rows {x.shape[0]}, selected {allm.sum()} of {nt}, min |gap| {gap.min():.3e}, "
+              f"mean d_p {float(d_p.mean()):.3f} d_n {float(d_n.mean()):.3f}, |e| max {float(e.abs().max()):.3f}")
+    path = os.path.join(HERE, "reference_offdist.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+TRAJ = dict(param_seed=7, corpus_seed=21, speakers=10, utts=24, train_utts=20, frames=160, mix=(0.3, 0.2, 0.9),
+            triplets=16, steps=30, lr=0.003, margin=0.1, triplet_seed0=1000)
+
+
+def trajectory_batches(step):
+    """(data_a, data_p, data_n) of training step `step` and the held-out test utterances: shared by the golden maker and
+    the GPU test (regenerated from seeds on both sides)"""
+    c = O.make_speaker_corpus(TRAJ["corpus_seed"], TRAJ["speakers"], TRAJ["utts"], TRAJ["frames"], mix=TRAJ["mix"])
+    a, p, n, _, _ = O.sample_triplets(TRAJ["triplet_seed0"] + step, TRAJ["speakers"], TRAJ["train_utts"], TRAJ["triplets"])
+    return [O.gather_utterances(c, i) for i in (a, p, n)]
+
+
+def trajectory_test_set():
+    c = O.make_speaker_corpus(TRAJ["corpus_seed"], TRAJ["speakers"], TRAJ["utts"], TRAJ["frames"], mix=TRAJ["mix"])
+    idx = np.array([(s_, u) for s_ in range(TRAJ["speakers"]) for u in range(TRAJ["train_utts"], TRAJ["utts"])], np.int64)
+    x = O.gather_utterances(c, idx)
+    ii, jj = np.triu_indices(len(idx), 1)
+    return x, ii, jj, (idx[ii, 0] == idx[jj, 0])
+
+
+def make_trajectory():
+    """BASELINE configs[3] in miniature (no VoxCeleb here): the triplet-regime loop of train_triplet.py:215-224 through
+    the UNMODIFIED reference for 30 steps -- train-mode forwards of a / p / n, TripletMarginLoss, backward, plain SGD (no
+    momentum: a smooth trajectory, unlike Adagrad's sign-like first steps) -- on 10 synthetic speakers with learnable
+    structure, a fresh batch of 16 triplets per step; then the test-time scoring of train_triplet.py:337-366 on held-out
+    utterances of the same speakers (all pairs): distances, the threshold sweep of eval_metrics.calculate_roc, EER."""
+    sys.path.insert(0, "/root/reference")
+    import eval_metrics as ref_eval
+    sd = O.make_state_dict(seed=TRAJ["param_seed"], num_classes=TRAJ["speakers"], randomize_bn=False)
+    m = build_ref(sd, TRAJ["speakers"]).train()
+    opt = torch.optim.SGD(m.parameters(), lr=TRAJ["lr"])
+    losses = []
+    x_test, ii, jj, same = trajectory_test_set()
+
+    def eer_now():
+        m.eval()
+        with torch.no_grad():
+            e = m(torch.from_numpy(x_test))
+            d = ref.PairwiseDistance(2).forward(e[ii], e[jj]).numpy()
+        m.train()
+        thr = np.arange(0, 30, 0.01)
+        tp, fp = O.roc_sweep(d, same.astype(np.float64), thr)[:2]
+        return e.numpy(), d, O.equal_error_rate(tp, fp, same.sum(), (~same).sum())
+
+    _, _, eer0 = eer_now()
+    for it in range(TRAJ["steps"]):
+        xs = [torch.from_numpy(v) for v in trajectory_batches(it)]
+        oa, op, on = m(xs[0]), m(xs[1]), m(xs[2])                           # train_triplet.py:215
+        loss = ref.TripletMarginLoss(TRAJ["margin"]).forward(oa, op, on)   # :219
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    e, d, eer = eer_now()
+    tpr, fpr, acc = ref_eval.calculate_roc(np.arange(0, 30, 0.01), d, same.astype(np.float64))
+    out = {"traj_loss": np.array(losses, np.float64), "traj_test_emb": e, "traj_test_dist": d,
+           "traj_test_same": same, "traj_eer": np.array(eer), "traj_eer_before": np.array(eer0),
+           "traj_roc_tpr_fpr_acc": np.array([tpr, fpr, acc], np.float64),
+           "traj_final_running_mean_bn1": m.state_dict()["model.bn1.running_mean"].numpy(),
+           "traj_final_fc_bias": m.state_dict()["model.fc.bias"].numpy()}
+    print("trajectory losses:", " ".join(f"{v:.4f}" for v in losses))
+    print(f"mean of first 10 {np.mean(losses[:10]):.4f}, last 10 {np.mean(losses[-10:]):.4f}; EER {eer0:.4f} -> {eer:.4f}")
+    path = os.path.join(HERE, "reference_trajectory.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cfg1_train":
         make_cfg1_train()
+    elif len(sys.argv) > 1 and sys.argv[1] == "offdist":
+        make_offdist()
+    elif len(sys.argv) > 1 and sys.argv[1] == "trajectory":
+        make_trajectory()
     else:
         main()
         make_cfg1_train()
+        make_offdist()
+        make_trajectory()
