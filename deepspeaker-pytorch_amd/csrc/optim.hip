@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) sgd_kernel(const OptTables t, float lr, f
     const long long i0 = (long long)t.chunk_index[blockIdx.x] * OPT_CHUNK;
     float *p = t.params[ti];
     const float *g = t.grads[ti];
-    float *b = t.s1[ti];
+    float *b = momentum != 0.0f ? t.s1[ti] : nullptr;      // plain SGD has no state table at all
     for (int k = threadIdx.x; k < OPT_CHUNK; k += 256) {
         const long long i = i0 + k;
         if (i >= n) break;

@@ -242,7 +242,7 @@ def test_forward_eval_bf16_precisions(precision, tol):
     assert err < tol
 
 
-@pytest.mark.parametrize("kind", ["adagrad", "sgd", "adam"])
+@pytest.mark.parametrize("kind", ["adagrad", "sgd", "sgd_plain", "adam"])
 def test_fused_optimizers_match_torch(kind):
     """One-launch multi-tensor steps vs torch.optim with the reference's hyper-parameters
     (train_triplet.py:369-383); the checker here is torch's own CPU optimizer."""
@@ -258,6 +258,9 @@ def test_fused_optimizers_match_torch(kind):
     elif kind == "sgd":
         ref = torch.optim.SGD(ref_p, lr=0.1, momentum=0.9, dampening=0.9, weight_decay=1e-3)
         ours = fo.FusedSGD(our_p, lr=0.1, momentum=0.9, dampening=0.9, weight_decay=1e-3)
+    elif kind == "sgd_plain":       # no momentum: the optimizer has no state tensors at all (a null state table)
+        ref = torch.optim.SGD(ref_p, lr=0.05)
+        ours = fo.FusedSGD(our_p, lr=0.05)
     else:
         ref = torch.optim.Adam(ref_p, lr=0.01, weight_decay=1e-3)
         ours = fo.FusedAdam(our_p, lr=0.01, weight_decay=1e-3)
@@ -278,7 +281,8 @@ def test_fused_optimizers_match_torch(kind):
             assert (b._version > versions[k]) == (b.grad is not None), (kind, it, k)
     # state interchange: our state_dict loads into torch's optimizer and vice versa
     sd = ours.state_dict()
-    assert set(sd["state"][0].keys()) == set(ref.state_dict()["state"][0].keys())
+    if kind != "sgd_plain":
+        assert set(sd["state"][0].keys()) == set(ref.state_dict()["state"][0].keys())
     ref.load_state_dict(sd)
 
 

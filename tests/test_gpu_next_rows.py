@@ -10,7 +10,7 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["adagrad", "sgd", "adam"])
+@pytest.mark.parametrize("kind", ["adagrad", "sgd", "sgd_plain", "adam"])
 def test_fused_optimizer_vs_torch(kind):
     from deepspeaker_pytorch_amd import optim as fo
     rs = np.random.RandomState(3)
@@ -23,6 +23,9 @@ def test_fused_optimizer_vs_torch(kind):
     elif kind == "sgd":         # train_triplet.py:372-374
         ref = torch.optim.SGD(ref_p, lr=0.1, momentum=0.9, dampening=0.9, weight_decay=1e-3)
         ours = fo.FusedSGD(our_p, lr=0.1, momentum=0.9, dampening=0.9, weight_decay=1e-3)
+    elif kind == "sgd_plain":   # no momentum: the optimizer has no state tensors at all (a null state table)
+        ref = torch.optim.SGD(ref_p, lr=0.05)
+        ours = fo.FusedSGD(our_p, lr=0.05)
     else:                       # train_triplet.py:376-377
         ref = torch.optim.Adam(ref_p, lr=0.01, weight_decay=1e-3)
         ours = fo.FusedAdam(our_p, lr=0.01, weight_decay=1e-3)
