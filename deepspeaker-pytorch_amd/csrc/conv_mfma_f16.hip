@@ -10,21 +10,42 @@
 
 namespace {
 
-// OIHW f32 -> [Cin/16][tap][Cout][16] fp16 (round to nearest even)
+// OIHW f32 -> [K/16][tap][N][16] fp16 (round to nearest even), the bank of a convolution contracting K input channels
+// into N output channels over `taps` taps:
+//   mode 0  forward:            K = Cin,  N = Cout,     taps = KS x KS            bank[k][t][n] = w[n][k][t]
+//   mode 1  data gradient:      K = Cout, N = Cin,      taps flipped              bank[k][t][n] = w[k][n][T-1-t]
+//   mode 2  data gradient of the 5x5 STRIDE-2 layers as ONE 3x3 stride-1 convolution over the output-gradient grid with
+//           4 Cin output channels, one block of Cin per parity class (a, b) of the input pixel (2i + a, 2j + b):
+//           dX[2i+a, 2j+b, ci] = sum_{r,c,co} dY[i-1+r, j-1+c, co] * w[co][ci][a + 2(2-r)][b + 2(2-c)]   (taps with a
+//           kernel index of 5 do not exist: zero).  K = Cout, N = 4 Cin (n = (2a + b) Cin + ci), taps = 3 x 3.
 __global__ void __launch_bounds__(256) pack_conv_weight_f16_kernel(const float *w, _Float16 *out, int Cout, int Cin,
-                                                                   int KS) {
-    const int T = KS * KS;
-    const long long n = (long long)Cout * Cin * T;
+                                                                   int KS, int mode) {
+    const int TK = mode == 2 ? 3 : KS, T = TK * TK;
+    const int N = mode == 0 ? Cout : (mode == 1 ? Cin : 4 * Cin), K = mode == 0 ? Cin : Cout;
+    const long long n = (long long)N * K * T;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int kk = (int)(i & 15);
         long long r = i >> 4;
-        const int co = (int)(r % Cout);
-        r /= Cout;
+        const int nn = (int)(r % N);
+        r /= N;
         const int t = (int)(r % T);
         const int kc = (int)(r / T);
-        const int ci = kc * 16 + kk;
-        const int kh = t / KS, kw = t - kh * KS;
-        out[i] = (_Float16)w[(((size_t)co * Cin + ci) * KS + kh) * KS + kw];
+        const int k = kc * 16 + kk;
+        float v;
+        if (mode == 0) {
+            const int kh = t / KS, kw = t - kh * KS;
+            v = w[(((size_t)nn * Cin + k) * KS + kh) * KS + kw];
+        } else if (mode == 1) {
+            const int tt = T - 1 - t;
+            const int kh = tt / KS, kw = tt - kh * KS;
+            v = w[(((size_t)k * Cin + nn) * KS + kh) * KS + kw];
+        } else {
+            const int cls = nn / Cin, ci = nn - cls * Cin;
+            const int a = cls >> 1, b = cls & 1;
+            const int kh = a + 2 * (2 - t / 3), kw = b + 2 * (2 - t % 3);
+            v = (kh < 5 && kw < 5) ? w[(((size_t)k * Cin + ci) * 5 + kh) * 5 + kw] : 0.0f;
+        }
+        out[i] = (_Float16)v;
     }
 }
 
@@ -237,14 +258,31 @@ static bool plan_persistent(PlanH &pl, const ds_conv_shape *s) {
 
 }  // namespace
 
-extern "C" int ds_pack_conv_weight_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, void *stream) {
+static int pack_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, int mode, void *stream) {
     DS_REQUIRE(w_oihw && w_f16, DS_ERR_NULL);
-    DS_REQUIRE(Cout > 0 && Cin > 0 && (KS == 3 || KS == 5) && (Cin % 16) == 0, DS_ERR_BAD_SHAPE);
-    const long long n = (long long)Cout * Cin * KS * KS;
+    DS_REQUIRE(Cout > 0 && Cin > 0 && (KS == 3 || KS == 5), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(((mode == 0 ? Cin : Cout) % 16) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(mode != 2 || KS == 5, DS_ERR_UNSUPPORTED);
+    const long long n = (long long)Cout * Cin * (mode == 2 ? 36 : KS * KS);
     long long g = (n + 255) / 256;
     DS_LAUNCH(pack_conv_weight_f16_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w_oihw, (_Float16 *)w_f16, Cout,
-              Cin, KS);
+              Cin, KS, mode);
     return ds_last_launch_error();
+}
+
+extern "C" int ds_pack_conv_weight_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, void *stream) {
+    return pack_f16(w_oihw, w_f16, Cout, Cin, KS, 0, stream);
+}
+
+// The data-gradient banks of the fp16 training step (train_f16.hip): ds_conv_fwd_f16 over dL/d(conv output) with these
+// filters IS the data gradient.  stride 1: [Cout/16][tap][Cin][16], taps flipped (Cout * Cin * KS * KS halfs; the
+// convolution then has Cin' = Cout, Cout' = Cin).  stride 2 (KS = 5 only): [Cout/16][9][4 Cin][16] (36 * Cout * Cin
+// halfs) -- a 3x3 stride-1 convolution with Cin' = Cout, Cout' = 4 Cin whose output [B][Ho][Wo][2][2][Cin] holds the four
+// parity classes of dX (ds_bn_bwd_group_f16 reads that layout directly).
+extern "C" int ds_pack_conv_weight_dgrad_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, int stride,
+                                             void *stream) {
+    DS_REQUIRE(stride == 1 || stride == 2, DS_ERR_UNSUPPORTED);
+    return pack_f16(w_oihw, w_f16, Cout, Cin, KS, stride == 2 ? 2 : 1, stream);
 }
 
 extern "C" int ds_cast_f32_to_f16(const float *x, void *y_f16, long long n, void *stream) {

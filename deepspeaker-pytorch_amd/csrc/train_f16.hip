@@ -1,0 +1,367 @@
+// train_f16.hip -- the element-wise side of the OPT-IN fp16 training step (DeepSpeakerModel(train_precision="f16")):
+// train-mode BatchNorm forward and backward (reference model.py:59,62,70,74,94,... under model.train(); autograd as run by
+// loss.backward(), train_triplet.py:223) over fp16 tensors in HBM, f32 arithmetic inside.
+//
+// Why a separate family: the f32-class step (bf16x3) keeps f32 activations and gradients in HBM -- 6 ms of its 18 ms are
+// HBM-bound BatchNorm / clip passes over them.  Here every activation, pre-activation and gradient tensor is fp16 (half
+// the bytes per pass), the convolutions are the eval path's fp16 matrix-core kernels (one MFMA per product), and the
+// statistics are taken by a pass of their own over the fp16 pre-activation (2 bytes per element -- cheaper than the f32
+// path's epilogue-fused sums were to give up).  Gradient tensors hold S * g (a constant loss scale, a power of two) so that
+// the small gradients of the early layers stay inside fp16's normal range; dgamma / dbeta and the filter gradients are
+// un-scaled where they leave in f32.
+//
+// Batch = G members (anchor / positive / negative forwards of a triplet step, train_triplet.py:215) with their own batch
+// statistics: member m owns pixels [m * n_pix, (m + 1) * n_pix) and row m of every [G][C] table.
+#include <ds_device.h>
+#include "ds_common.h"
+
+namespace {
+
+typedef _Float16 h16;
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const h16 *p, size_t i4) { return __builtin_convertvector(((const h16x4 *)p)[i4], f32x4); }
+__device__ __forceinline__ void st4(h16 *p, size_t i4, f32x4 v) { ((h16x4 *)p)[i4] = __builtin_convertvector(v, h16x4); }
+
+constexpr int TF_FOLD_R = 64;           // row lanes of the partial-sum folds below (x 4 channels per workgroup)
+
+// partial[member][blk][c] = { sum z, sum z^2 } over the block's pixels (f32 sums of fp16 values)
+__global__ void __launch_bounds__(256) bn_stats_f16_kernel(const h16 *z, float *partial, long long n_pix, int C,
+                                                           int pix_per_block, int blocks_per_member) {
+    const int member = blockIdx.x / blocks_per_member, mblock = blockIdx.x - member * blocks_per_member;
+    z += (size_t)member * n_pix * C;
+    float *red = ds_dynamic_lds();                         // [slots][C][2]
+    const int cvec = C >> 2;
+    const int slots = 256 / cvec;
+    const int cg = threadIdx.x % cvec, slot = threadIdx.x / cvec;
+    const long long p0 = (long long)mblock * pix_per_block;
+    long long p1 = p0 + pix_per_block;
+    if (p1 > n_pix) p1 = n_pix;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (slot < slots) {
+        for (long long p = p0 + slot; p < p1; p += slots) {
+            const f32x4 v = ld4(z, (size_t)p * cvec + cg);
+            s1 += v;
+            s2 += v * v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[((slot * C) + cg * 4 + j) * 2 + 0] = s1[j];
+            red[((slot * C) + cg * 4 + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int s = 0; s < slots; ++s) {
+            a1 += red[(s * C + c) * 2 + 0];
+            a2 += red[(s * C + c) * 2 + 1];
+        }
+        partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a1;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = a2;
+    }
+}
+
+// fold of one member's partial rows for 4 channels per workgroup, double precision, fixed order
+__device__ __forceinline__ bool fold4(const float *partial, int n_partial, int C, double *red, int c0, int &c, double &t1,
+                                      double &t2) {
+    const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    c = c0 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rl; r < n_partial; r += TF_FOLD_R) {
+            const float *src = partial + ((size_t)r * C + c) * 2;
+            s1 += (double)src[0];
+            s2 += (double)src[1];
+        }
+    __syncthreads();                                        // (the previous member's fold has been read)
+    red[(rl * 4 + cl) * 2 + 0] = s1;
+    red[(rl * 4 + cl) * 2 + 1] = s2;
+    __syncthreads();
+    if (rl != 0 || c >= C) return false;
+    t1 = t2 = 0.0;
+    for (int k = 0; k < TF_FOLD_R; ++k) {
+        t1 += red[(k * 4 + cl) * 2 + 0];
+        t2 += red[(k * 4 + cl) * 2 + 1];
+    }
+    return true;
+}
+
+// All G members of one BatchNorm layer in one launch: batch mean / invstd / (scale, shift) per member into [G][C]
+// tables, and the running statistics updated member after member IN CALL ORDER (the reference's model(data_a),
+// model(data_p), model(data_n) are three nn.BatchNorm2d.train() calls: three momentum updates, model.py:188).
+__global__ void __launch_bounds__(256) bn_stats_finalize_group_kernel(const float *partial, int n_partial, double count,
+                                                                      const float *gamma, const float *beta, float eps,
+                                                                      float momentum, float *running_mean,
+                                                                      float *running_var, float *mean_t, float *invstd_t,
+                                                                      float *scale_t, float *shift_t, int C, int G) {
+    double *red = (double *)ds_dynamic_lds();              // [TF_FOLD_R][4][2]
+    for (int m = 0; m < G; ++m) {
+        int c;
+        double t1, t2;
+        if (fold4(partial + (size_t)m * n_partial * C * 2, n_partial, C, red, (int)blockIdx.x * 4, c, t1, t2)) {
+            const double mean = t1 / count;
+            double var = t2 / count - mean * mean;         // biased (normalisation) variance
+            if (var < 0.0) var = 0.0;
+            const double invstd = 1.0 / sqrt(var + (double)eps);
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            if (running_mean) {
+                running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+                running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+            }
+            const size_t o = (size_t)m * C + c;
+            mean_t[o] = (float)mean;
+            invstd_t[o] = (float)invstd;
+            const double s = (double)gamma[c] * invstd;
+            scale_t[o] = (float)s;
+            shift_t[o] = (float)((double)beta[c] - mean * s);
+        }
+    }
+}
+
+// y = clip(z * scale[m] + shift[m] (+ residual)), fp16 in; fp16 or f32 out
+template <bool OUT32>
+__global__ void __launch_bounds__(256) bn_apply_f16_kernel(const h16 *z, const float *scale_t, const float *shift_t,
+                                                           const h16 *res, void *y, long long n_vec_member, int G, int C,
+                                                           int flags) {
+    const int cvec = C >> 2;
+    const long long n_vec = n_vec_member * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
+        const int member = (int)(i / n_vec_member);
+        const int c4 = (int)(i % cvec);
+        const f32x4 sc = ((const f32x4 *)(scale_t + (size_t)member * C))[c4], sh = ((const f32x4 *)(shift_t + (size_t)member * C))[c4];
+        f32x4 v = ld4(z, (size_t)i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ds_bn_affine(v[j], sc[j], sh[j]);
+        if (flags & DS_EPI_RESIDUAL) v += ld4(res, (size_t)i);
+        if (flags & DS_EPI_CLIP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], 0.0f), 20.0f);
+        }
+        if constexpr (OUT32) ((f32x4 *)y)[i] = v;
+        else st4((h16 *)y, (size_t)i, v);
+    }
+}
+
+// Backward, first half.  gy = (g1 [+ g2]) * [0 < act < 20] (act == nullptr: no mask), written as fp16;
+// partial[member][blk][c] = { sum gy, sum gy * xhat }, xhat = (z - mean) * invstd.
+// PARITY: g1 is the output of the 5x5 stride-2 data gradient run as ONE 3x3 convolution with 4 C output channels
+// (ds_pack_conv_weight_f16 mode 2): [B][Ho2][Wo2][2][2][C] -- pixel (h, w) of this layer's [H][W] map is parity class
+// (h & 1, w & 1) of cell (h >> 1, w >> 1).
+template <bool PARITY, bool ACT32>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_f16_kernel(const h16 *g1, const h16 *g2, const void *act, const h16 *z,
+                                                                const float *mean, const float *invstd, h16 *gy,
+                                                                float *partial, long long n_pix, int C, int pix_per_block,
+                                                                int blocks_per_member, int H, int W) {
+    const int member = blockIdx.x / blocks_per_member, mblock = blockIdx.x - member * blocks_per_member;
+    const size_t moff = (size_t)member * n_pix * C;
+    mean += (size_t)member * C;
+    invstd += (size_t)member * C;
+    float *red = ds_dynamic_lds();                         // [slots][C][2]
+    const int cvec = C >> 2;
+    const int slots = 256 / cvec;
+    const int cg = threadIdx.x % cvec, slot = threadIdx.x / cvec;
+    const long long p0 = (long long)mblock * pix_per_block;
+    long long p1 = p0 + pix_per_block;
+    if (p1 > n_pix) p1 = n_pix;
+    const int Ho2 = (H + 1) >> 1, Wo2 = (W + 1) >> 1;
+    const long long img_pix = (long long)H * W;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (slot < slots) {
+        const f32x4 mu = ((const f32x4 *)mean)[cg], is = ((const f32x4 *)invstd)[cg];
+        for (long long p = p0 + slot; p < p1; p += slots) {
+            const size_t i = (moff >> 2) + (size_t)p * cvec + cg;           // float4 index in the [G * n_pix][C] tensors
+            f32x4 g;
+            if constexpr (PARITY) {
+                const long long gp = (long long)member * n_pix + p;         // pixel index in the whole batch
+                const long long b = gp / img_pix;
+                const int rem = (int)(gp - b * img_pix);
+                const int h = rem / W, w = rem - h * W;
+                const size_t cell = ((size_t)b * Ho2 + (h >> 1)) * Wo2 + (w >> 1);
+                g = ld4(g1, (cell * 4 + (size_t)((h & 1) * 2 + (w & 1))) * cvec + cg);
+            } else {
+                g = ld4(g1, i);
+            }
+            if (g2) g += ld4(g2, i);
+            if (act) {
+                f32x4 a;
+                if constexpr (ACT32) a = ((const f32x4 *)act)[i];
+                else a = ld4((const h16 *)act, i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = (a[j] > 0.0f && a[j] < 20.0f) ? g[j] : 0.0f;
+            }
+            const h16x4 gh = __builtin_convertvector(g, h16x4);
+            ((h16x4 *)gy)[i] = gh;
+            g = __builtin_convertvector(gh, f32x4);                         // the sums are those of the STORED gradient
+            const f32x4 xh = (ld4(z, i) - mu) * is;
+            s1 += g;
+            s2 += g * xh;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[((slot * C) + cg * 4 + j) * 2 + 0] = s1[j];
+            red[((slot * C) + cg * 4 + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int s = 0; s < slots; ++s) {
+            a1 += red[(s * C + c) * 2 + 0];
+            a2 += red[(s * C + c) * 2 + 1];
+        }
+        partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a1;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = a2;
+    }
+}
+
+// Backward, fold: per member coef = { gamma * invstd, sum gy / N, sum gy * xhat / N } (in the gradient tensors' scaled
+// units), and dgamma / dbeta = the members' sums added in member order, UN-scaled (inv_scale = 1 / S).
+__global__ void __launch_bounds__(256) bn_bwd_finalize_f16_kernel(const float *partial, int n_partial, double count,
+                                                                  const float *gamma, const float *invstd_t, float *coef,
+                                                                  float *ggamma, float *gbeta, int C, int G,
+                                                                  float inv_scale) {
+    double *red = (double *)ds_dynamic_lds();
+    double gg = 0.0, gb = 0.0;
+    int c = 0;
+    bool mine = false;
+    for (int m = 0; m < G; ++m) {
+        double t1, t2;
+        if (fold4(partial + (size_t)m * n_partial * C * 2, n_partial, C, red, (int)blockIdx.x * 4, c, t1, t2)) {
+            mine = true;
+            float *cf = coef + (size_t)m * 3 * C;
+            cf[c] = gamma[c] * invstd_t[(size_t)m * C + c];
+            cf[C + c] = (float)(t1 / count);
+            cf[2 * C + c] = (float)(t2 / count);
+            gb += (double)(float)t1;                        // (the f32 path adds the members' f32 sums)
+            gg += (double)(float)t2;
+        }
+    }
+    if (mine) {
+        ggamma[c] = (float)(gg * (double)inv_scale);
+        gbeta[c] = (float)(gb * (double)inv_scale);
+    }
+}
+
+// Backward, second half: gz = gamma * invstd * (gy - mean(gy) - xhat * mean(gy * xhat)), fp16 in / out
+__global__ void __launch_bounds__(256) bn_bwd_apply_f16_kernel(const h16 *gy, const h16 *z, const float *mean_t,
+                                                               const float *invstd_t, const float *coef, h16 *gz,
+                                                               long long n_vec_member, int G, int C) {
+    const int cvec = C >> 2;
+    const long long n_vec = n_vec_member * G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
+        const int member = (int)(i / n_vec_member);
+        const int c4 = (int)(i % cvec);
+        const float *cf = coef + (size_t)member * 3 * C;
+        const f32x4 mu = ((const f32x4 *)(mean_t + (size_t)member * C))[c4], is = ((const f32x4 *)(invstd_t + (size_t)member * C))[c4];
+        const f32x4 k1 = ((const f32x4 *)cf)[c4], k2 = ((const f32x4 *)(cf + C))[c4], k3 = ((const f32x4 *)(cf + 2 * C))[c4];
+        const f32x4 xh = (ld4(z, (size_t)i) - mu) * is;
+        st4(gz, (size_t)i, k1 * (ld4(gy, (size_t)i) - k2 - xh * k3));
+    }
+}
+
+__global__ void __launch_bounds__(256) scale_cast_f16_kernel(const float *x, h16 *y, long long n_vec, float scale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256)
+        st4(y, (size_t)i, ((const f32x4 *)x)[i] * scale);
+}
+
+static int tf_grid(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+static bool tf_shape_ok(long long n_pix, int C, int G) {
+    return n_pix > 0 && G > 0 && G <= 64 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0;
+}
+
+}  // namespace
+
+extern "C" int ds_bn_bwd_partial_rows(long long n_pix, int C);
+
+// Train-mode BatchNorm statistics of G members over an fp16 pre-activation z [G * n_pix][C]: partial sums (rows =
+// ds_bn_bwd_partial_rows(n_pix, C) per member), then tables [G][C] of mean / invstd / scale / shift and the running
+// statistics updated member after member (call order).  `partial`: G * rows * C * 2 floats of scratch.
+extern "C" int ds_bn_stats_group_f16(const void *z_f16, float *partial, long long n_pix, const float *gamma,
+                                     const float *beta, float eps, float momentum, float *running_mean,
+                                     float *running_var, float *mean_t, float *invstd_t, float *scale_t, float *shift_t,
+                                     int C, int G, void *stream) {
+    DS_REQUIRE(z_f16 && partial && gamma && beta && mean_t && invstd_t && scale_t && shift_t, DS_ERR_NULL);
+    DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(z_f16), DS_ERR_ALIGNMENT);
+    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
+    const int ppb = (int)((n_pix + blocks - 1) / blocks);
+    const int slots = 256 / (C / 4);
+    DS_LAUNCH(bn_stats_f16_kernel, blocks * G, 256, (size_t)slots * C * 2 * 4, stream, (const h16 *)z_f16, partial, n_pix, C,
+              ppb, blocks);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(bn_stats_finalize_group_kernel, ds_ceil_div(C, 4), 256, TF_FOLD_R * 4 * 2 * sizeof(double), stream,
+              (const float *)partial, blocks, (double)n_pix, gamma, beta, eps, momentum, running_mean, running_var, mean_t,
+              invstd_t, scale_t, shift_t, C, G);
+    return ds_last_launch_error();
+}
+
+// y = clip(z * scale[m] + shift[m] (+ residual)) for all G members in one launch; y is fp16, or f32 with DS_EPI_OUT_F32
+// (the last stage hands f32 to the pooling / projection tail).  flags: DS_EPI_RESIDUAL | DS_EPI_CLIP | DS_EPI_OUT_F32.
+extern "C" int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, const float *shift_t, const void *res_f16,
+                                     void *y, long long n_pix, int C, int G, int flags, void *stream) {
+    DS_REQUIRE(z_f16 && scale_t && shift_t && y, DS_ERR_NULL);
+    DS_REQUIRE(!(flags & DS_EPI_RESIDUAL) || res_f16, DS_ERR_NULL);
+    DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(z_f16) && DS_ALIGNED16(y) && DS_ALIGNED16(res_f16) && DS_ALIGNED16(scale_t) && DS_ALIGNED16(shift_t),
+               DS_ERR_ALIGNMENT);
+    const long long nvm = n_pix * (C / 4);
+    if (flags & DS_EPI_OUT_F32)
+        DS_LAUNCH(bn_apply_f16_kernel<true>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)z_f16, scale_t, shift_t,
+                  (const h16 *)res_f16, y, nvm, G, C, flags);
+    else
+        DS_LAUNCH(bn_apply_f16_kernel<false>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)z_f16, scale_t, shift_t,
+                  (const h16 *)res_f16, y, nvm, G, C, flags);
+    return ds_last_launch_error();
+}
+
+// BatchNorm + clipped-ReLU backward of G members over fp16 tensors (three launches): g1 [+ g2] masked by 0 < act < 20
+// (act fp16, or f32 with act_is_f32; nullptr: g1 is already masked) -> gy; sums; gz = dL/d(conv output).  Gradient
+// tensors are in loss-scaled units (S * g); ggamma / gbeta [C] leave un-scaled (inv_scale = 1 / S).
+// g1_parity: g1 is the [B][ceil(H/2)][ceil(W/2)][4 C] output of the stride-2 data gradient run as one 3x3 convolution
+// (H, W = this layer's map; otherwise ignored).  partial: G * rows * C * 2 floats; coef: [G][3 C].
+extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
+                                   const void *z, const float *mean_t, const float *invstd_t, const float *gamma, void *gy,
+                                   float *partial, float *coef, float *ggamma, float *gbeta, void *gz, long long n_pix,
+                                   int H, int W, int C, int G, float inv_scale, void *stream) {
+    DS_REQUIRE(g1 && z && mean_t && invstd_t && gamma && gy && partial && coef && ggamma && gbeta && gz, DS_ERR_NULL);
+    DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(!g1_parity || (H > 0 && W > 0 && (n_pix * G) % ((long long)H * W) == 0), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(g2) && DS_ALIGNED16(act) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) &&
+                   DS_ALIGNED16(gz) && DS_ALIGNED16(mean_t) && DS_ALIGNED16(invstd_t) && DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
+    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
+    const int ppb = (int)((n_pix + blocks - 1) / blocks);
+    const int slots = 256 / (C / 4);
+    const size_t lds = (size_t)slots * C * 2 * 4;
+#define TF_REDUCE(P, A)                                                                                                    \
+    DS_LAUNCH((bn_bwd_reduce_f16_kernel<P, A>), blocks * G, 256, lds, stream, (const h16 *)g1, (const h16 *)g2, act,        \
+              (const h16 *)z, mean_t, invstd_t, (h16 *)gy, partial, n_pix, C, ppb, blocks, H, W)
+    if (g1_parity) { if (act_is_f32) TF_REDUCE(true, true); else TF_REDUCE(true, false); }
+    else           { if (act_is_f32) TF_REDUCE(false, true); else TF_REDUCE(false, false); }
+#undef TF_REDUCE
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(bn_bwd_finalize_f16_kernel, ds_ceil_div(C, 4), 256, TF_FOLD_R * 4 * 2 * sizeof(double), stream,
+              (const float *)partial, blocks, (double)n_pix, gamma, invstd_t, coef, ggamma, gbeta, C, G, inv_scale);
+    rc = ds_last_launch_error();
+    if (rc) return rc;
+    const long long nvm = n_pix * (C / 4);
+    DS_LAUNCH(bn_bwd_apply_f16_kernel, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy, (const h16 *)z, mean_t, invstd_t,
+              (const float *)coef, (h16 *)gz, nvm, G, C);
+    return ds_last_launch_error();
+}
+
+// y_f16 = fp16(x * scale): how an f32 gradient enters the fp16 backward pass (scale = the loss scale S)
+extern "C" int ds_scale_cast_f32_to_f16(const float *x, void *y_f16, long long n, float scale, void *stream) {
+    DS_REQUIRE(x && y_f16, DS_ERR_NULL);
+    DS_REQUIRE(n > 0 && (n % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(y_f16), DS_ERR_ALIGNMENT);
+    DS_LAUNCH(scale_cast_f16_kernel, tf_grid(n / 4), 256, 0, stream, x, (h16 *)y_f16, n / 4, scale);
+    return ds_last_launch_error();
+}

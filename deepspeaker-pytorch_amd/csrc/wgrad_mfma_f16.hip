@@ -1,20 +1,14 @@
-// wgrad_mfma_bf16.hip -- filter gradients of the 3x3 / 5x5 convolution layers on the bf16 matrix cores
-// with split operands (bf16x3: x = hi + lo, product = hi*hi + hi*lo + lo*hi, f32 accumulate).
+// wgrad_mfma_f16.hip -- filter gradients of the 3x3 / 5x5 convolution layers for the OPT-IN fp16 training step
+// (train_f16.hip): fp16 activations and fp16 (loss-scaled) output gradients in HBM, ONE v_mfma_f32_32x32x16_f16 per
+// product, f32 accumulation, f32 result un-scaled in the fixed-order fold.
 //
 // dW[co][ci][kh][kw] = sum over (b, h, w) of dY[b,h,w,co] * X[b, s*h+kh-p, s*w+kw-p, ci]
-// (autograd of nn.Conv2d under loss.backward(), reference train_triplet.py:223; layers model.py:47-50,
-// 98-106).  As a GEMM: M = Cout, N = Cin, K = every output pixel of the batch.  Same decomposition as the
-// f32 kernel (wgrad_mfma_f32.hip): workgroup = (tap group, 64 co, 64 ci, pixel split); per pixel tile the
-// dY rows and the X halo tile are staged in LDS once and reused by every tap of the group; partial sums go
-// to [split][tap][Cout][Cin] and wgrad_reduce_kernel folds them in a fixed order (deterministic).
-//
-// What is different: v_mfma_f32_32x32x16_bf16 contracts 16 pixels per instruction and wants, per lane, 8
-// CONSECUTIVE pixels of ONE channel -- the transposed view of the channels-last activations.  The tiles
-// stay pixel-major in LDS ([pixel][hi 64 ch | lo 64 ch] bf16 records, written with coalesced 8-byte
-// stores) and the operands are fetched with ds_read_b64_tr_b16: within a 16-lane group lane i supplies the
-// 8-byte piece (row i>>2, column quad i&3) of a 4-pixel x 16-channel block and receives column i, i.e. 4
-// pixels of its own channel.  Two such reads make one bf16x8 fragment; because every lane supplies its own
-// pixel address, any tap offset or stride works without alignment constraints.
+// (autograd of nn.Conv2d under loss.backward(), reference train_triplet.py:223; layers model.py:47-50, 98-106).
+// Same decomposition as the split-operand bf16 kernel (wgrad_mfma_bf16.hip: workgroup = (64 co, 64 ci, pixel split),
+// one accumulator per tap, operands fetched with ds_read_b64_tr_b16 from pixel-major LDS records, 5x5 as two launches
+// over kernel-row groups).  What fp16 tensors change: staging is a 16-byte copy (8 channels, no conversion, no hi / lo
+// halves), a pixel record is 128 B of data + 64 B of pad (conflict-free for the transposing reads) instead of 320 B, so
+// tiles are twice as many pixels (256 for a 3x3) at the same LDS footprint, and a tap is one MFMA instead of three.
 #include <ds_device.h>
 #include "ds_common.h"
 #include "wgrad_reduce.h"
@@ -22,19 +16,14 @@
 namespace {
 
 constexpr int WB_C = 64;                     // channels per tile on both sides
-constexpr int WB_REC = 4 * WB_C + 64;        // bytes per pixel record: hi (128) | lo (128) | pad -> 80 dwords = 16 mod 64
-// staging slots (16 pixels each) of the two 3x3 instantiations: 128-pixel tiles, and 160-pixel ones for geometries
-// whose image (or a much larger part of it) then fits one tile -- measured per layer at 768 utterances
-// (tools/wgrad_ab.py): 64-pixel tiles 610 / 506 / 463 / 587 us, 128: 540 / 431 / 461 / 422, 160: 564 / 446 / 410 / 442
-#ifndef DS_WGRAD_GSL3
-#define DS_WGRAD_GSL3 8
-#define DS_WGRAD_XSL3 14
-#endif
-constexpr int WB_GSL3 = DS_WGRAD_GSL3, WB_XSL3 = DS_WGRAD_XSL3;
-constexpr int WB_GSL3_BIG = 10, WB_XSL3_BIG = 17;
+constexpr int WB_REC = 2 * WB_C + 64;        // bytes per pixel record: 64 halfs | pad -> 48 dwords: four consecutive records (and their
+                                             // second 16-channel block, 8 dwords on) start in eight different 8-dword bank groups
+// staging slots per thread (16-byte items of 8 channels: 32 pixels per slot): a 3x3 tile is up to 256 output pixels and 446
+// halo pixels, a 5x5 kernel-row group up to 128 and 382
+constexpr int WH_GSL3 = 8, WH_XSL3 = 14, WH_GSL5 = 4, WH_XSL5 = 12;
 
-struct WgradKB {
-    const float *x, *gz;
+struct WgradKH {
+    const _Float16 *x, *gz;
     float *partial;
     int H, W, Cin, Ho, Wo, Cout;
     int KS, IS, pad;
@@ -46,26 +35,20 @@ struct WgradKB {
     int k0;                      // first kernel row of the group (5x5)
 };
 
-// one bf16x8 MFMA operand: pixels q0 .. q0+7 of this lane's channel; rec0 / rec1 are the byte addresses
+// one f16x8 MFMA operand: pixels q0 .. q0+7 of this lane's channel; rec0 / rec1 are the byte addresses
 // this lane supplies for the two 4-pixel blocks (its piece: pixel q0 + 4r + ((lane&15)>>2), quad lane&3)
-__device__ __forceinline__ bf16x8 frag_tr(const char *rec0, const char *rec1) {
-    const bf16x4 a = ds_read_tr16_b64(rec0);
-    const bf16x4 b = ds_read_tr16_b64(rec1);
+__device__ __forceinline__ f16x8 frag_tr(const char *rec0, const char *rec1) {
+    const f16x4 a = __builtin_bit_cast(f16x4, ds_read_tr16_b64(rec0));
+    const f16x4 b = __builtin_bit_cast(f16x4, ds_read_tr16_b64(rec1));
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// TG taps per workgroup, KW taps per kernel row.  <9, 3>: all of a 3x3.  A 5x5 runs as two launches over kernel-row
-// GROUPS: rows k0, k0 + stride, ... (k0 = 0: three rows = <15, 5>; the other two = <10, 5>).  With the stride between
-// a group's rows equal to the convolution stride, kernel row m of the group reads, for output row r, tile row r + m:
-// the staged tile holds only the input rows of that residue (RT + rows - 1 of them), and each dY tile staged is
-// contracted against 15 (10) taps instead of the 5 of a single kernel row.
-// Four waves as 2 (co) x 2 (ci), each owning a 32 x 32 block of every tap of the group; the accumulators take most
-// of the register file (one wave per SIMD).
-// GSL / XSL: staging slots per thread (float4 each) for the dY rows and the X halo tile -- the tile's size in registers:
-// 16 * GSL output pixels, 16 * XSL halo pixels.  A 3x3 (9 accumulators) has room for 8 + 14: 128-pixel tiles halve the
-// barriers, pipeline fills and halo rows per contracted pixel of the 64-pixel ones; a 5x5 group (15 accumulators) keeps 4 + 12.
+// TG taps per workgroup, KW taps per kernel row: <9, 3> = all of a 3x3; a 5x5 runs as two launches over kernel-row groups
+// (<15, 5>: rows k0, k0 + stride, k0 + 2 stride; <10, 5>: the other two) -- see wgrad_mfma_bf16.hip.  Four waves as
+// 2 (co) x 2 (ci), each owning a 32 x 32 block of every tap of the group (one wave per SIMD).
+// GSL / XSL: 16-byte staging slots per thread for the dY rows and the X halo tile.
 template <int TG, int KW, int GSL, int XSL>
-__global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kernel(const WgradKB p) {
+__global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_f16_kernel(const WgradKH p) {
     constexpr bool GROUP = KW == 5;                     // kernel-row group of a 5x5 (see above)
     char *lds = (char *)ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,7 +75,7 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     const int pix_per_seg = p.RT * p.Wo;
-    constexpr int QV = WB_C / 4;                        // float4 per staged pixel
+    constexpr int QV = WB_C / 8;                        // 16-byte items (8 halfs) per staged pixel
 
     // ---- tile-invariant staging descriptors: per slot the float offset RELATIVE to the segment's origin and
     //      (segment << 16 | row); per tile only four numbers per segment change (segtab) ----
@@ -108,7 +91,7 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
             const int seg = pp / pix_per_seg, rem = pp - seg * pix_per_seg;
             const int r = rem / p.Wo, c = rem - r * p.Wo;
             g_sr[it] = (seg < p.NI) ? ((seg << 16) | r) : -2;
-            g_rel[it] = (r * p.Wo + c) * p.Cout + cot * WB_C + q * 4;
+            g_rel[it] = (r * p.Wo + c) * p.Cout + cot * WB_C + q * 8;
         }
     }
 #pragma unroll
@@ -123,7 +106,7 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
             const int hrel = GROUP ? p.IS * rr + p.k0 : rr;            // image row = IS*r0 - pad + hrel
             const int w = cc - p.pad;
             x_sr[it] = (w >= 0 && w < p.W) ? ((seg << 16) | hrel) : -2;
-            x_rel[it] = (hrel * p.W + cc) * p.Cin + cit * WB_C + q * 4;
+            x_rel[it] = (hrel * p.W + cc) * p.Cin + cit * WB_C + q * 8;
         }
     }
     for (int pp = tid; pp < p.P; pp += 256) {
@@ -185,25 +168,16 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
 #pragma unroll
         for (int it = 0; it < GSL; ++it) {
             const bool ok = (g_sr[it] >= 0) & ((g_sr[it] & 0xFFFF) < g_rows[it]);
-            gv[it] = ds_buffer_load_f32x4(gbuf, ok ? (unsigned)(g_org[it] + g_rel[it]) * 4u : DS_BUFFER_OOB);
+            gv[it] = ds_buffer_load_f32x4(gbuf, ok ? (unsigned)(g_org[it] + g_rel[it]) * 2u : DS_BUFFER_OOB);
         }
 #pragma unroll
         for (int it = 0; it < XSL; ++it) {
             const int h = x_h0[it] + (x_sr[it] & 0xFFFF);
             const bool ok = (x_sr[it] >= 0) & (h >= 0) & (h < p.H);
-            xv[it] = ds_buffer_load_f32x4(xbuf, ok ? (unsigned)(x_org[it] + x_rel[it]) * 4u : DS_BUFFER_OOB);
+            xv[it] = ds_buffer_load_f32x4(xbuf, ok ? (unsigned)(x_org[it] + x_rel[it]) * 2u : DS_BUFFER_OOB);
         }
     };
-    auto put_split = [&](char *rec, int q, const f32x4 v) {     // 4 channels -> hi / lo halves of the record
-        bf16x4 h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h[j] = (__bf16)v[j];
-            l[j] = (__bf16)(v[j] - (float)h[j]);
-        }
-        *(bf16x4 *)(rec + q * 8) = h;
-        *(bf16x4 *)(rec + 2 * WB_C + q * 8) = l;
-    };
+    auto put = [&](char *rec, int q, const f32x4 v) { *(f32x4 *)(rec + q * 16) = v; };      // 8 channels, as they are
 
     // this lane's piece of every transposing read: pixel (lane&15)>>2 of the 4-pixel block, channel quad
     // lane&3 of the 16-channel block (lane>>4)&1 of the wave's 32 channels
@@ -221,13 +195,13 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
         for (int it = 0; it < GSL; ++it)
             if (g_sr[it] != -1) {
                 const int i = tid + it * 256;
-                put_split(gzt + (size_t)(i / QV) * WB_REC, i % QV, gv[it]);
+                put(gzt + (size_t)(i / QV) * WB_REC, i % QV, gv[it]);
             }
 #pragma unroll
         for (int it = 0; it < XSL; ++it)
             if (x_sr[it] != -1) {
                 const int i = tid + it * 256;
-                put_split(xt + (size_t)(i / QV) * WB_REC, i % QV, xv[it]);
+                put(xt + (size_t)(i / QV) * WB_REC, i % QV, xv[it]);
             }
         fill_segtab(tile + p.S, buf ^ 1);
         __syncthreads();
@@ -247,39 +221,28 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
         };
         const char *g0, *g1, *x0, *x1;
         step_ptrs(0, g0, g1, x0, x1);
-        bf16x8 a_hi = frag_tr(g0, g1), a_lo = frag_tr(g0 + 2 * WB_C, g1 + 2 * WB_C);
-        bf16x8 b_hi[NS], b_lo[NS];
+        f16x8 a = frag_tr(g0, g1);
+        f16x8 bf[NS];
 #pragma unroll
-        for (int t = 0; t < AH; ++t) {
-            b_hi[t] = frag_tr(x0 + tap_off(t), x1 + tap_off(t));
-            b_lo[t] = frag_tr(x0 + tap_off(t) + 2 * WB_C, x1 + tap_off(t) + 2 * WB_C);
-        }
+        for (int t = 0; t < AH; ++t) bf[t] = frag_tr(x0 + tap_off(t), x1 + tap_off(t));
         for (int s = 0; s < p.P; s += 16) {
             const char *ng0, *ng1, *nx0, *nx1;
             step_ptrs(s + 16 < p.P ? s + 16 : s, ng0, ng1, nx0, nx1);      // last step: harmless re-reads of this one
-            bf16x8 na_hi = a_hi, na_lo = a_lo;
+            f16x8 na = a;
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
                 const int ahead = t + AH, slot = ahead % NS;
                 if (ahead < TG) {
-                    b_hi[slot] = frag_tr(x0 + tap_off(ahead), x1 + tap_off(ahead));
-                    b_lo[slot] = frag_tr(x0 + tap_off(ahead) + 2 * WB_C, x1 + tap_off(ahead) + 2 * WB_C);
+                    bf[slot] = frag_tr(x0 + tap_off(ahead), x1 + tap_off(ahead));
                 } else {
-                    if (ahead == TG) {
-                        na_hi = frag_tr(ng0, ng1);
-                        na_lo = frag_tr(ng0 + 2 * WB_C, ng1 + 2 * WB_C);
-                    }
-                    b_hi[slot] = frag_tr(nx0 + tap_off(ahead - TG), nx1 + tap_off(ahead - TG));
-                    b_lo[slot] = frag_tr(nx0 + tap_off(ahead - TG) + 2 * WB_C, nx1 + tap_off(ahead - TG) + 2 * WB_C);
+                    if (ahead == TG) na = frag_tr(ng0, ng1);
+                    bf[slot] = frag_tr(nx0 + tap_off(ahead - TG), nx1 + tap_off(ahead - TG));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[t] = ds_mfma_32x32x16_bf16(a_lo, b_hi[t % NS], acc[t]);
-                acc[t] = ds_mfma_32x32x16_bf16(a_hi, b_lo[t % NS], acc[t]);
-                acc[t] = ds_mfma_32x32x16_bf16(a_hi, b_hi[t % NS], acc[t]);
+                acc[t] = ds_mfma_32x32x16_f16(a, bf[t % NS], acc[t]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            a_hi = na_hi;
-            a_lo = na_lo;
+            a = na;
             x0 = nx0;
             x1 = nx1;
         }
@@ -299,21 +262,20 @@ __global__ void __launch_bounds__(256) DS_ONE_WAVE_PER_SIMD wgrad_mfma_bf16_kern
     }
 }
 
-struct WgradPlanB {
-    WgradKB k;                   // 5x5: the geometry of the three-row group; wgrad_group_rows() derives the other
-    bool big;                    // 3x3: the 160-pixel-tile instantiation
+struct WgradPlanH {
+    WgradKH k;                   // 5x5: the geometry of the three-row group
     int grid;
     size_t lds_bytes;
     long long partial_floats;
 };
 
-static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
+static int plan_wgrad_h(WgradPlanH &pl, const ds_conv_shape *s) {
     DS_REQUIRE(s != nullptr, DS_ERR_NULL);
     DS_REQUIRE(s->B > 0 && s->H > 0 && s->W > 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(s->KS == 3 || s->KS == 5, DS_ERR_UNSUPPORTED);
     DS_REQUIRE(s->stride == 1 || s->stride == 2, DS_ERR_UNSUPPORTED);
     DS_REQUIRE(s->Cin % WB_C == 0 && s->Cout % WB_C == 0, DS_ERR_BAD_SHAPE);
-    WgradKB &k = pl.k;
+    WgradKH &k = pl.k;
     const int pad = s->KS / 2;
     k.H = s->H; k.W = s->W; k.Cin = s->Cin; k.Cout = s->Cout;
     k.Ho = (s->H + 2 * pad - s->KS) / s->stride + 1;
@@ -321,13 +283,12 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
     DS_REQUIRE(k.Ho > 0 && k.Wo > 0 && k.Wo <= 64, DS_ERR_BAD_SHAPE);
     DS_REQUIRE((long long)s->B * s->H * s->W * s->Cin < (1ll << 30), DS_ERR_BAD_SHAPE);      // 32-bit byte offsets
     DS_REQUIRE((long long)s->B * k.Ho * k.Wo * s->Cout < (1ll << 30), DS_ERR_BAD_SHAPE);
-    k.x_bytes = (unsigned)((long long)s->B * s->H * s->W * s->Cin * 4);
-    k.gz_bytes = (unsigned)((long long)s->B * k.Ho * k.Wo * s->Cout * 4);
+    k.x_bytes = (unsigned)((long long)s->B * s->H * s->W * s->Cin * 2);
+    k.gz_bytes = (unsigned)((long long)s->B * k.Ho * k.Wo * s->Cout * 2);
     k.KS = s->KS; k.IS = s->stride; k.pad = pad;
     k.k0 = 0;
     const int group_rows = 3;                             // kernel rows of the (larger) 5x5 group
-    // segment height / segments per tile: the kernel's staging slots bound the tile (16 pixels per slot): a 3x3 has
-    // 8 + 14 (128 output pixels, 222 halo pixels: 110 KiB of records, one workgroup per CU), a 5x5 group 4 + 12
+    // segment height / segments per tile: the kernel's staging slots bound the tile (32 pixels per slot)
     int max_out_pix = 0, max_in_pix = 0, best_rt = 0, best_ni = 1;
     // rows per segment: the most pixels per tile among the heights that waste the fewest rows in an image's last segment
     auto search = [&](int mo, int mi) {
@@ -353,17 +314,8 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
             ++best_ni;
         return best_ni * best_rt * k.Wo;                  // output pixels per tile
     };
-    pl.big = false;
-    if (s->KS == 3) {
-        const int px_big = search(WB_GSL3_BIG * 16, WB_XSL3_BIG * 16 - 2);
-        const int px = search(WB_GSL3 * 16, WB_XSL3 * 16 - 2);
-        if (WB_GSL3 < WB_GSL3_BIG && 2 * px_big >= 3 * px) {           // worth the larger tile only if it is much larger
-            search(WB_GSL3_BIG * 16, WB_XSL3_BIG * 16 - 2);
-            pl.big = true;
-        }
-    } else {
-        search(64, 190);
-    }
+    if (s->KS == 3) search(WH_GSL3 * 32, WH_XSL3 * 32 - 2);
+    else search(WH_GSL5 * 32, WH_XSL5 * 32 - 2);
     DS_REQUIRE(best_rt > 0, DS_ERR_UNSUPPORTED);
     k.RT = best_rt;
     k.segs_per_img = ds_ceil_div(k.Ho, best_rt);
@@ -391,41 +343,40 @@ static int plan_wgrad_b(WgradPlanB &pl, const ds_conv_shape *s) {
 
 }  // namespace
 
-extern "C" long long ds_conv_wgrad_bf16_workspace_floats(const ds_conv_shape *s) {
-    WgradPlanB pl;
-    int rc = plan_wgrad_b(pl, s);
+extern "C" long long ds_conv_wgrad_f16_workspace_floats(const ds_conv_shape *s) {
+    WgradPlanH pl;
+    int rc = plan_wgrad_h(pl, s);
     return rc == DS_OK ? pl.partial_floats : rc;
 }
 
-extern "C" int ds_conv_wgrad_bf16(const ds_conv_shape *s, const float *x, const float *gy, float *workspace,
-                                  float *gw_oihw, void *stream) {
-    DS_REQUIRE(s && x && gy && workspace && gw_oihw, DS_ERR_NULL);
-    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(gy), DS_ERR_ALIGNMENT);
-    WgradPlanB pl;
-    int rc = plan_wgrad_b(pl, s);
+// gw_oihw = out_scale * sum over pixels of gy (x) x: x [B,H,W,Cin] fp16 activations, gy [B,Ho,Wo,Cout] fp16 output
+// gradients in loss-scaled units (out_scale = 1 / S), workspace ds_conv_wgrad_f16_workspace_floats(s) floats.
+extern "C" int ds_conv_wgrad_f16(const ds_conv_shape *s, const void *x_f16, const void *gy_f16, float *workspace,
+                                 float *gw_oihw, float out_scale, void *stream) {
+    DS_REQUIRE(s && x_f16 && gy_f16 && workspace && gw_oihw, DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(x_f16) && DS_ALIGNED16(gy_f16), DS_ERR_ALIGNMENT);
+    WgradPlanH pl;
+    int rc = plan_wgrad_h(pl, s);
     if (rc != DS_OK) return rc;
-    pl.k.x = x; pl.k.gz = gy; pl.k.partial = workspace;
+    pl.k.x = (const _Float16 *)x_f16; pl.k.gz = (const _Float16 *)gy_f16; pl.k.partial = workspace;
     if (s->KS == 3) {
-        if (pl.big)
-            DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<9, 3, WB_GSL3_BIG, WB_XSL3_BIG>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
-        else
-            DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<9, 3, WB_GSL3, WB_XSL3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_f16_kernel<9, 3, WH_GSL3, WH_XSL3>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
     } else {
         // kernel rows 0, s, 2s (15 taps), then the remaining two (10 taps): same tiles, same splits, disjoint taps
-        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<15, 5, 4, 12>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_f16_kernel<15, 5, WH_GSL5, WH_XSL5>), pl.grid, 256, pl.lds_bytes, stream, pl.k);
         rc = ds_last_launch_error();
         if (rc) return rc;
-        WgradKB k2 = pl.k;
+        WgradKH k2 = pl.k;
         k2.k0 = s->stride == 2 ? 1 : 3;
         k2.rows_in = pl.k.RT + 1;
         k2.seg_pix = k2.rows_in * k2.cols_in;
-        DS_LAUNCH_BIG_LDS((wgrad_mfma_bf16_kernel<10, 5, 4, 12>), pl.grid, 256, pl.lds_bytes, stream, k2);
+        DS_LAUNCH_BIG_LDS((wgrad_mfma_f16_kernel<10, 5, WH_GSL5, WH_XSL5>), pl.grid, 256, pl.lds_bytes, stream, k2);
     }
     rc = ds_last_launch_error();
     if (rc) return rc;
     const long long n = (long long)s->KS * s->KS * s->Cout * s->Cin;
     long long g = (n + 255) / 256;
     DS_LAUNCH(wgrad_reduce_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, (const float *)workspace, gw_oihw,
-              pl.k.S, s->KS * s->KS, s->Cout, s->Cin, 0, 1.0f);
+              pl.k.S, s->KS * s->KS, s->Cout, s->Cin, 0, out_scale);
     return ds_last_launch_error();
 }

@@ -200,12 +200,14 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(const WgradK p) {
 // ---- conv1 (Cin = 1): dW[co][kh][kw] = sum_pix dY[pix][co] * x[pix @ tap]; VALU kernel mirroring
 //      conv5x5s2_c1_kernel: 16 lanes per pixel (4 channels each), 100 accumulators per lane ----
 struct Wgrad1K {
-    const float *x, *gz;
+    const float *x;
+    const void *gz;              // f32, or fp16 (GZ16: the fp16 training step's loss-scaled gradient)
     float *partial;
     int H, W, Ho, Wo, tiles_per_img, n_tiles, cols_in;
 };
 constexpr int W1_RT = 4;
 
+template <bool GZ16>
 __global__ void __launch_bounds__(256) wgrad_c1_kernel(const Wgrad1K p) {
     float *lds = ds_dynamic_lds();
     const int tid = threadIdx.x, cg = tid & 15, slot = tid >> 4;
@@ -230,7 +232,10 @@ __global__ void __launch_bounds__(256) wgrad_c1_kernel(const Wgrad1K p) {
         for (int pix = slot; pix < n_pix; pix += 16) {
             const int r = pix / p.Wo, c = pix - r * p.Wo;
             if (r0 + r >= p.Ho) break;
-            const f32x4 g = *(const f32x4 *)(p.gz + (((size_t)b * p.Ho + r0 + r) * p.Wo + c) * 64 + cg * 4);
+            const size_t go = (((size_t)b * p.Ho + r0 + r) * p.Wo + c) * 64 + cg * 4;
+            f32x4 g;
+            if constexpr (GZ16) g = __builtin_convertvector(*(const f16x4 *)((const _Float16 *)p.gz + go), f32x4);
+            else g = *(const f32x4 *)((const float *)p.gz + go);
             const float *in = lds + (2 * r) * p.cols_in + 2 * c;
 #pragma unroll
             for (int kh = 0; kh < 5; ++kh)
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(256) wgrad_c1_kernel(const Wgrad1K p) {
 
 // gw[co][0][tap] = sum_blk partial[blk][tap][co]: 8 lanes share one output (fixed interleave), then a fixed
 // xor-tree over the 8 lanes -- deterministic, and 50 workgroups instead of 7 serial ones
-__global__ void __launch_bounds__(256) wgrad_c1_reduce_kernel(const float *partial, float *gw, int n_blk) {
+__global__ void __launch_bounds__(256) wgrad_c1_reduce_kernel(const float *partial, float *gw, int n_blk, float scale) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 3, r = t & 7;
     float s = 0.f;
@@ -270,7 +275,7 @@ __global__ void __launch_bounds__(256) wgrad_c1_reduce_kernel(const float *parti
     s += ds_shfl_xor(s, 4);
     if (i < 1600 && r == 0) {
         const int tap = i / 64, co = i - tap * 64;
-        gw[co * 25 + tap] = s;
+        gw[co * 25 + tap] = scale == 1.0f ? s : s * scale;
     }
 }
 
@@ -354,29 +359,43 @@ extern "C" long long ds_conv_wgrad_workspace_floats(const ds_conv_shape *s) {
     return rc == DS_OK ? pl.partial_floats : rc;
 }
 
+static int wgrad_c1(const ds_conv_shape *s, const float *x, const void *gy, bool gy_f16, float *workspace, float *gw_oihw,
+                    float out_scale, void *stream) {
+    DS_REQUIRE(s->KS == 5 && s->stride == 2 && s->Cout == 64, DS_ERR_UNSUPPORTED);
+    Wgrad1K k;
+    k.x = x; k.gz = gy; k.partial = workspace;
+    k.H = s->H; k.W = s->W;
+    k.Ho = (s->H - 1) / 2 + 1; k.Wo = (s->W - 1) / 2 + 1;
+    k.tiles_per_img = ds_ceil_div(k.Ho, W1_RT);
+    k.n_tiles = s->B * k.tiles_per_img;
+    k.cols_in = 2 * (k.Wo - 1) + 5;
+    const int grid = k.n_tiles < 1024 ? k.n_tiles : 1024;
+    const size_t lds = ((size_t)(2 * (W1_RT - 1) + 5) * k.cols_in + 4 * 25 * 64) * 4;
+    if (gy_f16) DS_LAUNCH(wgrad_c1_kernel<true>, grid, 256, lds, stream, k);
+    else DS_LAUNCH(wgrad_c1_kernel<false>, grid, 256, lds, stream, k);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    DS_LAUNCH(wgrad_c1_reduce_kernel, 50, 256, 0, stream, (const float *)workspace, gw_oihw, grid, out_scale);
+    return ds_last_launch_error();
+}
+
+// conv1's filter gradient (Cin = 1: f32 network input x [B,H,W]) from an fp16 output gradient in loss-scaled units;
+// workspace: ds_conv_wgrad_workspace_floats(s) floats
+extern "C" int ds_conv_wgrad_c1_f16(const ds_conv_shape *s, const float *x, const void *gy_f16, float *workspace,
+                                    float *gw_oihw, float out_scale, void *stream) {
+    DS_REQUIRE(s && x && gy_f16 && workspace && gw_oihw, DS_ERR_NULL);
+    DS_REQUIRE(s->Cin == 1, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(gy_f16), DS_ERR_ALIGNMENT);
+    return wgrad_c1(s, x, gy_f16, true, workspace, gw_oihw, out_scale, stream);
+}
+
 // fc_F > 0: `s` describes the fc layer as a 1x1 convolution over [1,B,1,K] and the gradient is written
 // in the reference's [N, C*F] order (C = Cin / fc_F).
 extern "C" int ds_conv_wgrad_f32(const ds_conv_shape *s, const float *x, const float *gy, float *workspace,
                                  float *gw_oihw, int fc_F, void *stream) {
     DS_REQUIRE(s && x && gy && workspace && gw_oihw, DS_ERR_NULL);
     DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(gy), DS_ERR_ALIGNMENT);
-    if (s->Cin == 1) {                                    // conv1
-        DS_REQUIRE(s->KS == 5 && s->stride == 2 && s->Cout == 64, DS_ERR_UNSUPPORTED);
-        Wgrad1K k;
-        k.x = x; k.gz = gy; k.partial = workspace;
-        k.H = s->H; k.W = s->W;
-        k.Ho = (s->H - 1) / 2 + 1; k.Wo = (s->W - 1) / 2 + 1;
-        k.tiles_per_img = ds_ceil_div(k.Ho, W1_RT);
-        k.n_tiles = s->B * k.tiles_per_img;
-        k.cols_in = 2 * (k.Wo - 1) + 5;
-        const int grid = k.n_tiles < 1024 ? k.n_tiles : 1024;
-        const size_t lds = ((size_t)(2 * (W1_RT - 1) + 5) * k.cols_in + 4 * 25 * 64) * 4;
-        DS_LAUNCH(wgrad_c1_kernel, grid, 256, lds, stream, k);
-        int rc = ds_last_launch_error();
-        if (rc) return rc;
-        DS_LAUNCH(wgrad_c1_reduce_kernel, 50, 256, 0, stream, (const float *)workspace, gw_oihw, grid);
-        return ds_last_launch_error();
-    }
+    if (s->Cin == 1) return wgrad_c1(s, x, gy, false, workspace, gw_oihw, 1.0f, stream);      // conv1
     WgradPlan pl;
     int rc = plan_wgrad(pl, s);
     if (rc != DS_OK) return rc;
@@ -390,6 +409,6 @@ extern "C" int ds_conv_wgrad_f32(const ds_conv_shape *s, const float *x, const f
     const long long n = (long long)s->KS * s->KS * s->Cout * s->Cin;
     long long g = (n + 255) / 256;
     DS_LAUNCH(wgrad_reduce_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, (const float *)workspace, gw_oihw,
-              pl.k.S, s->KS * s->KS, s->Cout, s->Cin, fc_F);
+              pl.k.S, s->KS * s->KS, s->Cout, s->Cin, fc_F, 1.0f);
     return ds_last_launch_error();
 }

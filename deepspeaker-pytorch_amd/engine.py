@@ -58,6 +58,11 @@ class StageWeights:
     conv_f16: Optional[torch.Tensor] = None
     l_conv1_f16: Optional[torch.Tensor] = None
     l_conv2_f16: Optional[torch.Tensor] = None
+    # ... and the data-gradient banks of the fp16 training step (train_f16.py): flipped 3x3 banks; the 5x5 stride-2 layer's
+    # four parity classes as one 3x3 bank with 4 Cin output channels
+    conv_dgrad_f16: Optional[torch.Tensor] = None
+    l_conv1_dgrad_f16: Optional[torch.Tensor] = None
+    l_conv2_dgrad_f16: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -122,14 +127,21 @@ class Engine:
         self.lib.call("ds_pack_conv_weight_f16", self._p(w), self._p(out), w.shape[0], w.shape[1], ks, self._stream(w))
         return out
 
+    def _pack_f16_dgrad(self, w: torch.Tensor, ks: int, stride: int):
+        n = w.shape[0] * w.shape[1] * (36 if stride == 2 else ks * ks)
+        out = torch.empty(n, dtype=torch.float16, device=w.device)
+        self.lib.call("ds_pack_conv_weight_dgrad_f16", self._p(w), self._p(out), w.shape[0], w.shape[1], ks, stride,
+                      self._stream(w))
+        return out
+
     def pack_weights(self, sd: Dict[str, torch.Tensor], n_stages: int = 4,
                      with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False,
-                     f32_banks: bool = True) -> PackedWeights:
+                     f32_banks: bool = True, with_f16_dgrad: bool = False) -> PackedWeights:
         """OIHW / [out,in] parameters (reference shapes) -> kernel layouts.  `f32_banks=False`
         (with_bf16): the f32 banks of the 3x3 / 5x5 layers are not built -- a bf16x3 training step re-packs every
         filter after every optimizer step and never reads them (21 launches per step)."""
-        if not f32_banks and not with_bf16:
-            raise ValueError("f32_banks=False needs with_bf16=True")
+        if not f32_banks and not (with_bf16 or (with_f16 and with_f16_dgrad)):
+            raise ValueError("f32_banks=False needs with_bf16=True (or the fp16 training banks)")
         lib = self.lib
         stages = []
         for s in range(n_stages):
@@ -158,6 +170,11 @@ class Engine:
                     sw.conv_f16 = self._pack_f16(w, 5)
                 sw.l_conv1_f16 = self._pack_f16(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3)
                 sw.l_conv2_f16 = self._pack_f16(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3)
+                if with_f16_dgrad:
+                    if i > 1:
+                        sw.conv_dgrad_f16 = self._pack_f16_dgrad(w, 5, 2)
+                    sw.l_conv1_dgrad_f16 = self._pack_f16_dgrad(sd[f"model.layer{i}.0.conv1.weight"].detach(), 3, 1)
+                    sw.l_conv2_dgrad_f16 = self._pack_f16_dgrad(sd[f"model.layer{i}.0.conv2.weight"].detach(), 3, 1)
             if with_bf16:
                 if i > 1:
                     sw.conv_bf16 = self._pack_bf16(w, 5)

@@ -329,9 +329,14 @@ class _ResCNNTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
         eng = get_engine()
-        prec = "bf16x3" if model.precision in ("bf16x3", "f16") else "f32"
-        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
-        e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer, precision=prec)
+        prec = model._train_arith()
+        if prec == "f16":
+            from .train_f16 import forward_train_group_f16
+            pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
+            (e,), saved = forward_train_group_f16(eng, [x], pw, model._bn_params(), save=True)
+        else:
+            pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
+            e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer, precision=prec)
         ctx.precision = prec
         model._bump_batches_tracked(1)        # nn.BatchNorm2d.train() bookkeeping, one launch
         model._stat_updates += 1
@@ -345,9 +350,14 @@ class _ResCNNTrainFn(torch.autograd.Function):
     def backward(ctx, ge):
         from .backward import backward_train
         bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
-        grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
-                               reducer=ctx.model._reducer, precision=ctx.precision,
-                               reduce_gradients=ctx.model._reducer is not None)
+        if ctx.precision == "f16":
+            from .train_f16 import backward_train_f16
+            grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
+                                       loss_scale=ctx.model.loss_scale)
+        else:
+            grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
+                                   reducer=ctx.model._reducer, precision=ctx.precision,
+                                   reduce_gradients=ctx.model._reducer is not None)
         ctx.saved_forward = None
         return (None, None) + tuple(grads.get(n) for n in ctx.param_names)
 
@@ -359,10 +369,15 @@ class _ResCNNTripletFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xa, xp, xn, model, *params):
         eng = get_engine()
-        prec = "bf16x3" if model.precision in ("bf16x3", "f16") else "f32"
-        pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
-        embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
-                                              precision=prec)
+        prec = model._train_arith()
+        if prec == "f16":
+            from .train_f16 import forward_train_group_f16
+            pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
+            embs, saved = forward_train_group_f16(eng, [xa, xp, xn], pw, model._bn_params(), save=True)
+        else:
+            pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
+            embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
+                                                  precision=prec)
         model._bump_batches_tracked(3)        # nn.BatchNorm2d.train() bookkeeping, one launch
         model._stat_updates += 3
         ctx.precision, ctx.saved_forward, ctx.model, ctx.pw = prec, saved, model, pw
@@ -375,8 +390,12 @@ class _ResCNNTripletFn(torch.autograd.Function):
         ref = next(g for g in (ga, gp, gn) if g is not None)
         ge = torch.cat([g if g is not None else torch.zeros_like(ref) for g in (ga, gp, gn)]).contiguous().float()
         bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
-        grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, reducer=ctx.model._reducer,
-                               precision=ctx.precision, reduce_gradients=ctx.model._reducer is not None)
+        if ctx.precision == "f16":
+            from .train_f16 import backward_train_f16
+            grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, loss_scale=ctx.model.loss_scale)
+        else:
+            grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, reducer=ctx.model._reducer,
+                                   precision=ctx.precision, reduce_gradients=ctx.model._reducer is not None)
         ctx.saved_forward = None
         return (None, None, None, None) + tuple(grads.get(n) for n in ctx.param_names)
 
@@ -423,8 +442,15 @@ class DeepSpeakerModel(nn.Module):
     """
 
     def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4, precision: str = "f32",
-                 low_latency: bool = False):
+                 low_latency: bool = False, train_precision: Optional[str] = None, loss_scale: float = 1024.0):
         super().__init__()
+        # arithmetic of TRAINING steps: None = the f32-class default ("bf16x3" when `precision` is a 16-bit one, else
+        # "f32"); "f16" = the opt-in fp16 step (train_f16.py: fp16 activations and loss-scaled fp16 gradients in HBM, one
+        # fp16 MFMA per product; embeddings / loss within 1e-3, gradients within 3e-3 of the masked oracle)
+        if train_precision not in (None, "f32", "bf16x3", "f16"):
+            raise ValueError(f"unknown train_precision {train_precision!r}; expected None, 'f32', 'bf16x3' or 'f16'")
+        self.train_precision = train_precision
+        self.loss_scale = float(loss_scale)
         # serving: eval forwards of a few utterances (fp16 path) split each layer's contraction over several
         # workgroups instead of letting a handful of workgroups walk it alone (results then depend on the batch
         # size in the last bits: the f32 summation order changes)
@@ -501,19 +527,29 @@ class DeepSpeakerModel(nn.Module):
         sd["model.fc.bias"] = self.model.fc.bias
         return sd
 
-    def _packed(self, with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False, f32_banks: bool = True):
+    def _train_arith(self) -> str:
+        """arithmetic of the next training step (see `train_precision`); data parallelism runs the f32-class step"""
+        tp = self.train_precision
+        if tp == "f16" and self._reducer is not None and self._reducer.active:
+            tp = None
+        if tp is None:
+            return "bf16x3" if self.precision in ("bf16x3", "f16") else "f32"
+        return tp
+
+    def _packed(self, with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False, f32_banks: bool = True,
+                with_f16_dgrad: bool = False):
         """Kernel-layout copies of the filters for one set of consumers; one copy per variant is kept until a
         parameter changes (version counters), so alternating precisions do not re-pack."""
         sd = self._conv_fc_tensors()
         key = tuple((t.data_ptr(), t._version) for t in sd.values())
         if self._pack_key != key:
             self._pack_cache, self._pack_key = {}, key
-        variant = (with_dgrad, with_bf16, with_f16, f32_banks)
+        variant = (with_dgrad, with_bf16, with_f16, f32_banks, with_f16_dgrad)
         pw = self._pack_cache.get(variant)
         if pw is None:
             pw = self._pack_cache[variant] = get_engine().pack_weights(sd, self.n_stages, with_dgrad=with_dgrad,
                                                                        with_bf16=with_bf16, with_f16=with_f16,
-                                                                       f32_banks=f32_banks)
+                                                                       f32_banks=f32_banks, with_f16_dgrad=with_f16_dgrad)
             pw.owner = id(self)         # lets the engine's plan cache drop this model's older generations
         return pw
 

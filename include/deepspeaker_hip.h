@@ -414,6 +414,46 @@ int ds_group_mean_f32(const float *x, float *out, int n_groups, int G, void *str
 int ds_roc_sweep_f32(const float *dist, const int *issame, int N, float thr0, float dthr, int n_thr,
                      int n_same, int n_diff, int *tp, int *fp, float *summary6, void *stream);
 
+/* ---- OPT-IN fp16 training step (round 4; DeepSpeakerModel(train_precision="f16")): the triplet-regime step of
+ *      train_triplet.py:215-224 with every activation, pre-activation and gradient tensor fp16 in HBM, the convolutions
+ *      (forward AND data gradients) on ds_conv_fwd_f16 -- one fp16 MFMA per product, f32 accumulate -- and f32
+ *      statistics / parameter gradients.  Gradient tensors hold S * g for a constant loss scale S (a power of two);
+ *      what leaves in f32 (dgamma, dbeta, filter gradients) is un-scaled by `inv_scale` / `out_scale` = 1 / S.
+ *      Tolerances (tests/test_gpu_train_f16.py): train-mode embeddings and loss within 1e-3 of the reference's recorded
+ *      step, gradients within 3e-3 of the masked oracle (the reference's own fp32 run is 4e-3 from its fp64 run). ---- */
+/* data-gradient filter banks for ds_conv_fwd_f16.  stride 1: Cout*Cin*KS*KS halfs, [Cout/16][tap][Cin][16] with taps
+ * flipped -- run with shape {B, Ho, Wo, Cin' = Cout, Cout' = Cin, KS, 1} over dL/d(conv output).  stride 2 (KS = 5):
+ * 36*Cout*Cin halfs, [Cout/16][9][4 Cin][16] -- the four parity classes of dX as the output-channel blocks of ONE 3x3
+ * stride-1 convolution {B, Ho, Wo, Cout, 4 Cin, 3, 1}; its output [B][Ho][Wo][2][2][Cin] is read in place by
+ * ds_bn_bwd_group_f16(g1_parity = 1). */
+int ds_pack_conv_weight_dgrad_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, int stride, void *stream);
+/* train-mode BatchNorm statistics of G members (rows [m*n_pix, (m+1)*n_pix) of z) -> [G][C] tables; running statistics
+ * updated member after member (the reference's three forward calls); partial: G * ds_bn_bwd_partial_rows(n_pix, C) * C * 2
+ * floats of scratch.  Replaces nn.BatchNorm2d.train() forward bookkeeping (model.py:59,62,94,99,103,107). */
+int ds_bn_stats_group_f16(const void *z_f16, float *partial, long long n_pix, const float *gamma, const float *beta,
+                          float eps, float momentum, float *running_mean, float *running_var, float *mean_t,
+                          float *invstd_t, float *scale_t, float *shift_t, int C, int G, void *stream);
+/* y = clip(z * scale[m] + shift[m] (+ residual)); flags: DS_EPI_RESIDUAL | DS_EPI_CLIP | DS_EPI_OUT_F32 (y f32: the last
+ * stage, whose consumer is the f32 pooling / projection tail).  model.py:70-71,74-80,188-189 in train mode. */
+int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, const float *shift_t, const void *res_f16, void *y,
+                          long long n_pix, int C, int G, int flags, void *stream);
+/* backward of BatchNorm(train) + clipped ReLU for G members: gy = (g1 [+ g2]) * [0 < act < 20] (act fp16, or f32 with
+ * act_is_f32; NULL: no mask), gz = dL/d(conv output); ggamma / gbeta [C] summed over the members and un-scaled.
+ * partial as above; coef [G][3 C] scratch.  H, W: the layer's map (used when g1_parity). */
+int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32, const void *z,
+                        const float *mean_t, const float *invstd_t, const float *gamma, void *gy, float *partial,
+                        float *coef, float *ggamma, float *gbeta, void *gz, long long n_pix, int H, int W, int C, int G,
+                        float inv_scale, void *stream);
+int ds_scale_cast_f32_to_f16(const float *x, void *y_f16, long long n, float scale, void *stream);
+/* filter gradients from fp16 activations x and fp16 loss-scaled output gradients gy (cuDNN wgrad under
+ * loss.backward(), train_triplet.py:223): 3x3 / 5x5, stride 1 / 2, Cin and Cout multiples of 64. */
+long long ds_conv_wgrad_f16_workspace_floats(const ds_conv_shape *s);
+int ds_conv_wgrad_f16(const ds_conv_shape *s, const void *x_f16, const void *gy_f16, float *workspace, float *gw_oihw,
+                      float out_scale, void *stream);
+/* conv1 (Cin = 1): f32 network input, fp16 output gradient; workspace ds_conv_wgrad_workspace_floats(s) floats */
+int ds_conv_wgrad_c1_f16(const ds_conv_shape *s, const float *x, const void *gy_f16, float *workspace, float *gw_oihw,
+                         float out_scale, void *stream);
+
 /* ---- batch assembly on the device: out[b, t, :] = features[row_start[b] + t, :]
  *      for t < T, zero past row_end[b]; features = the corpus' [frames, F] fbank matrices concatenated
  *      and resident in HBM.  Replaces the host-side np.load + crop + transpose + H2D of
