@@ -186,6 +186,10 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (train-mode forward of the 768 utterances, triplet loss, "
                          "backward, gradient all-reduce, fused Adagrad): the step with collectives on its critical path")
+    ap.add_argument("--train-precision", default="bf16x3", choices=["f32", "bf16x3", "f16"],
+                    help="--train: arithmetic of the training step: the f32-class default (split-operand bf16, gradients 1e-4 "
+                         "from the masked oracle), exact f32, or the OPT-IN fp16 step (fp16 activations and loss-scaled "
+                         "gradients in HBM, one fp16 MFMA per product; embeddings / loss 1e-3, gradients 3e-3)")
     ap.add_argument("--grad-comm", default=None, choices=["shared", "separate"],
                     help="--train: gradient buckets on the BatchNorm collectives' communicator, exchanged after the backward "
                          "pass (default; one program-ordered collective sequence per rank), or on a communicator of their "
@@ -256,8 +260,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def load_model(precision):
-        model = DeepSpeakerModel(512, 1211, precision=precision)
+    def load_model(precision, train_precision=None):
+        model = DeepSpeakerModel(512, 1211, precision=precision, train_precision=train_precision)
         model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
         return model.to(dev)
 
@@ -412,7 +416,8 @@ def main():
         (three BatchNorm statistic sets, as the reference), triplet loss, backward (gradient all-reduce inside),
         fused Adagrad (lr 0.1, lr_decay 1e-4: train_triplet.py:369-383)."""
         from deepspeaker_pytorch_amd.optim import create_optimizer
-        model = load_model(precision).train()
+        # precision "f16": the opt-in fp16 step (fp16 activations / loss-scaled gradients in HBM, train_f16.py)
+        model = (load_model("f16", "f16") if precision == "f16" else load_model(precision)).train()
         red = model.enable_data_parallel(force=args.force_collectives, grad_comm=args.grad_comm,
                                          grad_reduce=args.grad_reduce) if multi else None
         opt = create_optimizer(model, 0.1, "adagrad", lr_decay=1e-4)
@@ -493,7 +498,9 @@ def main():
 
     emb_per_step = 3 * BATCH_TRIPLETS * world
     if args.train:
-        tprec = "bf16x3" if args.precision in ("bf16x3", "f16") else "f32"
+        tprec = args.train_precision
+        if tprec == "f16" and multi:
+            tprec = "bf16x3"            # the fp16 step is single-process; data parallelism runs the f32-class step
         elapsed, prof, again, ar_per_step = measure_train(tprec, args.steps, args.warmup, args.repeats)
         if rank == 0:
             line = {
@@ -530,6 +537,7 @@ def main():
                 secondary[prec] = (e2, p2, k2)
         kt = max(3, args.steps // 4)
         et, _, _, _ = measure_train("bf16x3", kt, 2)
+        et16, _, _, _ = measure_train("f16", kt, 2)
         # BASELINE configs[4]: variable-length inference (100-800 frames) + enrolment scoring, same arithmetic
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import varlen_bench
@@ -579,6 +587,14 @@ def main():
                                  "frac_of_bf16_peak": round(emb_per_step * kt / et * 3 * FWD_FLOPS_PER_EMB / 1e12 / 2500.0, 4),
                                  "what": "train-mode forward of a/p/n (three BatchNorm statistic sets) + triplet loss + "
                                          "backward + fused Adagrad (train_triplet.py:215-224); ~3x the forward FLOPs"}
+            out["train_step_f16"] = {"value": round(emb_per_step * kt / et16, 1), "unit": "utterances/s", "steps": kt,
+                                     "ms_per_step": round(et16 / kt * 1e3, 3), "dtype": "f16",
+                                     "algorithmic_tflops": round(emb_per_step * kt / et16 * 3 * FWD_FLOPS_PER_EMB / 1e12, 1),
+                                     "frac_of_f16_peak": round(emb_per_step * kt / et16 * 3 * FWD_FLOPS_PER_EMB / 1e12 / 2500.0, 4),
+                                     "what": "the same step in the OPT-IN fp16 mode (DeepSpeakerModel(train_precision='f16')): fp16 "
+                                             "activations and loss-scaled gradients in HBM, forward and data-gradient convolutions "
+                                             "on the fp16 matrix-core kernels; stated tolerance: embeddings / loss 1e-3, gradients "
+                                             "3e-3 vs the masked oracle (tests/test_gpu_train_f16.py)"}
             out["varlen"] = varlen
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_np)
