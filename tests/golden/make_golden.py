@@ -407,39 +407,57 @@ def make_trajectory():
     sys.path.insert(0, "/root/reference")
     import eval_metrics as ref_eval
     sd = O.make_state_dict(seed=TRAJ["param_seed"], num_classes=TRAJ["speakers"], randomize_bn=False)
-    m = build_ref(sd, TRAJ["speakers"]).train()
-    opt = torch.optim.SGD(m.parameters(), lr=TRAJ["lr"])
-    losses = []
     x_test, ii, jj, same = trajectory_test_set()
 
-    def eer_now():
-        m.eval()
-        with torch.no_grad():
-            e = m(torch.from_numpy(x_test))
-            d = ref.PairwiseDistance(2).forward(e[ii], e[jj]).numpy()
-        m.train()
-        thr = np.arange(0, 30, 0.01)
-        tp, fp = O.roc_sweep(d, same.astype(np.float64), thr)[:2]
-        return e.numpy(), d, O.equal_error_rate(tp, fp, same.sum(), (~same).sum())
+    def run(dtype, threads):
+        """the 30-step loop + test-time scoring; returns (losses, test embeddings, distances, EER before, EER after, model)"""
+        torch.set_num_threads(threads)
+        m = build_ref(sd, TRAJ["speakers"]).train().to(dtype)
+        opt = torch.optim.SGD(m.parameters(), lr=TRAJ["lr"])
 
-    _, _, eer0 = eer_now()
-    for it in range(TRAJ["steps"]):
-        xs = [torch.from_numpy(v) for v in trajectory_batches(it)]
-        oa, op, on = m(xs[0]), m(xs[1]), m(xs[2])                           # train_triplet.py:215
-        loss = ref.TripletMarginLoss(TRAJ["margin"]).forward(oa, op, on)   # :219
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        losses.append(float(loss))
-    e, d, eer = eer_now()
+        def eer_now():
+            m.eval()
+            with torch.no_grad():
+                e = m(torch.from_numpy(x_test).to(dtype))
+                d = ref.PairwiseDistance(2).forward(e[ii], e[jj]).float().numpy()
+            m.train()
+            tp, fp = O.roc_sweep(d, same.astype(np.float64), np.arange(0, 30, 0.01))[:2]
+            return e.float().numpy(), d, O.equal_error_rate(tp, fp, same.sum(), (~same).sum())
+
+        _, _, eer0 = eer_now()
+        losses = []
+        for it in range(TRAJ["steps"]):
+            xs = [torch.from_numpy(v).to(dtype) for v in trajectory_batches(it)]
+            oa, op, on = m(xs[0]), m(xs[1]), m(xs[2])                           # train_triplet.py:215
+            loss = ref.TripletMarginLoss(TRAJ["margin"]).forward(oa, op, on)   # :219
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        e, d, eer = eer_now()
+        return np.array(losses, np.float64), e, d, eer0, eer, m
+
+    losses, e, d, eer0, eer, m = run(torch.float32, 8)
+    # The loop is CHAOTIC: a hinge or clip mask that rounds the other way changes which triplets / elements carry gradient,
+    # and SGD amplifies the difference step after step.  How far the reference is from ITSELF under perturbations of the
+    # last bit -- another thread count (another summation order inside ATen / oneDNN), float64 -- is recorded next to the
+    # trajectory: it is the yardstick for any other implementation of the same arithmetic.
+    losses_alt, _, _, _, eer_alt, _ = run(torch.float32, 3)
+    losses64, _, _, _, eer64, _ = run(torch.float64, 8)
+    torch.set_num_threads(8)
     tpr, fpr, acc = ref_eval.calculate_roc(np.arange(0, 30, 0.01), d, same.astype(np.float64))
-    out = {"traj_loss": np.array(losses, np.float64), "traj_test_emb": e, "traj_test_dist": d,
+    out = {"traj_loss": losses, "traj_loss_alt_threads": losses_alt, "traj_loss_f64": losses64,
+           "traj_test_emb": e, "traj_test_dist": d,
            "traj_test_same": same, "traj_eer": np.array(eer), "traj_eer_before": np.array(eer0),
+           "traj_eer_alt_threads": np.array(eer_alt), "traj_eer_f64": np.array(eer64),
            "traj_roc_tpr_fpr_acc": np.array([tpr, fpr, acc], np.float64),
            "traj_final_running_mean_bn1": m.state_dict()["model.bn1.running_mean"].numpy(),
            "traj_final_fc_bias": m.state_dict()["model.fc.bias"].numpy()}
     print("trajectory losses:", " ".join(f"{v:.4f}" for v in losses))
-    print(f"mean of first 10 {np.mean(losses[:10]):.4f}, last 10 {np.mean(losses[-10:]):.4f}; EER {eer0:.4f} -> {eer:.4f}")
+    print("  3 threads, rel:  ", " ".join(f"{abs(a - b) / max(b, 5e-3):.1e}" for a, b in zip(losses_alt, losses)))
+    print("  float64, rel:    ", " ".join(f"{abs(a - b) / max(b, 5e-3):.1e}" for a, b in zip(losses64, losses)))
+    print(f"mean of first 10 {np.mean(losses[:10]):.4f}, last 10 {np.mean(losses[-10:]):.4f}; EER {eer0:.4f} -> {eer:.4f} "
+          f"(3 threads {eer_alt:.4f}, float64 {eer64:.4f})")
     path = os.path.join(HERE, "reference_trajectory.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -22,6 +22,8 @@ for w in $WHAT; do
           python tools/rocpd_stats.py $(find $OUT/prof -name "*.db") > $OUT/kernel_stats.md 2>$OUT/kernel_stats.err; head -40 $OUT/kernel_stats.md ;;
     trainprof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trainprof -- python $R/bench.py --train --steps 6 --warmup 2 --repeats 0 --no-cpu-baseline > $OUT/trainprof.log 2>&1); echo "trainprof rc=$?"
           python tools/rocpd_stats.py $(find $OUT/trainprof -name "*.db") > $OUT/train_kernel_stats.md 2>$OUT/train_kernel_stats.err; python tools/timeline.py $(find $OUT/trainprof -name "*.db") adagrad | head -12 ;;
+    trainprof16) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trainprof16 -- python $R/bench.py --train --train-precision f16 --steps 6 --warmup 2 --repeats 0 --no-cpu-baseline > $OUT/trainprof16.log 2>&1); echo "trainprof16 rc=$?"
+          python tools/rocpd_stats.py $(find $OUT/trainprof16 -name "*.db") > $OUT/train16_kernel_stats.md 2>$OUT/train16_kernel_stats.err; head -45 $OUT/train16_kernel_stats.md; python tools/timeline.py $(find $OUT/trainprof16 -name "*.db") adagrad | head -12 ;;
     dpprof) (cd /tmp && export TMPDIR=/tmp && MASTER_ADDR=127.0.0.1 MASTER_PORT=29572 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/dpprof -- python $R/bench.py --train --force-collectives --steps 6 --warmup 2 --repeats 0 --no-cpu-baseline > $OUT/dpprof.log 2>&1); echo "dpprof rc=$?"
           python tools/dp_gaps.py $(find $OUT/dpprof -name "*.db") > $OUT/dp_gaps.md 2>$OUT/dp_gaps.err; head -3 $OUT/dp_gaps.md; python tools/timeline.py $(find $OUT/dpprof -name "*.db") adagrad | head -12 ;;
     slots) for c in 4 8 16 32; do timeout 300 python bench.py --no-secondary --no-cpu-baseline --refine-slots $c --repeats 2 > $OUT/slots_$c.json 2> $OUT/slots_$c.err; python -c "import json;d=json.load(open('$OUT/slots_$c.json'));print('slots',$c,d['value'],d['ms_per_step'],d['repeats_ms_per_step'],d['roofline']['achieved'],d['refine'])"; done ;;
