@@ -294,23 +294,28 @@ def main():
         """untimed settle-in steps run BEFORE the W contract warm-ups (reported as `pre_steps` in the line)"""
         return max(0, 30 - warmup)
 
-    def timed(step, steps, warmup, repeats=0):
-        eng.profile = []                        # warm-up with the event instrumentation on: the first
+    def timed(step, steps, warmup, repeats=0, profile=True):
+        # profile: per-launch events around the convolutions of the timed region (the live roofline of the eval line); the
+        # training steps are timed without them (a pair of events per launch is ~70 per fp16 training step -- measured
+        # 12.7 ms per step with them, 9.6 without)
+        def prof_on():
+            eng.profile = [] if profile else None
+        prof_on()                               # warm-up with the event instrumentation on: the first
         for _ in range(pre_steps(warmup)):      # timing events of a process cost ~40 ms to create; and a fresh
             step()                              # box needs ~0.2 s of work before clocks / caches settle (setup,
         fence()                                 # not part of the W contract warm-up steps that follow)
-        eng.profile = []
+        prof_on()
         for _ in range(warmup):
             step()
         for j, st_ in enumerate(streams):       # launch plans / allocator pools of the side streams
             with torch.cuda.stream(st_):
                 step(j)
-        eng.profile = []
+        prof_on()
         elapsed, t_enq = region(step, steps)
         if rank == 0:
             print(f"[bench] host enqueue {t_enq / steps * 1e3:.3f} ms/step, device-complete {elapsed / steps * 1e3:.3f} ms/step",
                   file=sys.stderr)
-        prof, eng.profile = eng.profile, None
+        prof, eng.profile = (eng.profile or []), None
         # the same region again, `repeats` times, without the per-launch events: the spread of the box
         again = [region(step, steps)[0] / steps * 1e3 for _ in range(repeats)]
         if rank == 0 and again:
@@ -437,7 +442,7 @@ def main():
                 red.all_reduce_sum_(loss.detach())
             return loss
 
-        elapsed, prof, again = timed(step, steps, warmup, repeats)
+        elapsed, prof, again = timed(step, steps, warmup, repeats, profile=False)
         per_step = None
         if red is not None:
             red_modes[:] = [red.grad_comm, red.grad_reduce]

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "ds_conv_wgrad_bf16_workspace_floats": (c_longlong, [POINTER(ConvShape)]),
     "ds_conv_wgrad_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P]),
     "ds_pack_conv_weight_dgrad_f16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_bn_f16_partial_rows": (c_int, [c_longlong, c_int]),
     "ds_bn_stats_group_f16": (c_int, [_P, _P, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_bn_apply_group_f16": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P]),
     "ds_bn_bwd_group_f16": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int,

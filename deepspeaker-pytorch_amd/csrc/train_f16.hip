@@ -18,36 +18,33 @@
 namespace {
 
 typedef _Float16 h16;
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ f32x4 ld4(const h16 *p, size_t i4) { return __builtin_convertvector(((const h16x4 *)p)[i4], f32x4); }
-__device__ __forceinline__ void st4(h16 *p, size_t i4, f32x4 v) { ((h16x4 *)p)[i4] = __builtin_convertvector(v, h16x4); }
+// 8 channels (16 bytes of fp16) per thread and access: half the memory instructions of 4-channel accesses for the same
+// bytes in flight (measured on the first build, 4 channels per access: 2.6 - 3.2 TB/s on the stage-1 tensors)
+__device__ __forceinline__ f32x8 ld8(const h16 *p, size_t i8) { return __builtin_convertvector(((const h16x8 *)p)[i8], f32x8); }
+__device__ __forceinline__ void st8(h16 *p, size_t i8, f32x8 v) { ((h16x8 *)p)[i8] = __builtin_convertvector(v, h16x8); }
+__device__ __forceinline__ f32x8 ld8f(const float *p, size_t i8) {
+    const f32x4 a = ((const f32x4 *)p)[2 * i8], b = ((const f32x4 *)p)[2 * i8 + 1];
+    return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ void st8f(float *p, size_t i8, f32x8 v) {
+    ((f32x4 *)p)[2 * i8] = f32x4{v[0], v[1], v[2], v[3]};
+    ((f32x4 *)p)[2 * i8 + 1] = f32x4{v[4], v[5], v[6], v[7]};
+}
 
-constexpr int TF_FOLD_R = 64;           // row lanes of the partial-sum folds below (x 4 channels per workgroup)
+constexpr int TF_FOLD_R = 128, TF_FOLD_C = 2;   // row lanes x channels per workgroup of the partial-sum folds below
+constexpr int TF_MAX_ROWS = 768;                // partial rows per member (x G members: enough workgroups, short folds)
 
-// partial[member][blk][c] = { sum z, sum z^2 } over the block's pixels (f32 sums of fp16 values)
-__global__ void __launch_bounds__(256) bn_stats_f16_kernel(const h16 *z, float *partial, long long n_pix, int C,
-                                                           int pix_per_block, int blocks_per_member) {
-    const int member = blockIdx.x / blocks_per_member, mblock = blockIdx.x - member * blocks_per_member;
-    z += (size_t)member * n_pix * C;
-    float *red = ds_dynamic_lds();                         // [slots][C][2]
-    const int cvec = C >> 2;
-    const int slots = 256 / cvec;
-    const int cg = threadIdx.x % cvec, slot = threadIdx.x / cvec;
-    const long long p0 = (long long)mblock * pix_per_block;
-    long long p1 = p0 + pix_per_block;
-    if (p1 > n_pix) p1 = n_pix;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+// per-block partial sums of two per-channel quantities -> partial[blockIdx.x][c][2]; red: [slots][C][2] floats
+__device__ __forceinline__ void block_fold(float *red, const f32x8 &s1, const f32x8 &s2, int slot, int slots, int cg, int C,
+                                           float *partial) {
     if (slot < slots) {
-        for (long long p = p0 + slot; p < p1; p += slots) {
-            const f32x4 v = ld4(z, (size_t)p * cvec + cg);
-            s1 += v;
-            s2 += v * v;
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            red[((slot * C) + cg * 4 + j) * 2 + 0] = s1[j];
-            red[((slot * C) + cg * 4 + j) * 2 + 1] = s2[j];
+        for (int j = 0; j < 8; ++j) {
+            red[((slot * C) + cg * 8 + j) * 2 + 0] = s1[j];
+            red[((slot * C) + cg * 8 + j) * 2 + 1] = s2[j];
         }
     }
     __syncthreads();
@@ -62,10 +59,32 @@ __global__ void __launch_bounds__(256) bn_stats_f16_kernel(const h16 *z, float *
     }
 }
 
-// fold of one member's partial rows for 4 channels per workgroup, double precision, fixed order
-__device__ __forceinline__ bool fold4(const float *partial, int n_partial, int C, double *red, int c0, int &c, double &t1,
-                                      double &t2) {
-    const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+// partial[member][blk][c] = { sum z, sum z^2 } over the block's pixels (f32 sums of fp16 values)
+__global__ void __launch_bounds__(256) bn_stats_f16_kernel(const h16 *z, float *partial, long long n_pix, int C,
+                                                           int pix_per_block, int blocks_per_member) {
+    const int member = blockIdx.x / blocks_per_member, mblock = blockIdx.x - member * blocks_per_member;
+    z += (size_t)member * n_pix * C;
+    float *red = ds_dynamic_lds();                         // [slots][C][2]
+    const int cvec = C >> 3;
+    const int slots = 256 / cvec;
+    const int cg = threadIdx.x % cvec, slot = threadIdx.x / cvec;
+    const long long p0 = (long long)mblock * pix_per_block;
+    long long p1 = p0 + pix_per_block;
+    if (p1 > n_pix) p1 = n_pix;
+    f32x8 s1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (slot < slots)
+        for (long long p = p0 + slot; p < p1; p += slots) {
+            const f32x8 v = ld8(z, (size_t)p * cvec + cg);
+            s1 += v;
+            s2 += v * v;
+        }
+    block_fold(red, s1, s2, slot, slots, cg, C, partial);
+}
+
+// fold of one member's partial rows for TF_FOLD_C channels per workgroup, double precision, fixed order
+__device__ __forceinline__ bool fold_rows(const float *partial, int n_partial, int C, double *red, int c0, int &c, double &t1,
+                                          double &t2) {
+    const int cl = threadIdx.x % TF_FOLD_C, rl = threadIdx.x / TF_FOLD_C;
     c = c0 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
@@ -75,14 +94,14 @@ __device__ __forceinline__ bool fold4(const float *partial, int n_partial, int C
             s2 += (double)src[1];
         }
     __syncthreads();                                        // (the previous member's fold has been read)
-    red[(rl * 4 + cl) * 2 + 0] = s1;
-    red[(rl * 4 + cl) * 2 + 1] = s2;
+    red[(rl * TF_FOLD_C + cl) * 2 + 0] = s1;
+    red[(rl * TF_FOLD_C + cl) * 2 + 1] = s2;
     __syncthreads();
     if (rl != 0 || c >= C) return false;
     t1 = t2 = 0.0;
     for (int k = 0; k < TF_FOLD_R; ++k) {
-        t1 += red[(k * 4 + cl) * 2 + 0];
-        t2 += red[(k * 4 + cl) * 2 + 1];
+        t1 += red[(k * TF_FOLD_C + cl) * 2 + 0];
+        t2 += red[(k * TF_FOLD_C + cl) * 2 + 1];
     }
     return true;
 }
@@ -95,11 +114,11 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_group_kernel(const floa
                                                                       float momentum, float *running_mean,
                                                                       float *running_var, float *mean_t, float *invstd_t,
                                                                       float *scale_t, float *shift_t, int C, int G) {
-    double *red = (double *)ds_dynamic_lds();              // [TF_FOLD_R][4][2]
+    double *red = (double *)ds_dynamic_lds();              // [TF_FOLD_R][TF_FOLD_C][2]
     for (int m = 0; m < G; ++m) {
         int c;
         double t1, t2;
-        if (fold4(partial + (size_t)m * n_partial * C * 2, n_partial, C, red, (int)blockIdx.x * 4, c, t1, t2)) {
+        if (fold_rows(partial + (size_t)m * n_partial * C * 2, n_partial, C, red, (int)blockIdx.x * TF_FOLD_C, c, t1, t2)) {
             const double mean = t1 / count;
             double var = t2 / count - mean * mean;         // biased (normalisation) variance
             if (var < 0.0) var = 0.0;
@@ -124,41 +143,41 @@ template <bool OUT32>
 __global__ void __launch_bounds__(256) bn_apply_f16_kernel(const h16 *z, const float *scale_t, const float *shift_t,
                                                            const h16 *res, void *y, long long n_vec_member, int G, int C,
                                                            int flags) {
-    const int cvec = C >> 2;
+    const int cvec = C >> 3;
     const long long n_vec = n_vec_member * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
         const int member = (int)(i / n_vec_member);
-        const int c4 = (int)(i % cvec);
-        const f32x4 sc = ((const f32x4 *)(scale_t + (size_t)member * C))[c4], sh = ((const f32x4 *)(shift_t + (size_t)member * C))[c4];
-        f32x4 v = ld4(z, (size_t)i);
+        const int c8 = (int)(i % cvec);
+        const f32x8 sc = ld8f(scale_t + (size_t)member * C, c8), sh = ld8f(shift_t + (size_t)member * C, c8);
+        f32x8 v = ld8(z, (size_t)i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ds_bn_affine(v[j], sc[j], sh[j]);
-        if (flags & DS_EPI_RESIDUAL) v += ld4(res, (size_t)i);
+        for (int j = 0; j < 8; ++j) v[j] = ds_bn_affine(v[j], sc[j], sh[j]);
+        if (flags & DS_EPI_RESIDUAL) v += ld8(res, (size_t)i);
         if (flags & DS_EPI_CLIP) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], 0.0f), 20.0f);
+            for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j], 0.0f), 20.0f);
         }
-        if constexpr (OUT32) ((f32x4 *)y)[i] = v;
-        else st4((h16 *)y, (size_t)i, v);
+        if constexpr (OUT32) st8f((float *)y, (size_t)i, v);
+        else st8((h16 *)y, (size_t)i, v);
     }
 }
 
 // Backward, first half.  gy = (g1 [+ g2]) * [0 < act < 20] (act == nullptr: no mask), written as fp16;
 // partial[member][blk][c] = { sum gy, sum gy * xhat }, xhat = (z - mean) * invstd.
 // PARITY: g1 is the output of the 5x5 stride-2 data gradient run as ONE 3x3 convolution with 4 C output channels
-// (ds_pack_conv_weight_f16 mode 2): [B][Ho2][Wo2][2][2][C] -- pixel (h, w) of this layer's [H][W] map is parity class
-// (h & 1, w & 1) of cell (h >> 1, w >> 1).
+// (ds_pack_conv_weight_dgrad_f16, stride 2): [B][Ho2][Wo2][2][2][C] -- pixel (h, w) of this layer's [H][W] map is parity
+// class (h & 1, w & 1) of cell (h >> 1, w >> 1).
 template <bool PARITY, bool ACT32>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_f16_kernel(const h16 *g1, const h16 *g2, const void *act, const h16 *z,
                                                                 const float *mean, const float *invstd, h16 *gy,
                                                                 float *partial, long long n_pix, int C, int pix_per_block,
                                                                 int blocks_per_member, int H, int W) {
     const int member = blockIdx.x / blocks_per_member, mblock = blockIdx.x - member * blocks_per_member;
-    const size_t moff = (size_t)member * n_pix * C;
+    const size_t moff8 = ((size_t)member * n_pix * C) >> 3;
     mean += (size_t)member * C;
     invstd += (size_t)member * C;
     float *red = ds_dynamic_lds();                         // [slots][C][2]
-    const int cvec = C >> 2;
+    const int cvec = C >> 3;
     const int slots = 256 / cvec;
     const int cg = threadIdx.x % cvec, slot = threadIdx.x / cvec;
     const long long p0 = (long long)mblock * pix_per_block;
@@ -166,53 +185,39 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_f16_kernel(const h16 *g1, c
     if (p1 > n_pix) p1 = n_pix;
     const int Ho2 = (H + 1) >> 1, Wo2 = (W + 1) >> 1;
     const long long img_pix = (long long)H * W;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x8 s1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (slot < slots) {
-        const f32x4 mu = ((const f32x4 *)mean)[cg], is = ((const f32x4 *)invstd)[cg];
+        const f32x8 mu = ld8f(mean, cg), is = ld8f(invstd, cg);
         for (long long p = p0 + slot; p < p1; p += slots) {
-            const size_t i = (moff >> 2) + (size_t)p * cvec + cg;           // float4 index in the [G * n_pix][C] tensors
-            f32x4 g;
+            const size_t i = moff8 + (size_t)p * cvec + cg;                 // 8-channel index in the [G * n_pix][C] tensors
+            f32x8 g;
             if constexpr (PARITY) {
                 const long long gp = (long long)member * n_pix + p;         // pixel index in the whole batch
                 const long long b = gp / img_pix;
                 const int rem = (int)(gp - b * img_pix);
                 const int h = rem / W, w = rem - h * W;
                 const size_t cell = ((size_t)b * Ho2 + (h >> 1)) * Wo2 + (w >> 1);
-                g = ld4(g1, (cell * 4 + (size_t)((h & 1) * 2 + (w & 1))) * cvec + cg);
+                g = ld8(g1, (cell * 4 + (size_t)((h & 1) * 2 + (w & 1))) * cvec + cg);
             } else {
-                g = ld4(g1, i);
+                g = ld8(g1, i);
             }
-            if (g2) g += ld4(g2, i);
+            if (g2) g += ld8(g2, i);
             if (act) {
-                f32x4 a;
-                if constexpr (ACT32) a = ((const f32x4 *)act)[i];
-                else a = ld4((const h16 *)act, i);
+                f32x8 a;
+                if constexpr (ACT32) a = ld8f((const float *)act, i);
+                else a = ld8((const h16 *)act, i);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = (a[j] > 0.0f && a[j] < 20.0f) ? g[j] : 0.0f;
+                for (int j = 0; j < 8; ++j) g[j] = (a[j] > 0.0f && a[j] < 20.0f) ? g[j] : 0.0f;
             }
-            const h16x4 gh = __builtin_convertvector(g, h16x4);
-            ((h16x4 *)gy)[i] = gh;
-            g = __builtin_convertvector(gh, f32x4);                         // the sums are those of the STORED gradient
-            const f32x4 xh = (ld4(z, i) - mu) * is;
+            const h16x8 gh = __builtin_convertvector(g, h16x8);
+            ((h16x8 *)gy)[i] = gh;
+            g = __builtin_convertvector(gh, f32x8);                         // the sums are those of the STORED gradient
+            const f32x8 xh = (ld8(z, i) - mu) * is;
             s1 += g;
             s2 += g * xh;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            red[((slot * C) + cg * 4 + j) * 2 + 0] = s1[j];
-            red[((slot * C) + cg * 4 + j) * 2 + 1] = s2[j];
-        }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int s = 0; s < slots; ++s) {
-            a1 += red[(s * C + c) * 2 + 0];
-            a2 += red[(s * C + c) * 2 + 1];
-        }
-        partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a1;
-        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = a2;
-    }
+    block_fold(red, s1, s2, slot, slots, cg, C, partial);
 }
 
 // Backward, fold: per member coef = { gamma * invstd, sum gy / N, sum gy * xhat / N } (in the gradient tensors' scaled
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_f16_kernel(const float *p
     bool mine = false;
     for (int m = 0; m < G; ++m) {
         double t1, t2;
-        if (fold4(partial + (size_t)m * n_partial * C * 2, n_partial, C, red, (int)blockIdx.x * 4, c, t1, t2)) {
+        if (fold_rows(partial + (size_t)m * n_partial * C * 2, n_partial, C, red, (int)blockIdx.x * TF_FOLD_C, c, t1, t2)) {
             mine = true;
             float *cf = coef + (size_t)m * 3 * C;
             cf[c] = gamma[c] * invstd_t[(size_t)m * C + c];
@@ -247,22 +252,22 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_f16_kernel(const float *p
 __global__ void __launch_bounds__(256) bn_bwd_apply_f16_kernel(const h16 *gy, const h16 *z, const float *mean_t,
                                                                const float *invstd_t, const float *coef, h16 *gz,
                                                                long long n_vec_member, int G, int C) {
-    const int cvec = C >> 2;
+    const int cvec = C >> 3;
     const long long n_vec = n_vec_member * G;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
         const int member = (int)(i / n_vec_member);
-        const int c4 = (int)(i % cvec);
+        const int c8 = (int)(i % cvec);
         const float *cf = coef + (size_t)member * 3 * C;
-        const f32x4 mu = ((const f32x4 *)(mean_t + (size_t)member * C))[c4], is = ((const f32x4 *)(invstd_t + (size_t)member * C))[c4];
-        const f32x4 k1 = ((const f32x4 *)cf)[c4], k2 = ((const f32x4 *)(cf + C))[c4], k3 = ((const f32x4 *)(cf + 2 * C))[c4];
-        const f32x4 xh = (ld4(z, (size_t)i) - mu) * is;
-        st4(gz, (size_t)i, k1 * (ld4(gy, (size_t)i) - k2 - xh * k3));
+        const f32x8 mu = ld8f(mean_t + (size_t)member * C, c8), is = ld8f(invstd_t + (size_t)member * C, c8);
+        const f32x8 k1 = ld8f(cf, c8), k2 = ld8f(cf + C, c8), k3 = ld8f(cf + 2 * C, c8);
+        const f32x8 xh = (ld8(z, (size_t)i) - mu) * is;
+        st8(gz, (size_t)i, k1 * (ld8(gy, (size_t)i) - k2 - xh * k3));
     }
 }
 
 __global__ void __launch_bounds__(256) scale_cast_f16_kernel(const float *x, h16 *y, long long n_vec, float scale) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256)
-        st4(y, (size_t)i, ((const f32x4 *)x)[i] * scale);
+        st8(y, (size_t)i, ld8f(x, (size_t)i) * scale);
 }
 
 static int tf_grid(long long n) {
@@ -271,15 +276,28 @@ static int tf_grid(long long n) {
 }
 
 static bool tf_shape_ok(long long n_pix, int C, int G) {
-    return n_pix > 0 && G > 0 && G <= 64 && C >= 4 && (C % 4) == 0 && C <= 1024 && 256 % (C / 4) == 0;
+    return n_pix > 0 && G > 0 && G <= 64 && C >= 8 && (C % 8) == 0 && C <= 1024 && 256 % (C / 8) == 0;
+}
+
+// partial rows (= workgroups) per member of the reductions: ~8 pixel steps per thread, at most TF_MAX_ROWS
+static int tf_rows(long long n_pix, int C) {
+    long long ppb = 16384 / C;
+    if (ppb < 8) ppb = 8;
+    long long blocks = (n_pix + ppb - 1) / ppb;
+    if (blocks > TF_MAX_ROWS) blocks = TF_MAX_ROWS;
+    return (int)blocks;
 }
 
 }  // namespace
 
-extern "C" int ds_bn_bwd_partial_rows(long long n_pix, int C);
+// partial rows per member that ds_bn_stats_group_f16 / ds_bn_bwd_group_f16 write (sizes their `partial` scratch)
+extern "C" int ds_bn_f16_partial_rows(long long n_pix, int C) {
+    if (n_pix <= 0 || C <= 0) return DS_ERR_BAD_SHAPE;
+    return tf_rows(n_pix, C);
+}
 
 // Train-mode BatchNorm statistics of G members over an fp16 pre-activation z [G * n_pix][C]: partial sums (rows =
-// ds_bn_bwd_partial_rows(n_pix, C) per member), then tables [G][C] of mean / invstd / scale / shift and the running
+// ds_bn_f16_partial_rows(n_pix, C) per member), then tables [G][C] of mean / invstd / scale / shift and the running
 // statistics updated member after member (call order).  `partial`: G * rows * C * 2 floats of scratch.
 extern "C" int ds_bn_stats_group_f16(const void *z_f16, float *partial, long long n_pix, const float *gamma,
                                      const float *beta, float eps, float momentum, float *running_mean,
@@ -289,14 +307,14 @@ extern "C" int ds_bn_stats_group_f16(const void *z_f16, float *partial, long lon
     DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
     DS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DS_ERR_NULL);
     DS_REQUIRE(DS_ALIGNED16(z_f16), DS_ERR_ALIGNMENT);
-    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
+    const int blocks = tf_rows(n_pix, C);
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
-    const int slots = 256 / (C / 4);
+    const int slots = 256 / (C / 8);
     DS_LAUNCH(bn_stats_f16_kernel, blocks * G, 256, (size_t)slots * C * 2 * 4, stream, (const h16 *)z_f16, partial, n_pix, C,
               ppb, blocks);
     int rc = ds_last_launch_error();
     if (rc) return rc;
-    DS_LAUNCH(bn_stats_finalize_group_kernel, ds_ceil_div(C, 4), 256, TF_FOLD_R * 4 * 2 * sizeof(double), stream,
+    DS_LAUNCH(bn_stats_finalize_group_kernel, ds_ceil_div(C, TF_FOLD_C), 256, TF_FOLD_R * TF_FOLD_C * 2 * sizeof(double), stream,
               (const float *)partial, blocks, (double)n_pix, gamma, beta, eps, momentum, running_mean, running_var, mean_t,
               invstd_t, scale_t, shift_t, C, G);
     return ds_last_launch_error();
@@ -311,7 +329,7 @@ extern "C" int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, co
     DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(z_f16) && DS_ALIGNED16(y) && DS_ALIGNED16(res_f16) && DS_ALIGNED16(scale_t) && DS_ALIGNED16(shift_t),
                DS_ERR_ALIGNMENT);
-    const long long nvm = n_pix * (C / 4);
+    const long long nvm = n_pix * (C / 8);
     if (flags & DS_EPI_OUT_F32)
         DS_LAUNCH(bn_apply_f16_kernel<true>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)z_f16, scale_t, shift_t,
                   (const h16 *)res_f16, y, nvm, G, C, flags);
@@ -335,9 +353,9 @@ extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2
     DS_REQUIRE(!g1_parity || (H > 0 && W > 0 && (n_pix * G) % ((long long)H * W) == 0), DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(g2) && DS_ALIGNED16(act) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) &&
                    DS_ALIGNED16(gz) && DS_ALIGNED16(mean_t) && DS_ALIGNED16(invstd_t) && DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
-    const int blocks = ds_bn_bwd_partial_rows(n_pix, C);
+    const int blocks = tf_rows(n_pix, C);
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
-    const int slots = 256 / (C / 4);
+    const int slots = 256 / (C / 8);
     const size_t lds = (size_t)slots * C * 2 * 4;
 #define TF_REDUCE(P, A)                                                                                                    \
     DS_LAUNCH((bn_bwd_reduce_f16_kernel<P, A>), blocks * G, 256, lds, stream, (const h16 *)g1, (const h16 *)g2, act,        \
@@ -347,11 +365,11 @@ extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2
 #undef TF_REDUCE
     int rc = ds_last_launch_error();
     if (rc) return rc;
-    DS_LAUNCH(bn_bwd_finalize_f16_kernel, ds_ceil_div(C, 4), 256, TF_FOLD_R * 4 * 2 * sizeof(double), stream,
+    DS_LAUNCH(bn_bwd_finalize_f16_kernel, ds_ceil_div(C, TF_FOLD_C), 256, TF_FOLD_R * TF_FOLD_C * 2 * sizeof(double), stream,
               (const float *)partial, blocks, (double)n_pix, gamma, invstd_t, coef, ggamma, gbeta, C, G, inv_scale);
     rc = ds_last_launch_error();
     if (rc) return rc;
-    const long long nvm = n_pix * (C / 4);
+    const long long nvm = n_pix * (C / 8);
     DS_LAUNCH(bn_bwd_apply_f16_kernel, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy, (const h16 *)z, mean_t, invstd_t,
               (const float *)coef, (h16 *)gz, nvm, G, C);
     return ds_last_launch_error();
@@ -360,8 +378,8 @@ extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2
 // y_f16 = fp16(x * scale): how an f32 gradient enters the fp16 backward pass (scale = the loss scale S)
 extern "C" int ds_scale_cast_f32_to_f16(const float *x, void *y_f16, long long n, float scale, void *stream) {
     DS_REQUIRE(x && y_f16, DS_ERR_NULL);
-    DS_REQUIRE(n > 0 && (n % 4) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(n > 0 && (n % 8) == 0, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(x) && DS_ALIGNED16(y_f16), DS_ERR_ALIGNMENT);
-    DS_LAUNCH(scale_cast_f16_kernel, tf_grid(n / 4), 256, 0, stream, x, (h16 *)y_f16, n / 4, scale);
+    DS_LAUNCH(scale_cast_f16_kernel, tf_grid(n / 8), 256, 0, stream, x, (h16 *)y_f16, n / 8, scale);
     return ds_last_launch_error();
 }

@@ -424,8 +424,9 @@ extern "C" int ds_conv_wgrad_bf16(const ds_conv_shape *s, const float *x, const 
     rc = ds_last_launch_error();
     if (rc) return rc;
     const long long n = (long long)s->KS * s->KS * s->Cout * s->Cin;
-    long long g = (n + 255) / 256;
-    DS_LAUNCH(wgrad_reduce_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, (const float *)workspace, gw_oihw,
-              pl.k.S, s->KS * s->KS, s->Cout, s->Cin, 0, 1.0f);
+    int lg, rgrid;
+    wgrad_reduce_shape(n, pl.k.S, lg, rgrid);
+    DS_LAUNCH(wgrad_reduce_kernel, rgrid, 256, 0, stream, (const float *)workspace, gw_oihw,
+              pl.k.S, s->KS * s->KS, s->Cout, s->Cin, 0, 1.0f, lg);
     return ds_last_launch_error();
 }

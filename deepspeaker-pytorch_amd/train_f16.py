@@ -38,7 +38,7 @@ def _bn_stats(eng: Engine, z16: torch.Tensor, bn: BNParams, G: int, update_runni
     """[G][C] tables (mean, invstd, scale, shift) of a train-mode BatchNorm over the G members of z16 [B,h,w,C] fp16"""
     c = z16.shape[-1]
     n_pix = (z16.numel() // c) // G
-    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix, c)
+    rows = eng.lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
     partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=z16.device)
     tables = torch.empty((4, G, c), dtype=torch.float32, device=z16.device)
     eng.lib.call("ds_bn_stats_group_f16", eng._p(z16), eng._p(partial), n_pix, eng._p(bn.weight.detach()),
@@ -119,7 +119,7 @@ def _bn_bwd(eng: Engine, g1, g1_parity, g2, act, z16, tables, gamma, G: int, hw,
     c = z16.shape[-1]
     n_pix = (z16.numel() // c) // G
     dev = z16.device
-    rows = eng.lib.raw("ds_bn_bwd_partial_rows")(n_pix, c)
+    rows = eng.lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
     partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=dev)
     coef = torch.empty((G, 3 * c), dtype=torch.float32, device=dev)
     gy, gz = torch.empty_like(z16), torch.empty_like(z16)

@@ -428,8 +428,9 @@ int ds_roc_sweep_f32(const float *dist, const int *issame, int N, float thr0, fl
  * ds_bn_bwd_group_f16(g1_parity = 1). */
 int ds_pack_conv_weight_dgrad_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, int stride, void *stream);
 /* train-mode BatchNorm statistics of G members (rows [m*n_pix, (m+1)*n_pix) of z) -> [G][C] tables; running statistics
- * updated member after member (the reference's three forward calls); partial: G * ds_bn_bwd_partial_rows(n_pix, C) * C * 2
+ * updated member after member (the reference's three forward calls); partial: G * ds_bn_f16_partial_rows(n_pix, C) * C * 2
  * floats of scratch.  Replaces nn.BatchNorm2d.train() forward bookkeeping (model.py:59,62,94,99,103,107). */
+int ds_bn_f16_partial_rows(long long n_pix, int C);
 int ds_bn_stats_group_f16(const void *z_f16, float *partial, long long n_pix, const float *gamma, const float *beta,
                           float eps, float momentum, float *running_mean, float *running_var, float *mean_t,
                           float *invstd_t, float *scale_t, float *shift_t, int C, int G, void *stream);

@@ -36,7 +36,7 @@ def test_bn_stats_apply_f16(G, bm, h, w, c):
     gamma, beta = rs.uniform(0.5, 1.5, c).astype(np.float32), (rs.randn(c) * 0.1).astype(np.float32)
     rm, rv = (rs.randn(c) * 0.1).astype(np.float32), rs.uniform(0.5, 1.5, c).astype(np.float32)
     n_pix = bm * h * w
-    rows = lib.raw("ds_bn_bwd_partial_rows")(n_pix, c)
+    rows = lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
     partial = aligned((G, rows, c, 2), np.float32)
     tables = aligned((4, G, c), np.float32, fill=np.nan)
     zz = nhwc(z)
@@ -87,7 +87,7 @@ def test_bn_bwd_group_f16(G, bm, h, w, c, parity, act32, with_g2):
     mean_t = np.stack([z[m * bm:(m + 1) * bm].mean(axis=(0, 2, 3)) for m in range(G)]).astype(np.float32)
     invstd_t = np.stack([1 / np.sqrt(z[m * bm:(m + 1) * bm].var(axis=(0, 2, 3)) + 1e-5) for m in range(G)]).astype(np.float32)
     n_pix = bm * h * w
-    rows = lib.raw("ds_bn_bwd_partial_rows")(n_pix, c)
+    rows = lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
     if parity:          # [B][ceil(h/2)][ceil(w/2)][2][2][c]; cells past an odd edge hold garbage that must not be read
         h2, w2 = (h + 1) // 2, (w + 1) // 2
         g1_dev = aligned((B, h2, w2, 2, 2, c), np.float16, fill=np.nan)

@@ -88,7 +88,7 @@ def test_offdist_inputs_vs_reference_golden(gold, name, precision):
              gold[f"{name}_selected"], name)
 
 
-def _train_on_speakers(steps=24, lr=0.01, triplets=32, speakers=16, utts=8):
+def _train_on_speakers(optimizer="adagrad", steps=24, lr=0.01, triplets=32, speakers=16, utts=8):
     """`steps` fused-Adagrad steps (train_triplet.py:369-383, lr_decay 1e-4; lr 0.01: at the script's default of 0.1
     Adagrad's sign-like first step moves every filter by 0.1 -- three times the init's standard deviation -- and 24
     steps later the network saturates at 0 / 20 almost everywhere, values fp16 holds exactly: no test) of the triplet regime
@@ -100,7 +100,7 @@ def _train_on_speakers(steps=24, lr=0.01, triplets=32, speakers=16, utts=8):
     m = DeepSpeakerModel(512, speakers, precision="f32")
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     m = m.cuda().train()
-    opt = create_optimizer(m, lr, "adagrad", lr_decay=1e-4)
+    opt = create_optimizer(m, lr, optimizer, lr_decay=1e-4)       # "sgd": momentum 0.9, dampening 0.9 (train_triplet.py:372-374)
     corpus = O.make_speaker_corpus(31, speakers, utts, 160, scale=12.0, mix=(0.4, 0.3, 0.85))
     losses = []
     for it in range(steps):
@@ -116,10 +116,11 @@ def _train_on_speakers(steps=24, lr=0.01, triplets=32, speakers=16, utts=8):
     return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, corpus, losses
 
 
-@pytest.fixture(scope="module")
-def trained():
+@pytest.fixture(scope="module", params=[("adagrad", 0.01, 24), ("sgd", 0.02, 40)], ids=["adagrad", "sgd"])
+def trained(request):
     import torch_restatement as TR
-    tsd, corpus, losses = _train_on_speakers()
+    opt_name, lr, steps = request.param
+    tsd, corpus, losses = _train_on_speakers(opt_name, steps=steps, lr=lr)
     # the evaluation batch: 256 triplets of the same corpus (the reference's validation works on training speakers too)
     a, p, n, _, _ = O.sample_triplets(9000, corpus.shape[0], corpus.shape[1], 256)
     x = torch.from_numpy(np.concatenate([O.gather_utterances(corpus, i) for i in (a, p, n)]))
