@@ -572,7 +572,7 @@ static int conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_
 #endif
     // persistent workgroups: as many as the chip holds at once (two 2-wave workgroups per CU: one wave per SIMD, 65 KB
     // of LDS each); batches of >= 8 images that fill them are dealt to the XCDs by image (see the kernel)
-    const int resident = 2 * ds_persist_cus();
+    const int resident = 2 * ds_cu_count();
     int grid = k.n_tiles < resident ? k.n_tiles : resident;
     k.xcd_slots = 0;
     if (B >= 8 && grid == resident && resident % 8 == 0) k.xcd_slots = resident / 8;

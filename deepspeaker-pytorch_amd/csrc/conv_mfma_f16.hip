@@ -251,7 +251,7 @@ static bool plan_persistent(PlanH &pl, const ds_conv_shape *s) {
     if (nit_p > 16 || (nit_p > 8 && !lin)) return false;
     pl.lin = lin;
     pl.nit = nit_p;
-    const int resident = (256 / cf.NTHR) * ds_persist_cus();      // one wave per SIMD
+    const int resident = (256 / cf.NTHR) * ds_cu_count();        // one wave per SIMD
     if (pl.grid > resident) pl.grid = resident;
     return true;
 }

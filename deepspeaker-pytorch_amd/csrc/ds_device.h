@@ -158,23 +158,6 @@ static inline int ds_cu_count() {
     return n;
 }
 
-// Compute units a PERSISTENT launch fills: all of them, minus DS_PERSIST_RESERVE_CUS (environment, read once; default 0).
-// A persistent grid holds every CU it was given until it ends, so the small kernels of another stream (the near-tie
-// refinement, the semi-hard search: a few workgroups each) start only at its launch boundaries -- and then take CUs from
-// the NEXT persistent launch's first round.  A few reserved CUs give them somewhere to run at once.
-static inline int ds_persist_cus() {
-    static int n = 0;
-    if (n == 0) {
-        const char *e = getenv("DS_PERSIST_RESERVE_CUS");
-        int r = e ? atoi(e) : 0;
-        const int cus = ds_cu_count();
-        if (r < 0) r = 0;
-        if (r > cus / 2) r = cus / 2;
-        n = cus - r;
-    }
-    return n;
-}
-
 // ---- dynamic tile scheduling of the persistent kernels ----
 // A persistent workgroup takes its first tile from its block index and every further one from a device-side counter:
 // a workgroup that starts late -- its CU was busy with another stream's kernel -- simply takes fewer tiles (a static

@@ -426,7 +426,7 @@ extern "C" int ds_conv_wgrad_bf16(const ds_conv_shape *s, const float *x, const 
     const long long n = (long long)s->KS * s->KS * s->Cout * s->Cin;
     int lg, rgrid;
     wgrad_reduce_shape(n, pl.k.S, lg, rgrid);
-    DS_LAUNCH(wgrad_reduce_kernel, rgrid, 256, 0, stream, (const float *)workspace, gw_oihw,
+    DS_LAUNCH(wgrad_reduce_kernel, rgrid, 256, 1024, stream, (const float *)workspace, gw_oihw,
               pl.k.S, s->KS * s->KS, s->Cout, s->Cin, 0, 1.0f, lg);
     return ds_last_launch_error();
 }

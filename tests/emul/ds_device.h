@@ -188,8 +188,6 @@ static inline int ds_cu_count() {
     return n > 0 ? n : 2;
 }
 
-static inline int ds_persist_cus() { return ds_cu_count(); }
-
 // dynamic tile scheduling of the persistent kernels (see csrc/ds_device.h): blocks run on several OS threads here
 constexpr int DS_SCHED_RING = 8, DS_SCHED_WORDS = 16, DS_SCHED_DONE = 8;
 static inline unsigned ds_atomic_inc(unsigned *p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
-@pytest.mark.parametrize("precision,loss_tol", [("f32", 0.02), ("bf16x3", 0.02), ("f16t", 0.03)])
+@pytest.mark.parametrize("precision,loss_tol", [("f32", 0.02), ("bf16x3", 0.02), ("f16t", 0.05)])
 def test_thirty_step_trajectory_and_eer_vs_reference(precision, loss_tol):
     from deepspeaker_pytorch_amd import scoring
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel, PairwiseDistance, TripletMarginLoss

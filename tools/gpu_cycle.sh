@@ -14,7 +14,6 @@ for w in $WHAT; do
     r4tests) timeout 1500 python -m pytest tests/test_gpu_offdist.py tests/test_gpu_trajectory.py tests/test_gpu_streams.py tests/test_gpu_bench_size.py tests/test_gpu_bench_cli.py -m gpu -q -s > $OUT/pytest_r4.log 2>&1; echo "pytest(r4) rc=$?"; grep -E "^\[|passed|failed|FAILED|Error|policy after" $OUT/pytest_r4.log | tail -60 ;;
     f16train) timeout 1500 python -m pytest tests/test_gpu_train_f16.py tests/test_gpu_trajectory.py -m gpu -q -s > $OUT/pytest_f16train.log 2>&1; echo "pytest(f16train) rc=$?"; grep -E "^\[|passed|failed|FAILED|Error|loss scale|unmasked|bf16x3:|f16:" $OUT/pytest_f16train.log | tail -40
            for tp in bf16x3 f16; do timeout 600 python bench.py --train --train-precision $tp --no-cpu-baseline > $OUT/train_$tp.json 2> $OUT/train_$tp.err; echo "train $tp rc=$?"; cat $OUT/train_$tp.json; done ;;
-    reserve) for r in 0 8 16 0 8; do DS_PERSIST_RESERVE_CUS=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --repeats 3 > $OUT/reserve_$r.json 2> $OUT/reserve_$r.err; python -c "import json;d=json.load(open('$OUT/reserve_$r.json'));print('reserve',$r,d['value'],d['ms_per_step'],d['repeats_ms_per_step'],d['roofline']['achieved'],d['roofline']['isolated']['achieved'])"; done ;;
     offdist) timeout 900 python -m pytest tests/test_gpu_offdist.py -m gpu -q -s -k "trained or planted" > $OUT/pytest_offdist.log 2>&1; echo "pytest(offdist) rc=$?"; grep -E "^\[trained|passed|failed|FAILED|policy after|training losses|^E " $OUT/pytest_offdist.log | tail -30 ;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json | head -c 6000 ;;
     benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?"; cat $OUT/benchq.json | head -c 4000 ;;
