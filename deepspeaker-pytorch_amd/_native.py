@@ -92,8 +92,8 @@ _SIGNATURES = {
     "ds_bn_f16_partial_rows": (c_int, [c_longlong, c_int]),
     "ds_bn_stats_group_f16": (c_int, [_P, _P, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_bn_apply_group_f16": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P]),
-    "ds_bn_bwd_group_f16": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int,
-                                    c_int, c_int, c_int, c_float, _P]),
+    "ds_bn_bwd_group_f16": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong,
+                                    c_int, c_int, c_int, c_int, c_float, _P]),
     "ds_scale_cast_f32_to_f16": (c_int, [_P, _P, c_longlong, c_float, _P]),
     "ds_conv_wgrad_f16_workspace_floats": (c_longlong, [POINTER(ConvShape)]),
     "ds_conv_wgrad_f16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, c_float, _P]),

@@ -162,20 +162,56 @@ __global__ void __launch_bounds__(256) bn_apply_f16_kernel(const h16 *z, const f
     }
 }
 
-// Backward, first half.  gy = (g1 [+ g2]) * [0 < act < 20] (act == nullptr: no mask), written as fp16;
-// partial[member][blk][c] = { sum gy, sum gy * xhat }, xhat = (z - mean) * invstd.
+// The masked upstream gradient of one 8-channel group: g = (g1 [+ g2]) * mask.  The mask is the clipped ReLU's, taken
+//   MODE 0: from nothing (g1 is already masked),
+//   MODE 1: from the stored activation `act` (fp16, or f32 with ACT32): 0 < act < 20 -- the layers whose activation had a
+//           residual added before the clip,
+//   MODE 2: from the layer's own pre-activation: a = fp16(clip(z * msc + msh)) recomputed exactly as bn_apply_f16_kernel
+//           stored it, 0 < a < 20 -- no third tensor is read.
 // PARITY: g1 is the output of the 5x5 stride-2 data gradient run as ONE 3x3 convolution with 4 C output channels
 // (ds_pack_conv_weight_dgrad_f16, stride 2): [B][Ho2][Wo2][2][2][C] -- pixel (h, w) of this layer's [H][W] map is parity
 // class (h & 1, w & 1) of cell (h >> 1, w >> 1).
-template <bool PARITY, bool ACT32>
+struct BwdGeom { long long n_pix, img_pix; int W, Ho2, Wo2, cvec; };
+template <int MODE, bool PARITY, bool ACT32>
+__device__ __forceinline__ f32x8 masked_grad(const h16 *g1, const h16 *g2, const void *act, const f32x8 &zv, const f32x8 &msc,
+                                             const f32x8 &msh, size_t i, long long gp, int cg, const BwdGeom &q) {
+    f32x8 g;
+    if constexpr (PARITY) {
+        const long long b = gp / q.img_pix;
+        const int rem = (int)(gp - b * q.img_pix);
+        const int h = rem / q.W, w = rem - h * q.W;
+        const size_t cell = ((size_t)b * q.Ho2 + (h >> 1)) * q.Wo2 + (w >> 1);
+        g = ld8(g1, (cell * 4 + (size_t)((h & 1) * 2 + (w & 1))) * q.cvec + cg);
+    } else {
+        g = ld8(g1, i);
+    }
+    if (g2) g += ld8(g2, i);
+    if constexpr (MODE == 1) {
+        f32x8 a;
+        if constexpr (ACT32) a = ld8f((const float *)act, i);
+        else a = ld8((const h16 *)act, i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (a[j] > 0.0f && a[j] < 20.0f) ? g[j] : 0.0f;
+    } else if constexpr (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)(h16)fminf(fmaxf(ds_bn_affine(zv[j], msc[j], msh[j]), 0.0f), 20.0f);
+            g[j] = (a > 0.0f && a < 20.0f) ? g[j] : 0.0f;
+        }
+    }
+    return __builtin_convertvector(__builtin_convertvector(g, h16x8), f32x8);      // as an fp16 tensor would hold it
+}
+
+// Backward, first half: partial[member][blk][c] = { sum gy, sum gy * xhat }, xhat = (z - mean) * invstd, gy as above; gy is
+// also written out unless gy == nullptr (the second half then recomputes it: bn_bwd_apply_f16_kernel with REGEN).
+template <int MODE, bool PARITY, bool ACT32>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_f16_kernel(const h16 *g1, const h16 *g2, const void *act, const h16 *z,
-                                                                const float *mean, const float *invstd, h16 *gy,
-                                                                float *partial, long long n_pix, int C, int pix_per_block,
-                                                                int blocks_per_member, int H, int W) {
+                                                                const float *mean, const float *invstd, const float *msc_t,
+                                                                const float *msh_t, h16 *gy, float *partial, long long n_pix,
+                                                                int C, int pix_per_block, int blocks_per_member, int H,
+                                                                int W) {
     const int member = blockIdx.x / blocks_per_member, mblock = blockIdx.x - member * blocks_per_member;
     const size_t moff8 = ((size_t)member * n_pix * C) >> 3;
-    mean += (size_t)member * C;
-    invstd += (size_t)member * C;
     float *red = ds_dynamic_lds();                         // [slots][C][2]
     const int cvec = C >> 3;
     const int slots = 256 / cvec;
@@ -183,38 +219,22 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_f16_kernel(const h16 *g1, c
     const long long p0 = (long long)mblock * pix_per_block;
     long long p1 = p0 + pix_per_block;
     if (p1 > n_pix) p1 = n_pix;
-    const int Ho2 = (H + 1) >> 1, Wo2 = (W + 1) >> 1;
-    const long long img_pix = (long long)H * W;
+    const BwdGeom q = {n_pix, (long long)H * W, W, (H + 1) >> 1, (W + 1) >> 1, cvec};
     f32x8 s1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (slot < slots) {
-        const f32x8 mu = ld8f(mean, cg), is = ld8f(invstd, cg);
+        const f32x8 mu = ld8f(mean + (size_t)member * C, cg), is = ld8f(invstd + (size_t)member * C, cg);
+        f32x8 msc = s1, msh = s1;
+        if constexpr (MODE == 2) {
+            msc = ld8f(msc_t + (size_t)member * C, cg);
+            msh = ld8f(msh_t + (size_t)member * C, cg);
+        }
         for (long long p = p0 + slot; p < p1; p += slots) {
             const size_t i = moff8 + (size_t)p * cvec + cg;                 // 8-channel index in the [G * n_pix][C] tensors
-            f32x8 g;
-            if constexpr (PARITY) {
-                const long long gp = (long long)member * n_pix + p;         // pixel index in the whole batch
-                const long long b = gp / img_pix;
-                const int rem = (int)(gp - b * img_pix);
-                const int h = rem / W, w = rem - h * W;
-                const size_t cell = ((size_t)b * Ho2 + (h >> 1)) * Wo2 + (w >> 1);
-                g = ld8(g1, (cell * 4 + (size_t)((h & 1) * 2 + (w & 1))) * cvec + cg);
-            } else {
-                g = ld8(g1, i);
-            }
-            if (g2) g += ld8(g2, i);
-            if (act) {
-                f32x8 a;
-                if constexpr (ACT32) a = ld8f((const float *)act, i);
-                else a = ld8((const h16 *)act, i);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] = (a[j] > 0.0f && a[j] < 20.0f) ? g[j] : 0.0f;
-            }
-            const h16x8 gh = __builtin_convertvector(g, h16x8);
-            ((h16x8 *)gy)[i] = gh;
-            g = __builtin_convertvector(gh, f32x8);                         // the sums are those of the STORED gradient
-            const f32x8 xh = (ld8(z, i) - mu) * is;
+            const f32x8 zv = ld8(z, i);
+            const f32x8 g = masked_grad<MODE, PARITY, ACT32>(g1, g2, act, zv, msc, msh, i, (long long)member * n_pix + p, cg, q);
+            if (gy) st8(gy, i, g);
             s1 += g;
-            s2 += g * xh;
+            s2 += g * ((zv - mu) * is);
         }
     }
     block_fold(red, s1, s2, slot, slots, cg, C, partial);
@@ -248,20 +268,31 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_f16_kernel(const float *p
     }
 }
 
-// Backward, second half: gz = gamma * invstd * (gy - mean(gy) - xhat * mean(gy * xhat)), fp16 in / out
+// Backward, second half: gz = gamma * invstd * (gy - mean(gy) - xhat * mean(gy * xhat)), fp16 in / out.
+// REGEN: gy was not stored: it is recomputed from g1 (not parity-laid-out, no g2) with the MODE-2 mask.
+template <bool REGEN>
 __global__ void __launch_bounds__(256) bn_bwd_apply_f16_kernel(const h16 *gy, const h16 *z, const float *mean_t,
-                                                               const float *invstd_t, const float *coef, h16 *gz,
-                                                               long long n_vec_member, int G, int C) {
+                                                               const float *invstd_t, const float *coef, const float *msc_t,
+                                                               const float *msh_t, h16 *gz, long long n_vec_member, int G,
+                                                               int C) {
     const int cvec = C >> 3;
     const long long n_vec = n_vec_member * G;
+    const BwdGeom q = {0, 1, 1, 1, 1, cvec};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
         const int member = (int)(i / n_vec_member);
         const int c8 = (int)(i % cvec);
         const float *cf = coef + (size_t)member * 3 * C;
         const f32x8 mu = ld8f(mean_t + (size_t)member * C, c8), is = ld8f(invstd_t + (size_t)member * C, c8);
         const f32x8 k1 = ld8f(cf, c8), k2 = ld8f(cf + C, c8), k3 = ld8f(cf + 2 * C, c8);
-        const f32x8 xh = (ld8(z, (size_t)i) - mu) * is;
-        st8(gz, (size_t)i, k1 * (ld8(gy, (size_t)i) - k2 - xh * k3));
+        const f32x8 zv = ld8(z, (size_t)i);
+        f32x8 g;
+        if constexpr (REGEN) {
+            const f32x8 msc = ld8f(msc_t + (size_t)member * C, c8), msh = ld8f(msh_t + (size_t)member * C, c8);
+            g = masked_grad<2, false, false>(gy, nullptr, nullptr, zv, msc, msh, (size_t)i, 0, c8, q);
+        } else {
+            g = ld8(gy, (size_t)i);
+        }
+        st8(gz, (size_t)i, k1 * (g - k2 - ((zv - mu) * is) * k3));
     }
 }
 
@@ -339,29 +370,40 @@ extern "C" int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, co
     return ds_last_launch_error();
 }
 
-// BatchNorm + clipped-ReLU backward of G members over fp16 tensors (three launches): g1 [+ g2] masked by 0 < act < 20
-// (act fp16, or f32 with act_is_f32; nullptr: g1 is already masked) -> gy; sums; gz = dL/d(conv output).  Gradient
-// tensors are in loss-scaled units (S * g); ggamma / gbeta [C] leave un-scaled (inv_scale = 1 / S).
+// BatchNorm + clipped-ReLU backward of G members over fp16 tensors (three launches): g1 [+ g2] masked -> gy; sums; gz =
+// dL/d(conv output).  The clip mask comes from `act` (0 < act < 20; fp16, or f32 with act_is_f32), or -- act == nullptr and
+// mask_scale_t / mask_shift_t given ([G][C]: the forward's scale / shift tables) -- from the layer's own pre-activation z,
+// or from nothing (both nullptr: g1 is already masked).  gy == nullptr (allowed with the z-derived mask, no g2, no
+// parity layout): the masked gradient is never stored, the second launch recomputes it from g1.  Gradient tensors are in
+// loss-scaled units (S * g); ggamma / gbeta [C] leave un-scaled (inv_scale = 1 / S).
 // g1_parity: g1 is the [B][ceil(H/2)][ceil(W/2)][4 C] output of the stride-2 data gradient run as one 3x3 convolution
-// (H, W = this layer's map; otherwise ignored).  partial: G * rows * C * 2 floats; coef: [G][3 C].
+// (H, W = this layer's map; otherwise ignored).  partial: G * ds_bn_f16_partial_rows(n_pix, C) * C * 2 floats; coef: [G][3 C].
 extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
-                                   const void *z, const float *mean_t, const float *invstd_t, const float *gamma, void *gy,
-                                   float *partial, float *coef, float *ggamma, float *gbeta, void *gz, long long n_pix,
-                                   int H, int W, int C, int G, float inv_scale, void *stream) {
-    DS_REQUIRE(g1 && z && mean_t && invstd_t && gamma && gy && partial && coef && ggamma && gbeta && gz, DS_ERR_NULL);
+                                   const float *mask_scale_t, const float *mask_shift_t, const void *z, const float *mean_t,
+                                   const float *invstd_t, const float *gamma, void *gy, float *partial, float *coef,
+                                   float *ggamma, float *gbeta, void *gz, long long n_pix, int H, int W, int C, int G,
+                                   float inv_scale, void *stream) {
+    DS_REQUIRE(g1 && z && mean_t && invstd_t && gamma && partial && coef && ggamma && gbeta && gz, DS_ERR_NULL);
     DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
     DS_REQUIRE(!g1_parity || (H > 0 && W > 0 && (n_pix * G) % ((long long)H * W) == 0), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((mask_scale_t == nullptr) == (mask_shift_t == nullptr), DS_ERR_NULL);
+    DS_REQUIRE(!(act && mask_scale_t), DS_ERR_UNSUPPORTED);
+    const bool maskz = mask_scale_t != nullptr;
+    DS_REQUIRE(gy || (maskz && !g2 && !g1_parity), DS_ERR_UNSUPPORTED);
     DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(g2) && DS_ALIGNED16(act) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) &&
-                   DS_ALIGNED16(gz) && DS_ALIGNED16(mean_t) && DS_ALIGNED16(invstd_t) && DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
+                   DS_ALIGNED16(gz) && DS_ALIGNED16(mean_t) && DS_ALIGNED16(invstd_t) && DS_ALIGNED16(coef) &&
+                   DS_ALIGNED16(mask_scale_t) && DS_ALIGNED16(mask_shift_t), DS_ERR_ALIGNMENT);
     const int blocks = tf_rows(n_pix, C);
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
     const int slots = 256 / (C / 8);
     const size_t lds = (size_t)slots * C * 2 * 4;
-#define TF_REDUCE(P, A)                                                                                                    \
-    DS_LAUNCH((bn_bwd_reduce_f16_kernel<P, A>), blocks * G, 256, lds, stream, (const h16 *)g1, (const h16 *)g2, act,        \
-              (const h16 *)z, mean_t, invstd_t, (h16 *)gy, partial, n_pix, C, ppb, blocks, H, W)
-    if (g1_parity) { if (act_is_f32) TF_REDUCE(true, true); else TF_REDUCE(true, false); }
-    else           { if (act_is_f32) TF_REDUCE(false, true); else TF_REDUCE(false, false); }
+#define TF_REDUCE(M, P, A)                                                                                                 \
+    DS_LAUNCH((bn_bwd_reduce_f16_kernel<M, P, A>), blocks * G, 256, lds, stream, (const h16 *)g1, (const h16 *)g2, act,     \
+              (const h16 *)z, mean_t, invstd_t, mask_scale_t, mask_shift_t, (h16 *)gy, partial, n_pix, C, ppb, blocks, H, W)
+    if (maskz) { if (g1_parity) TF_REDUCE(2, true, false); else TF_REDUCE(2, false, false); }
+    else if (!act) { if (g1_parity) TF_REDUCE(0, true, false); else TF_REDUCE(0, false, false); }
+    else if (g1_parity) { if (act_is_f32) TF_REDUCE(1, true, true); else TF_REDUCE(1, true, false); }
+    else { if (act_is_f32) TF_REDUCE(1, false, true); else TF_REDUCE(1, false, false); }
 #undef TF_REDUCE
     int rc = ds_last_launch_error();
     if (rc) return rc;
@@ -370,8 +412,12 @@ extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2
     rc = ds_last_launch_error();
     if (rc) return rc;
     const long long nvm = n_pix * (C / 8);
-    DS_LAUNCH(bn_bwd_apply_f16_kernel, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy, (const h16 *)z, mean_t, invstd_t,
-              (const float *)coef, (h16 *)gz, nvm, G, C);
+    if (gy)
+        DS_LAUNCH(bn_bwd_apply_f16_kernel<false>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy, (const h16 *)z, mean_t,
+                  invstd_t, (const float *)coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
+    else
+        DS_LAUNCH(bn_bwd_apply_f16_kernel<true>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)g1, (const h16 *)z, mean_t,
+                  invstd_t, (const float *)coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
     return ds_last_launch_error();
 }
 

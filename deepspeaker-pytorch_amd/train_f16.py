@@ -114,18 +114,23 @@ def forward_train_group_f16(eng: Engine, xs: List[torch.Tensor], pw: PackedWeigh
     return [e[g * Bm:(g + 1) * Bm] for g in range(G)], saved
 
 
-def _bn_bwd(eng: Engine, g1, g1_parity, g2, act, z16, tables, gamma, G: int, hw, inv_scale: float):
-    """(gy16, gz16, dgamma, dbeta) of one BatchNorm + clip layer; see ds_bn_bwd_group_f16"""
+def _bn_bwd(eng: Engine, g1, g1_parity, g2, act, z16, tables, gamma, G: int, hw, inv_scale: float, mask_from_z: bool = False,
+            want_gy: bool = True):
+    """(gy16 or None, gz16, dgamma, dbeta) of one BatchNorm + clip layer; see ds_bn_bwd_group_f16.  mask_from_z: the clip
+    mask is re-derived from the pre-activation z16 and the forward's scale / shift tables instead of being read from a
+    stored activation; want_gy=False (then also: no g2, no parity layout): the masked gradient is not stored."""
     c = z16.shape[-1]
     n_pix = (z16.numel() // c) // G
     dev = z16.device
     rows = eng.lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
     partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=dev)
     coef = torch.empty((G, 3 * c), dtype=torch.float32, device=dev)
-    gy, gz = torch.empty_like(z16), torch.empty_like(z16)
+    gz = torch.empty_like(z16)
+    gy = torch.empty_like(z16) if want_gy else None
     gg, gb = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
-    eng.lib.call("ds_bn_bwd_group_f16", eng._p(g1), int(g1_parity), eng._p(g2), eng._p(act),
-                 int(act is not None and act.dtype == torch.float32), eng._p(z16), eng._p(tables[0]), eng._p(tables[1]),
+    eng.lib.call("ds_bn_bwd_group_f16", eng._p(g1), int(g1_parity), eng._p(g2), None if mask_from_z else eng._p(act),
+                 int(act is not None and act.dtype == torch.float32), eng._p(tables[2]) if mask_from_z else None,
+                 eng._p(tables[3]) if mask_from_z else None, eng._p(z16), eng._p(tables[0]), eng._p(tables[1]),
                  eng._p(gamma.detach()), eng._p(gy), eng._p(partial), eng._p(coef), eng._p(gg), eng._p(gb), eng._p(gz),
                  n_pix, hw[0], hw[1], c, G, float(inv_scale), eng._stream(z16))
     return gy, gz, gg, gb
@@ -212,16 +217,17 @@ def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: Pac
         # y = clip(bn1(conv1(r)))                  (model.py:69-71)
         name = f"model.layer{i}.0.bn1"
         g_y = eng.conv_f16(gz, sw.l_conv2_dgrad_f16, B, h, w, c, c, 3, 1)
-        _, gz, gg, gbeta = _bn_bwd(eng, g_y, False, None, b_act, saved.raws[name], saved.stats[name], bn_weights[name], G,
-                                   (h, w), inv)
+        # (no residual was added before this clip: its mask is re-derived from z; nobody else needs the masked gradient)
+        _, gz, gg, gbeta = _bn_bwd(eng, g_y, False, None, None, saved.raws[name], saved.stats[name], bn_weights[name], G,
+                                   (h, w), inv, mask_from_z=True, want_gy=False)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv1.weight"] = lane.run(
             lambda gz=gz: _wgrad(eng, shp3, a_act, gz, buckets.views[f"model.layer{i}.0.conv1.weight"], inv), gz)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
         g_r = eng.conv_f16(gz, sw.l_conv1_dgrad_f16, B, h, w, c, c, 3, 1)
-        _, gz, gg, gbeta = _bn_bwd(eng, g_r, False, g_out, a_act, saved.raws[name], saved.stats[name], bn_weights[name], G,
-                                   (h, w), inv)
+        _, gz, gg, gbeta = _bn_bwd(eng, g_r, False, g_out, None, saved.raws[name], saved.stats[name], bn_weights[name], G,
+                                   (h, w), inv, mask_from_z=True)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
         shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)

@@ -438,13 +438,16 @@ int ds_bn_stats_group_f16(const void *z_f16, float *partial, long long n_pix, co
  * stage, whose consumer is the f32 pooling / projection tail).  model.py:70-71,74-80,188-189 in train mode. */
 int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, const float *shift_t, const void *res_f16, void *y,
                           long long n_pix, int C, int G, int flags, void *stream);
-/* backward of BatchNorm(train) + clipped ReLU for G members: gy = (g1 [+ g2]) * [0 < act < 20] (act fp16, or f32 with
- * act_is_f32; NULL: no mask), gz = dL/d(conv output); ggamma / gbeta [C] summed over the members and un-scaled.
+/* backward of BatchNorm(train) + clipped ReLU for G members: gy = (g1 [+ g2]) * mask, gz = dL/d(conv output); ggamma /
+ * gbeta [C] summed over the members and un-scaled.  mask = 0 < act < 20 (act fp16, or f32 with act_is_f32), or -- act NULL,
+ * mask_scale_t / mask_shift_t = the forward's [G][C] scale / shift tables -- 0 < fp16(clip(z * scale + shift)) < 20 taken
+ * from the layer's own pre-activation (no third tensor read), or none (all NULL: g1 is already masked).  gy may be NULL
+ * with the z-derived mask (no g2, no parity layout): the masked gradient is then never stored.
  * partial as above; coef [G][3 C] scratch.  H, W: the layer's map (used when g1_parity). */
-int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32, const void *z,
-                        const float *mean_t, const float *invstd_t, const float *gamma, void *gy, float *partial,
-                        float *coef, float *ggamma, float *gbeta, void *gz, long long n_pix, int H, int W, int C, int G,
-                        float inv_scale, void *stream);
+int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
+                        const float *mask_scale_t, const float *mask_shift_t, const void *z, const float *mean_t,
+                        const float *invstd_t, const float *gamma, void *gy, float *partial, float *coef, float *ggamma,
+                        float *gbeta, void *gz, long long n_pix, int H, int W, int C, int G, float inv_scale, void *stream);
 int ds_scale_cast_f32_to_f16(const float *x, void *y_f16, long long n, float scale, void *stream);
 /* filter gradients from fp16 activations x and fp16 loss-scaled output gradients gy (cuDNN wgrad under
  * loss.backward(), train_triplet.py:223): 3x3 / 5x5, stride 1 / 2, Cin and Cout multiples of 64. */

@@ -104,7 +104,7 @@ def test_bn_bwd_group_f16(G, bm, h, w, c, parity, act32, with_g2):
     gg, gb = aligned(c, np.float32), aligned(c, np.float32)
     mt, it, gm = to_aligned(mean_t), to_aligned(invstd_t), to_aligned(gamma)
     z_dev = nhwc(z)
-    lib.call("ds_bn_bwd_group_f16", ptr(g1_dev), int(parity), ptr(g2_dev), ptr(act_dev), int(act32), ptr(z_dev), ptr(mt),
+    lib.call("ds_bn_bwd_group_f16", ptr(g1_dev), int(parity), ptr(g2_dev), ptr(act_dev), int(act32), None, None, ptr(z_dev), ptr(mt),
              ptr(it), ptr(gm), ptr(gy), ptr(partial), ptr(coef), ptr(gg), ptr(gb), ptr(gz), n_pix, h, w, c, G, 1.0 / S, None)
     gsum = g1 + (g2 if with_g2 else 0)
     gy_ref = r16(O.clip_bwd(act, gsum))
@@ -120,6 +120,56 @@ def test_bn_bwd_group_f16(G, bm, h, w, c, parity, act32, with_g2):
         gb_ref += g_b
     assert rel_l2(gz.transpose(0, 3, 1, 2), gz_ref) < 1e-3              # fp16 storage of the result
     assert rel_l2(gg, gg_ref / S) < 1e-5 and rel_l2(gb, gb_ref / S) < 1e-5
+
+
+@pytest.mark.parametrize("G,bm,h,w,c,with_g2,store_gy", [(3, 2, 6, 4, 64, True, True), (2, 2, 5, 3, 128, False, False), (1, 1, 4, 4, 512, False, True)])
+def test_bn_bwd_group_f16_mask_from_preactivation(G, bm, h, w, c, with_g2, store_gy):
+    """The clip mask re-derived from z and the forward's scale / shift tables must be the mask of the activation
+    ds_bn_apply_group_f16 stored (bitwise: same fma, same fp16 rounding) -- so the results equal the act-masked call's --
+    also when the masked gradient is never stored (gy NULL: the second launch recomputes it)."""
+    lib = emul_lib()
+    rs = np.random.RandomState(11 * G + c)
+    B = G * bm
+    S = 256.0
+    z = r16(rs.randn(B, c, h, w) * 4 + 1)
+    g1 = r16(rs.randn(B, c, h, w) * 1e-3 * S)
+    g2 = r16(rs.randn(B, c, h, w) * 1e-3 * S) if with_g2 else None
+    gamma = rs.uniform(0.5, 1.5, c).astype(np.float32)
+    mean_t = to_aligned(np.stack([z[m * bm:(m + 1) * bm].mean(axis=(0, 2, 3)) for m in range(G)]).astype(np.float32))
+    invstd_t = to_aligned(np.stack([1 / np.sqrt(z[m * bm:(m + 1) * bm].var(axis=(0, 2, 3)) + 1e-5) for m in range(G)]).astype(np.float32))
+    # tables that put plenty of values on both clip boundaries (and exactly on fp16 ties)
+    sc_t = to_aligned((rs.uniform(2.0, 6.0, (G, c))).astype(np.float32))
+    sh_t = to_aligned((rs.randn(G, c) * 3 + 6).astype(np.float32))
+    n_pix = bm * h * w
+    rows = lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
+    z_dev, g1_dev, g2_dev = nhwc(z), nhwc(g1), (nhwc(g2) if with_g2 else None)
+    act = aligned((B, h, w, c), np.float16, fill=np.nan)            # what the forward stored
+    lib.call("ds_bn_apply_group_f16", ptr(z_dev), ptr(sc_t), ptr(sh_t), None, ptr(act), n_pix, c, G, DS_EPI_CLIP, None)
+    frac = float(((act > 0) & (act < 20)).mean())
+    assert 0.2 < frac < 0.9, frac
+    gm = to_aligned(gamma)
+    outs = []
+    for maskz in (False, True):
+        gy = aligned((B, h, w, c), np.float16, fill=np.nan) if (store_gy or not maskz) else None
+        gz = aligned((B, h, w, c), np.float16, fill=np.nan)
+        partial, coef = aligned((G, rows, c, 2), np.float32), aligned((G, 3 * c), np.float32)
+        gg, gb = aligned(c, np.float32), aligned(c, np.float32)
+        lib.call("ds_bn_bwd_group_f16", ptr(g1_dev), 0, ptr(g2_dev), None if maskz else ptr(act), 0,
+                 ptr(sc_t) if maskz else None, ptr(sh_t) if maskz else None, ptr(z_dev), ptr(mean_t), ptr(invstd_t), ptr(gm),
+                 ptr(gy), ptr(partial), ptr(coef), ptr(gg), ptr(gb), ptr(gz), n_pix, h, w, c, G, 1.0 / S, None)
+        outs.append((gy, gz.copy(), gg.copy(), gb.copy()))
+    (gy0, gz0, gg0, gb0), (gy1, gz1, gg1, gb1) = outs
+    if gy1 is not None:
+        assert np.array_equal(gy0, gy1)
+    assert np.array_equal(gz0, gz1) and np.array_equal(gg0, gg1) and np.array_equal(gb0, gb1)
+    if with_g2 or not store_gy:     # combinations the ABI refuses: no stored gradient with g2 / parity / act masks
+        gz = aligned((B, h, w, c), np.float16)
+        partial, coef = aligned((G, rows, c, 2), np.float32), aligned((G, 3 * c), np.float32)
+        gg, gb = aligned(c, np.float32), aligned(c, np.float32)
+        rc = lib.raw("ds_bn_bwd_group_f16")(ptr(g1_dev), 0, ptr(g1_dev), None, 0, ptr(sc_t), ptr(sh_t), ptr(z_dev), ptr(mean_t),
+                                            ptr(invstd_t), ptr(gm), None, ptr(partial), ptr(coef), ptr(gg), ptr(gb), ptr(gz),
+                                            n_pix, h, w, c, G, 1.0 / S, None)
+        assert rc != 0
 
 
 def conv16(lib, x_nhwc16, bank, shp, out_c):
