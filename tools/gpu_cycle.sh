@@ -15,6 +15,7 @@ for w in $WHAT; do
     f16train) timeout 1500 python -m pytest tests/test_gpu_train_f16.py tests/test_gpu_trajectory.py -m gpu -q -s > $OUT/pytest_f16train.log 2>&1; echo "pytest(f16train) rc=$?"; grep -E "^\[|passed|failed|FAILED|Error|loss scale|unmasked|bf16x3:|f16:" $OUT/pytest_f16train.log | tail -40
            for tp in bf16x3 f16; do timeout 600 python bench.py --train --train-precision $tp --no-cpu-baseline > $OUT/train_$tp.json 2> $OUT/train_$tp.err; echo "train $tp rc=$?"; cat $OUT/train_$tp.json; done ;;
     offdist) timeout 900 python -m pytest tests/test_gpu_offdist.py -m gpu -q -s -k "trained or planted" > $OUT/pytest_offdist.log 2>&1; echo "pytest(offdist) rc=$?"; grep -E "^\[trained|passed|failed|FAILED|policy after|training losses|^E " $OUT/pytest_offdist.log | tail -30 ;;
+    varlen) timeout 300 python tools/varlen_bench.py > $OUT/varlen.json 2> $OUT/varlen.err; echo "varlen rc=$?"; cat $OUT/varlen.json | cut -c1-400 ;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json | head -c 6000 ;;
     benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?"; cat $OUT/benchq.json | head -c 4000 ;;
     train) timeout 600 python bench.py --train --no-cpu-baseline > $OUT/train.json 2> $OUT/train.err; echo "train rc=$?"; cat $OUT/train.json
