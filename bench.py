@@ -504,8 +504,6 @@ def main():
     emb_per_step = 3 * BATCH_TRIPLETS * world
     if args.train:
         tprec = args.train_precision
-        if tprec == "f16" and multi:
-            tprec = "bf16x3"            # the fp16 step is single-process; data parallelism runs the f32-class step
         elapsed, prof, again, ar_per_step = measure_train(tprec, args.steps, args.warmup, args.repeats)
         if rank == 0:
             line = {

@@ -94,6 +94,11 @@ _SIGNATURES = {
     "ds_bn_apply_group_f16": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P]),
     "ds_bn_bwd_group_f16": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong,
                                     c_int, c_int, c_int, c_int, c_float, _P]),
+    "ds_bn_stats_partial_f16": (c_int, [_P, _P, c_longlong, c_int, c_int, _P]),
+    "ds_bn_bwd_group_reduce_f16": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int,
+                                           c_int, c_int, _P]),
+    "ds_bn_bwd_group_apply_f16": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int,
+                                          c_float, _P]),
     "ds_scale_cast_f32_to_f16": (c_int, [_P, _P, c_longlong, c_float, _P]),
     "ds_conv_wgrad_f16_workspace_floats": (c_longlong, [POINTER(ConvShape)]),
     "ds_conv_wgrad_f16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, c_float, _P]),

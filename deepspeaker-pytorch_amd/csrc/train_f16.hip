@@ -268,6 +268,28 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_f16_kernel(const float *p
     }
 }
 
+// data-parallel fold: the [G][2C+1] float64 sums (per member C pairs { sum gy, sum gy * xhat } and the pixel count) have
+// been all-reduced over the ranks; coefficients per member, dgamma / dbeta summed over the members and un-scaled
+__global__ void __launch_bounds__(256) bn_bwd_from_sums_f16_kernel(const double *sums, const float *gamma, const float *invstd_t,
+                                                                   float *coef, float *ggamma, float *gbeta, int C, int G,
+                                                                   float inv_scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double gg = 0.0, gb = 0.0;
+    for (int m = 0; m < G; ++m) {
+        const double *sm = sums + (size_t)m * (2 * C + 1);
+        const double count = sm[2 * C];
+        float *cf = coef + (size_t)m * 3 * C;
+        cf[c] = gamma[c] * invstd_t[(size_t)m * C + c];
+        cf[C + c] = (float)(sm[c * 2] / count);
+        cf[2 * C + c] = (float)(sm[c * 2 + 1] / count);
+        gb += (double)(float)sm[c * 2];
+        gg += (double)(float)sm[c * 2 + 1];
+    }
+    ggamma[c] = (float)(gg * (double)inv_scale);
+    gbeta[c] = (float)(gb * (double)inv_scale);
+}
+
 // Backward, second half: gz = gamma * invstd * (gy - mean(gy) - xhat * mean(gy * xhat)), fp16 in / out.
 // REGEN: gy was not stored: it is recomputed from g1 (not parity-laid-out, no g2) with the MODE-2 mask.
 template <bool REGEN>
@@ -351,6 +373,21 @@ extern "C" int ds_bn_stats_group_f16(const void *z_f16, float *partial, long lon
     return ds_last_launch_error();
 }
 
+// Data-parallel split of the above (one process per GPU): only the partial sums { sum z, sum z^2 } per member.  The caller
+// folds them to float64 (ds_partial_sum_f64_group, n_partial = ds_bn_f16_partial_rows), all-reduces the [G][2C+1] sums over
+// RCCL and finishes each member with ds_bn_stats_from_sums_f32: every rank normalises with the GLOBAL batch's statistics.
+extern "C" int ds_bn_stats_partial_f16(const void *z_f16, float *partial, long long n_pix, int C, int G, void *stream) {
+    DS_REQUIRE(z_f16 && partial, DS_ERR_NULL);
+    DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(z_f16), DS_ERR_ALIGNMENT);
+    const int blocks = tf_rows(n_pix, C);
+    const int ppb = (int)((n_pix + blocks - 1) / blocks);
+    const int slots = 256 / (C / 8);
+    DS_LAUNCH(bn_stats_f16_kernel, blocks * G, 256, (size_t)slots * C * 2 * 4, stream, (const h16 *)z_f16, partial, n_pix, C,
+              ppb, blocks);
+    return ds_last_launch_error();
+}
+
 // y = clip(z * scale[m] + shift[m] (+ residual)) for all G members in one launch; y is fp16, or f32 with DS_EPI_OUT_F32
 // (the last stage hands f32 to the pooling / projection tail).  flags: DS_EPI_RESIDUAL | DS_EPI_CLIP | DS_EPI_OUT_F32.
 extern "C" int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, const float *shift_t, const void *res_f16,
@@ -378,12 +415,11 @@ extern "C" int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, co
 // loss-scaled units (S * g); ggamma / gbeta [C] leave un-scaled (inv_scale = 1 / S).
 // g1_parity: g1 is the [B][ceil(H/2)][ceil(W/2)][4 C] output of the stride-2 data gradient run as one 3x3 convolution
 // (H, W = this layer's map; otherwise ignored).  partial: G * ds_bn_f16_partial_rows(n_pix, C) * C * 2 floats; coef: [G][3 C].
-extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
-                                   const float *mask_scale_t, const float *mask_shift_t, const void *z, const float *mean_t,
-                                   const float *invstd_t, const float *gamma, void *gy, float *partial, float *coef,
-                                   float *ggamma, float *gbeta, void *gz, long long n_pix, int H, int W, int C, int G,
-                                   float inv_scale, void *stream) {
-    DS_REQUIRE(g1 && z && mean_t && invstd_t && gamma && partial && coef && ggamma && gbeta && gz, DS_ERR_NULL);
+static int bwd_reduce_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
+                          const float *mask_scale_t, const float *mask_shift_t, const void *z, const float *mean_t,
+                          const float *invstd_t, void *gy, float *partial, long long n_pix, int H, int W, int C, int G,
+                          void *stream) {
+    DS_REQUIRE(g1 && z && mean_t && invstd_t && partial, DS_ERR_NULL);
     DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
     DS_REQUIRE(!g1_parity || (H > 0 && W > 0 && (n_pix * G) % ((long long)H * W) == 0), DS_ERR_BAD_SHAPE);
     DS_REQUIRE((mask_scale_t == nullptr) == (mask_shift_t == nullptr), DS_ERR_NULL);
@@ -391,8 +427,8 @@ extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2
     const bool maskz = mask_scale_t != nullptr;
     DS_REQUIRE(gy || (maskz && !g2 && !g1_parity), DS_ERR_UNSUPPORTED);
     DS_REQUIRE(DS_ALIGNED16(g1) && DS_ALIGNED16(g2) && DS_ALIGNED16(act) && DS_ALIGNED16(z) && DS_ALIGNED16(gy) &&
-                   DS_ALIGNED16(gz) && DS_ALIGNED16(mean_t) && DS_ALIGNED16(invstd_t) && DS_ALIGNED16(coef) &&
-                   DS_ALIGNED16(mask_scale_t) && DS_ALIGNED16(mask_shift_t), DS_ERR_ALIGNMENT);
+                   DS_ALIGNED16(mean_t) && DS_ALIGNED16(invstd_t) && DS_ALIGNED16(mask_scale_t) && DS_ALIGNED16(mask_shift_t),
+               DS_ERR_ALIGNMENT);
     const int blocks = tf_rows(n_pix, C);
     const int ppb = (int)((n_pix + blocks - 1) / blocks);
     const int slots = 256 / (C / 8);
@@ -405,20 +441,65 @@ extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2
     else if (g1_parity) { if (act_is_f32) TF_REDUCE(1, true, true); else TF_REDUCE(1, true, false); }
     else { if (act_is_f32) TF_REDUCE(1, false, true); else TF_REDUCE(1, false, false); }
 #undef TF_REDUCE
-    int rc = ds_last_launch_error();
+    return ds_last_launch_error();
+}
+
+static int bwd_apply_f16(const void *gy_or_g1, bool regen, const void *z, const float *mean_t, const float *invstd_t,
+                         const float *coef, const float *mask_scale_t, const float *mask_shift_t, void *gz, long long n_pix,
+                         int C, int G, void *stream) {
+    DS_REQUIRE(gy_or_g1 && z && gz && coef, DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(gy_or_g1) && DS_ALIGNED16(gz) && DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
+    const long long nvm = n_pix * (C / 8);
+    if (!regen)
+        DS_LAUNCH(bn_bwd_apply_f16_kernel<false>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy_or_g1, (const h16 *)z, mean_t,
+                  invstd_t, coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
+    else
+        DS_LAUNCH(bn_bwd_apply_f16_kernel<true>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy_or_g1, (const h16 *)z, mean_t,
+                  invstd_t, coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
+                                   const float *mask_scale_t, const float *mask_shift_t, const void *z, const float *mean_t,
+                                   const float *invstd_t, const float *gamma, void *gy, float *partial, float *coef,
+                                   float *ggamma, float *gbeta, void *gz, long long n_pix, int H, int W, int C, int G,
+                                   float inv_scale, void *stream) {
+    DS_REQUIRE(gamma && coef && ggamma && gbeta && gz, DS_ERR_NULL);
+    int rc = bwd_reduce_f16(g1, g1_parity, g2, act, act_is_f32, mask_scale_t, mask_shift_t, z, mean_t, invstd_t, gy, partial,
+                            n_pix, H, W, C, G, stream);
     if (rc) return rc;
     DS_LAUNCH(bn_bwd_finalize_f16_kernel, ds_ceil_div(C, TF_FOLD_C), 256, TF_FOLD_R * TF_FOLD_C * 2 * sizeof(double), stream,
-              (const float *)partial, blocks, (double)n_pix, gamma, invstd_t, coef, ggamma, gbeta, C, G, inv_scale);
+              (const float *)partial, tf_rows(n_pix, C), (double)n_pix, gamma, invstd_t, coef, ggamma, gbeta, C, G, inv_scale);
     rc = ds_last_launch_error();
     if (rc) return rc;
-    const long long nvm = n_pix * (C / 8);
-    if (gy)
-        DS_LAUNCH(bn_bwd_apply_f16_kernel<false>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy, (const h16 *)z, mean_t,
-                  invstd_t, (const float *)coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
-    else
-        DS_LAUNCH(bn_bwd_apply_f16_kernel<true>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)g1, (const h16 *)z, mean_t,
-                  invstd_t, (const float *)coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
-    return ds_last_launch_error();
+    return bwd_apply_f16(gy ? gy : g1, gy == nullptr, z, mean_t, invstd_t, coef, mask_scale_t, mask_shift_t, gz, n_pix, C, G,
+                         stream);
+}
+
+// Data-parallel split of ds_bn_bwd_group_f16: the reduction alone (partial sums + gy), then -- after the caller has folded
+// the partials to float64 (ds_partial_sum_f64_group), and all-reduced the [G][2C+1] sums over RCCL -- coefficients, dgamma /
+// dbeta and gz from the GLOBAL sums.  Same arguments, same mask choices.
+extern "C" int ds_bn_bwd_group_reduce_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
+                                          const float *mask_scale_t, const float *mask_shift_t, const void *z,
+                                          const float *mean_t, const float *invstd_t, void *gy, float *partial,
+                                          long long n_pix, int H, int W, int C, int G, void *stream) {
+    return bwd_reduce_f16(g1, g1_parity, g2, act, act_is_f32, mask_scale_t, mask_shift_t, z, mean_t, invstd_t, gy, partial, n_pix,
+                          H, W, C, G, stream);
+}
+
+// gy_or_g1: the stored masked gradient, or (gy was not stored: regen != 0) g1 itself with the z-derived mask tables
+extern "C" int ds_bn_bwd_group_apply_f16(const double *sums, const void *gy_or_g1, int regen, const float *mask_scale_t,
+                                         const float *mask_shift_t, const void *z, const float *mean_t, const float *invstd_t,
+                                         const float *gamma, float *coef, float *ggamma, float *gbeta, void *gz,
+                                         long long n_pix, int C, int G, float inv_scale, void *stream) {
+    DS_REQUIRE(sums && gamma && coef && ggamma && gbeta && mean_t && invstd_t, DS_ERR_NULL);
+    DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(!regen || (mask_scale_t && mask_shift_t), DS_ERR_NULL);
+    DS_LAUNCH(bn_bwd_from_sums_f16_kernel, ds_ceil_div(C, 256), 256, 0, stream, sums, gamma, invstd_t, coef, ggamma, gbeta, C, G,
+              inv_scale);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    return bwd_apply_f16(gy_or_g1, regen != 0, z, mean_t, invstd_t, coef, mask_scale_t, mask_shift_t, gz, n_pix, C, G, stream);
 }
 
 // y_f16 = fp16(x * scale): how an f32 gradient enters the fp16 backward pass (scale = the loss scale S)

@@ -210,20 +210,25 @@ class TripletStepResult:
 
 def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, reducer: Optional[Reducer] = None,
                        labels: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                       mine: bool = False) -> TripletStepResult:
+                       mine: bool = False, arith: str = "f32", loss_scale: float = 1024.0) -> TripletStepResult:
     """One data-parallel training step on this rank's shard of the triplet batch (engine level).
 
     reference semantics (train_triplet.py:215-224): three train-mode forwards (three BatchNorm statistic
     sets), TripletMarginLoss over the batch, backward.  With `reducer` the statistics, the loss mean and
     the gradients are those of the GLOBAL batch.  With `mine` (needs `labels` = (c1, c2) speaker ids of
     positives / negatives) every anchor's negative is replaced by the semi-hard negative found among the
-    all-gathered embeddings of all ranks before the loss is taken.
+    all-gathered embeddings of all ranks before the loss is taken.  `arith` "f16": the opt-in fp16 step (train_f16.py;
+    `pw` packed with with_f16=True, with_f16_dgrad=True), same exchange pattern.
     """
     from .backward import backward_train
     lib = eng.lib
     world = reducer.world if reducer is not None else 1
     # the three forwards in lock-step over one batch: one statistics all-reduce per BatchNorm layer
-    (ea, ep, en), saved = eng.forward_train_group([xa, xp, xn], pw, bns, save=True, reducer=reducer)
+    if arith == "f16":
+        from .train_f16 import backward_train_f16, forward_train_group_f16
+        (ea, ep, en), saved = forward_train_group_f16(eng, [xa, xp, xn], pw, bns, save=True, reducer=reducer)
+    else:
+        (ea, ep, en), saved = eng.forward_train_group([xa, xp, xn], pw, bns, save=True, reducer=reducer)
     ea, ep, en = ea.contiguous(), ep.contiguous(), en.contiguous()
     n_loc, d = ea.shape
     n_glob = n_loc * world
@@ -275,6 +280,10 @@ def triplet_train_step(eng, pw, bns, bn_weights, xa, xp, xn, margin: float, redu
         gn = gn_used
     # one backward pass over the concatenated batch; its per-stage gradient buckets are all-reduced as they
     # are produced (backward._GradBuckets), overlapped with the earlier stages' kernels
-    grads = backward_train(eng, bn_weights, pw, saved, torch.cat([ga, gp, gn]).contiguous(), reducer=reducer,
-                           reduce_gradients=reducer is not None)
+    if arith == "f16":
+        grads = backward_train_f16(eng, bn_weights, pw, saved, torch.cat([ga, gp, gn]).contiguous(), loss_scale=loss_scale,
+                                   reducer=reducer, reduce_gradients=reducer is not None)
+    else:
+        grads = backward_train(eng, bn_weights, pw, saved, torch.cat([ga, gp, gn]).contiguous(), reducer=reducer,
+                               reduce_gradients=reducer is not None)
     return TripletStepResult(loss.reshape(()), grads, (ea, ep, en), mined)

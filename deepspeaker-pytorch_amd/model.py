@@ -333,7 +333,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
         if prec == "f16":
             from .train_f16 import forward_train_group_f16
             pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
-            (e,), saved = forward_train_group_f16(eng, [x], pw, model._bn_params(), save=True)
+            (e,), saved = forward_train_group_f16(eng, [x], pw, model._bn_params(), save=True, reducer=model._reducer)
         else:
             pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
             e, saved = eng.forward_train(x, pw, model._bn_params(), save=True, reducer=model._reducer, precision=prec)
@@ -353,7 +353,8 @@ class _ResCNNTrainFn(torch.autograd.Function):
         if ctx.precision == "f16":
             from .train_f16 import backward_train_f16
             grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
-                                       loss_scale=ctx.model.loss_scale)
+                                       loss_scale=ctx.model.loss_scale, reducer=ctx.model._reducer,
+                                       reduce_gradients=ctx.model._reducer is not None)
         else:
             grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
                                    reducer=ctx.model._reducer, precision=ctx.precision,
@@ -373,7 +374,8 @@ class _ResCNNTripletFn(torch.autograd.Function):
         if prec == "f16":
             from .train_f16 import forward_train_group_f16
             pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
-            embs, saved = forward_train_group_f16(eng, [xa, xp, xn], pw, model._bn_params(), save=True)
+            embs, saved = forward_train_group_f16(eng, [xa, xp, xn], pw, model._bn_params(), save=True,
+                                                  reducer=model._reducer)
         else:
             pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
             embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
@@ -392,7 +394,8 @@ class _ResCNNTripletFn(torch.autograd.Function):
         bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
         if ctx.precision == "f16":
             from .train_f16 import backward_train_f16
-            grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, loss_scale=ctx.model.loss_scale)
+            grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, loss_scale=ctx.model.loss_scale,
+                                       reducer=ctx.model._reducer, reduce_gradients=ctx.model._reducer is not None)
         else:
             grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, reducer=ctx.model._reducer,
                                    precision=ctx.precision, reduce_gradients=ctx.model._reducer is not None)
@@ -528,10 +531,8 @@ class DeepSpeakerModel(nn.Module):
         return sd
 
     def _train_arith(self) -> str:
-        """arithmetic of the next training step (see `train_precision`); data parallelism runs the f32-class step"""
+        """arithmetic of the next training step (see `train_precision`)"""
         tp = self.train_precision
-        if tp == "f16" and self._reducer is not None and self._reducer.active:
-            tp = None
         if tp is None:
             return "bf16x3" if self.precision in ("bf16x3", "f16") else "f32"
         return tp

@@ -35,7 +35,7 @@ def _problem(N_STAGES):
     return sd, xs, c1, c2
 
 
-def _run(rank, world, mine, reducer, N_STAGES=2):
+def _run(rank, world, mine, reducer, N_STAGES=2, arith="f32"):
     _setup_paths()
     from emul_util import emul_lib
     from deepspeaker_pytorch_amd.distributed import triplet_train_step
@@ -44,7 +44,10 @@ def _run(rank, world, mine, reducer, N_STAGES=2):
     eng = Engine(emul_lib())
     eng.lib.trace = {}
     tsd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
-    pw = eng.pack_weights(tsd, N_STAGES, with_dgrad=True)
+    if arith == "f16":
+        pw = eng.pack_weights(tsd, N_STAGES, with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
+    else:
+        pw = eng.pack_weights(tsd, N_STAGES, with_dgrad=True)
     names = []
     for i in range(1, N_STAGES + 1):
         names += [f"model.bn{i}", f"model.layer{i}.0.bn1", f"model.layer{i}.0.bn2"]
@@ -55,7 +58,7 @@ def _run(rank, world, mine, reducer, N_STAGES=2):
     xa, xp, xn = (torch.from_numpy(x[sl].copy()) for x in xs)
     labels = (torch.from_numpy(c1[sl].copy()), torch.from_numpy(c2[sl].copy()))
     res = triplet_train_step(eng, pw, bns, {n: b.weight for n, b in bns.items()}, xa, xp, xn, 0.1, reducer,
-                             labels=labels, mine=mine)
+                             labels=labels, mine=mine, arith=arith)
     out = {"loss": res.loss.numpy()}
     for k, v in eng.lib.trace.items():
         out["calls/" + k] = np.array(v)
@@ -72,14 +75,14 @@ def _run(rank, world, mine, reducer, N_STAGES=2):
     return out
 
 
-def _worker(rank, world, port, mine, outdir, n_stages=2, force=False, grad_comm=None, grad_reduce=None):
+def _worker(rank, world, port, mine, outdir, n_stages=2, force=False, grad_comm=None, grad_reduce=None, arith="f32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _setup_paths()
     from deepspeaker_pytorch_amd.distributed import Reducer
-    out = _run(rank, world, mine, Reducer(force=force, grad_comm=grad_comm, grad_reduce=grad_reduce), n_stages)
+    out = _run(rank, world, mine, Reducer(force=force, grad_comm=grad_comm, grad_reduce=grad_reduce), n_stages, arith)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -178,6 +181,35 @@ def test_reducer_rejects_unknown_modes_and_defaults_to_the_safe_ones(tmp_path):
         assert r2.grad_group is g and r2.overlap_gradients
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mine", [(2, False), (2, True), (1, False)])
+def test_fp16_step_data_parallel_reproduces_single_process(tmp_path, world, mine):
+    """The opt-in fp16 training step under data parallelism (world 2, and the forced sequence with one rank): global
+    BatchNorm sums in one float64 all-reduce per layer and direction, f32 gradient buckets -- the same exchange count as the
+    f32-class step -- reproduce the single-process fp16 step on the global batch up to what a last-bit difference in a
+    statistic does to fp16-rounded tensors."""
+    mp.spawn(_worker, args=(world, _free_port(), mine, str(tmp_path), 2, world == 1, None, None, "f16"), nprocs=world, join=True)
+    ref = _run(0, 1, mine, None, 2, "f16")
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    n_loc = B_GLOBAL // world
+    for r, got in enumerate(ranks):
+        assert abs(float(got["loss"]) - float(ref["loss"])) <= 2e-3 * max(1.0, abs(float(ref["loss"])))
+        for k, v in ref.items():
+            if k.startswith("grad/"):
+                err = np.linalg.norm(got[k] - v) / max(np.linalg.norm(v), 1e-30)
+                assert err < 3e-2, (r, k, err)              # (tiny maps: one flipped fp16 rounding at a clip boundary)
+            elif k.startswith(("rm/", "rv/")):
+                np.testing.assert_allclose(got[k], v, rtol=2e-3, atol=2e-3, err_msg=k)
+            elif k.startswith("emb_"):
+                np.testing.assert_allclose(got[k], v[r * n_loc:(r + 1) * n_loc], rtol=5e-3, atol=5e-3)
+    assert int(ranks[0]["n_all_reduce"]) == 2 * 3 * 2 + (2 + 1) + 1
+    assert int(ranks[0]["calls/ds_bn_bwd_group_reduce_f16"]) == 3 * 2 and int(ranks[0]["calls/ds_bn_bwd_group_apply_f16"]) == 3 * 2
+    assert "calls/ds_bn_bwd_group_f16" not in ranks[0].files and int(ref["calls/ds_bn_bwd_group_f16"]) == 3 * 2
+    for k in ranks[0].files:                                # all ranks hold identical global gradients
+        if k.startswith("grad/"):
+            for other in ranks[1:]:
+                np.testing.assert_array_equal(ranks[0][k], other[k])
 
 
 def test_gradient_bucketing_names():
