@@ -17,6 +17,7 @@ DS_CONV_HINT_SINGLE_BUFFER = 64
 DS_CONV_HINT_CHUNK16 = 128
 DS_CONV_HINT_NO_PERSIST = 1024
 DS_CONV_CK = 8
+DS_TAIL_SMALL_MAX_B = 4
 
 
 class ConvShape(Structure):
@@ -88,6 +89,8 @@ _SIGNATURES = {
     "ds_conv_wgrad_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, c_int, _P]),
     "ds_conv_wgrad_bf16_workspace_floats": (c_longlong, [POINTER(ConvShape)]),
     "ds_conv_wgrad_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P]),
+    "ds_pack_fc_weight_rows_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_tail_small_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "ds_pack_conv_weight_dgrad_f16": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_bn_f16_partial_rows": (c_int, [c_longlong, c_int]),
     "ds_bn_stats_group_f16": (c_int, [_P, _P, c_longlong, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

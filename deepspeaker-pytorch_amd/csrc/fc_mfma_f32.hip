@@ -128,6 +128,58 @@ __global__ void __launch_bounds__(256) fc_mean_kernel(const float *x, float *out
     if (threadIdx.x == 0) out[0] = (scratch[0] + scratch[1] + scratch[2] + scratch[3]) / (float)n;
 }
 
+// ---- small-batch tail (serving latency: B <= 4 utterances): temporal mean + projection in ONE launch --------------
+// At B = 1 the three-launch tail (pool 5 us, split-K GEMM 15 us on 32 workgroups each walking a 128 KB weight slice in
+// sequence, fold + norm 10 us) is pure latency.  Here a workgroup first pools the whole utterance into LDS (80 KB of the
+// last stage's output -> 2048 means, 20 independent 16-byte loads per thread), then each of its 4 waves takes ONE output
+// feature: a 2048-long dot product against that feature's weight row (row-major copy of the fc filter in the pooled
+// vector's f*C + c order, ds_pack_fc_weight_rows_f32: eight coalesced 1 KiB loads per wave), folded by a fixed xor tree.
+// N / 4 = 128 workgroups; the norm follows in ds_l2norm_scale_f32's kernel.  Summation order differs from the split-K
+// GEMM's: results agree to f32 rounding, not bitwise.
+__global__ void __launch_bounds__(256) pool_fc_small_kernel(const float *a, const float *w_rows, const float *bias, float *f,
+                                                            int B, int Hr, int K, int N) {
+    float *pooled = ds_dynamic_lds();                       // [B][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kv = K >> 2;                                  // float4 columns per row
+    const float rcp = 1.0f / (float)Hr;
+    for (int b = 0; b < B; ++b)
+        for (int v = tid; v < kv; v += 256) {
+            const f32x4 *src = (const f32x4 *)(a + (size_t)b * Hr * K) + v;
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < Hr; ++h) s4 += src[(size_t)h * kv];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s4[j] = s4[j] / (float)Hr;      // the division avgpool_time_kernel does
+            ((f32x4 *)(pooled + (size_t)b * K))[v] = s4;
+        }
+    (void)rcp;
+    __syncthreads();
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const f32x4 *wr = (const f32x4 *)(w_rows + (size_t)n * K);
+    for (int b = 0; b < B; ++b) {
+        const f32x4 *pv = (const f32x4 *)(pooled + (size_t)b * K);
+        float acc = 0.f;
+        for (int v = lane; v < kv; v += 64) {
+            const f32x4 x4 = pv[v], w4 = wr[v];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(x4[j], w4[j], acc);
+        }
+        acc = fc_wave_sum(acc);
+        if (lane == 0) f[(size_t)b * N + n] = acc + (bias ? bias[n] : 0.0f);
+    }
+}
+
+// fc weight [N][C*F] (reference order c*F + f) -> [N][K'] with k' = f*C + c: each output feature's filter as ONE
+// contiguous row in the order of the pooled channels-last vector
+__global__ void __launch_bounds__(256) pack_fc_weight_rows_kernel(const float *w, float *out, int N, int C, int F) {
+    const long long n = (long long)N * C * F;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int kp = (int)(i % (C * F)), nn = (int)(i / (C * F));
+        const int f_ = kp / C, c = kp - f_ * C;
+        out[i] = w[(size_t)nn * C * F + (size_t)c * F + f_];
+    }
+}
+
 static int fc_splits(int K) {
     const int chunks = K / CK;
     for (int s = 8; s > 1; s >>= 1)
@@ -176,4 +228,28 @@ extern "C" int ds_fc_ce_fwd_f32(const float *x, const float *w_packed, const flo
     if (rc) return rc;
     DS_LAUNCH(fc_mean_kernel, 1, 256, 64, stream, (const float *)row_loss, loss, M);
     return ds_last_launch_error();
+}
+
+extern "C" int ds_pack_fc_weight_rows_f32(const float *w, float *w_rows, int N, int C, int F, void *stream) {
+    DS_REQUIRE(w && w_rows, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && C > 0 && F > 0 && ((C * F) % 4) == 0, DS_ERR_BAD_SHAPE);
+    const long long n = (long long)N * C * F;
+    long long g = (n + 255) / 256;
+    DS_LAUNCH(pack_fc_weight_rows_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w, w_rows, N, C, F);
+    return ds_last_launch_error();
+}
+
+// Small-batch tail (B <= DS_TAIL_SMALL_MAX_B): f = mean_t(a) . W^T + bias from the last stage's f32 output a [B, Hr, K]
+// (K = Wc * C channels-last), W as ds_pack_fc_weight_rows_f32 laid it out; e = alpha * f / sqrt(sum f^2 + eps).
+// Two launches (pool + projection; norm).  model.py:207-213.
+extern "C" int ds_tail_small_f32(const float *a, const float *w_rows, const float *bias, float *f, float *e, int B, int Hr,
+                                 int K, int N, float alpha, float eps, void *stream) {
+    DS_REQUIRE(a && w_rows && f && e, DS_ERR_NULL);
+    DS_REQUIRE(B > 0 && B <= DS_TAIL_SMALL_MAX_B && Hr > 0 && K > 0 && (K % 4) == 0 && N > 0 && (N % 4) == 0 &&
+                   (size_t)B * K * 4 <= 64 * 1024, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(a) && DS_ALIGNED16(w_rows), DS_ERR_ALIGNMENT);
+    DS_LAUNCH(pool_fc_small_kernel, N / 4, 256, (size_t)B * K * 4, stream, a, w_rows, bias, f, B, Hr, K, N);
+    int rc = ds_last_launch_error();
+    if (rc) return rc;
+    return ds_l2norm_scale_f32(f, e, B, N, alpha, eps, stream);
 }

@@ -414,6 +414,15 @@ int ds_group_mean_f32(const float *x, float *out, int n_groups, int G, void *str
 int ds_roc_sweep_f32(const float *dist, const int *issame, int N, float thr0, float dthr, int n_thr,
                      int n_same, int n_diff, int *tp, int *fp, float *summary6, void *stream);
 
+/* ---- small-batch tail (serving latency, round 4): temporal mean + 2048 -> 512 projection in one launch for
+ *      B <= DS_TAIL_SMALL_MAX_B utterances, then the norm (model.py:207-213).  w_rows = the fc filter as [N][K'] rows in
+ *      the pooled vector's f*C + c order (ds_pack_fc_weight_rows_f32).  Agrees with ds_avgpool_time_f32 +
+ *      ds_fc_l2norm_fwd_f32 to f32 rounding (another summation order), 8 us instead of 30 at B = 1. ---- */
+#define DS_TAIL_SMALL_MAX_B 4
+int ds_pack_fc_weight_rows_f32(const float *w, float *w_rows, int N, int C, int F, void *stream);
+int ds_tail_small_f32(const float *a, const float *w_rows, const float *bias, float *f, float *e, int B, int Hr, int K,
+                      int N, float alpha, float eps, void *stream);
+
 /* ---- OPT-IN fp16 training step (round 4; DeepSpeakerModel(train_precision="f16")): the triplet-regime step of
  *      train_triplet.py:215-224 with every activation, pre-activation and gradient tensor fp16 in HBM, the convolutions
  *      (forward AND data gradients) on ds_conv_fwd_f16 -- one fp16 MFMA per product, f32 accumulate -- and f32

@@ -533,3 +533,38 @@ def test_enrolment_scores_over_sets_of_different_sizes():
             scoring.enrolment_scores(torch.from_numpy(test), torch.from_numpy(enrol), [3, 1, 5, 3])
     finally:
         scoring._engine_override = None
+
+
+@pytest.mark.parametrize("B", [1, 3, 4])
+def test_small_batch_tail_equals_the_three_launch_tail(B):
+    """ds_tail_small_f32 (serving latency: temporal mean + projection in one launch, then the norm) against the oracle and
+    against ds_avgpool_time_f32 + ds_fc_l2norm_fwd_f32 on the same activations -- another summation order, f32 rounding."""
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(40 + B)
+    hr, wc, c, n_out = 10, 4, 512, 512
+    a = torch.from_numpy(np.abs(rs.randn(B, hr, wc, c)).astype(np.float32))
+    wfc = torch.from_numpy((rs.randn(n_out, c * wc) / np.sqrt(c * wc)).astype(np.float32))     # reference order c*F + f
+    bias = torch.from_numpy((rs.randn(n_out) * 0.1).astype(np.float32))
+    k = wc * c
+    rows = torch.empty(n_out * k)
+    eng.lib.call("ds_pack_fc_weight_rows_f32", eng._p(wfc), eng._p(rows), n_out, c, wc, None)
+    f, e = torch.empty(B, n_out), torch.empty(B, n_out)
+    eng.lib.call("ds_tail_small_f32", eng._p(a), eng._p(rows), eng._p(bias), eng._p(f), eng._p(e), B, hr, k, n_out, 10.0, 1e-10, None)
+    # oracle: NCHW mean over time, flatten c*F + f (model.py:207-213)
+    x = a.numpy().transpose(0, 3, 1, 2)                     # [B, C, Hr, Wc]
+    pooled = x.mean(axis=2).reshape(B, -1)
+    f_ref = pooled @ wfc.numpy().T + bias.numpy()
+    e_ref = O.l2_norm_scale(f_ref.astype(np.float64))
+    assert rel_err(f.numpy(), f_ref) < 2e-6 and rel_err(e.numpy(), e_ref) < 2e-6
+    # the three-launch tail
+    packed = torch.empty(n_out * k)
+    eng.lib.call("ds_pack_fc_weight_f32", eng._p(wfc), eng._p(packed), n_out, c, wc, None)
+    pooled_t = torch.empty(B, k)
+    eng.lib.call("ds_avgpool_time_f32", eng._p(a), eng._p(pooled_t), B, hr, wc, c, None)
+    ws = torch.empty(eng.lib.raw("ds_fc_workspace_floats")(B, k, n_out))
+    f2, e2 = torch.empty(B, n_out), torch.empty(B, n_out)
+    eng.lib.call("ds_fc_l2norm_fwd_f32", eng._p(pooled_t), eng._p(packed), eng._p(bias), eng._p(ws), eng._p(f2), eng._p(e2), B, k,
+                 n_out, 10.0, 1e-10, None)
+    assert rel_err(e.numpy(), e2.numpy()) < 2e-6
+    assert eng.lib.raw("ds_tail_small_f32")(eng._p(a), eng._p(rows), eng._p(bias), eng._p(f), eng._p(e), 5, hr, k, n_out, 10.0,
+                                            1e-10, None) != 0           # B above DS_TAIL_SMALL_MAX_B is refused
