@@ -130,43 +130,39 @@ __global__ void __launch_bounds__(256) fc_mean_kernel(const float *x, float *out
 
 // ---- small-batch tail (serving latency: B <= 4 utterances): temporal mean + projection in ONE launch --------------
 // At B = 1 the three-launch tail (pool 5 us, split-K GEMM 15 us on 32 workgroups each walking a 128 KB weight slice in
-// sequence, fold + norm 10 us) is pure latency.  Here a workgroup first pools the whole utterance into LDS (80 KB of the
+// sequence, fold + norm 10 us) is pure latency.  Here a workgroup first pools ITS utterance into LDS (80 KB of the
 // last stage's output -> 2048 means, 20 independent 16-byte loads per thread), then each of its 4 waves takes ONE output
 // feature: a 2048-long dot product against that feature's weight row (row-major copy of the fc filter in the pooled
 // vector's f*C + c order, ds_pack_fc_weight_rows_f32: eight coalesced 1 KiB loads per wave), folded by a fixed xor tree.
-// N / 4 = 128 workgroups; the norm follows in ds_l2norm_scale_f32's kernel.  Summation order differs from the split-K
+// B x N / 4 workgroups; the norm follows in ds_l2norm_scale_f32's kernel.  Summation order differs from the split-K
 // GEMM's: results agree to f32 rounding, not bitwise.
 __global__ void __launch_bounds__(256) pool_fc_small_kernel(const float *a, const float *w_rows, const float *bias, float *f,
-                                                            int B, int Hr, int K, int N) {
-    float *pooled = ds_dynamic_lds();                       // [B][K]
+                                                            int Hr, int K, int N) {
+    float *pooled = ds_dynamic_lds();                       // [K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ngroups = N >> 2;
+    const int b = blockIdx.x / ngroups, ng = blockIdx.x - b * ngroups;      // B x N/4 workgroups: (utterance, 4 features)
     const int kv = K >> 2;                                  // float4 columns per row
-    const float rcp = 1.0f / (float)Hr;
-    for (int b = 0; b < B; ++b)
-        for (int v = tid; v < kv; v += 256) {
-            const f32x4 *src = (const f32x4 *)(a + (size_t)b * Hr * K) + v;
-            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-            for (int h = 0; h < Hr; ++h) s4 += src[(size_t)h * kv];
+    for (int v = tid; v < kv; v += 256) {
+        const f32x4 *src = (const f32x4 *)(a + (size_t)b * Hr * K) + v;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < Hr; ++h) s4 += src[(size_t)h * kv];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s4[j] = s4[j] / (float)Hr;      // the division avgpool_time_kernel does
-            ((f32x4 *)(pooled + (size_t)b * K))[v] = s4;
-        }
-    (void)rcp;
-    __syncthreads();
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
-    const f32x4 *wr = (const f32x4 *)(w_rows + (size_t)n * K);
-    for (int b = 0; b < B; ++b) {
-        const f32x4 *pv = (const f32x4 *)(pooled + (size_t)b * K);
-        float acc = 0.f;
-        for (int v = lane; v < kv; v += 64) {
-            const f32x4 x4 = pv[v], w4 = wr[v];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(x4[j], w4[j], acc);
-        }
-        acc = fc_wave_sum(acc);
-        if (lane == 0) f[(size_t)b * N + n] = acc + (bias ? bias[n] : 0.0f);
+        for (int j = 0; j < 4; ++j) s4[j] = s4[j] / (float)Hr;          // the division avgpool_time_kernel does
+        ((f32x4 *)pooled)[v] = s4;
     }
+    __syncthreads();
+    const int n = ng * 4 + wave;
+    const f32x4 *wr = (const f32x4 *)(w_rows + (size_t)n * K);
+    const f32x4 *pv = (const f32x4 *)pooled;
+    float acc = 0.f;
+    for (int v = lane; v < kv; v += 64) {
+        const f32x4 x4 = pv[v], w4 = wr[v];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(x4[j], w4[j], acc);
+    }
+    acc = fc_wave_sum(acc);
+    if (lane == 0) f[(size_t)b * N + n] = acc + (bias ? bias[n] : 0.0f);
 }
 
 // fc weight [N][C*F] (reference order c*F + f) -> [N][K'] with k' = f*C + c: each output feature's filter as ONE
@@ -246,9 +242,9 @@ extern "C" int ds_tail_small_f32(const float *a, const float *w_rows, const floa
                                  int K, int N, float alpha, float eps, void *stream) {
     DS_REQUIRE(a && w_rows && f && e, DS_ERR_NULL);
     DS_REQUIRE(B > 0 && B <= DS_TAIL_SMALL_MAX_B && Hr > 0 && K > 0 && (K % 4) == 0 && N > 0 && (N % 4) == 0 &&
-                   (size_t)B * K * 4 <= 64 * 1024, DS_ERR_BAD_SHAPE);
+                   (size_t)K * 4 <= 64 * 1024, DS_ERR_BAD_SHAPE);
     DS_REQUIRE(DS_ALIGNED16(a) && DS_ALIGNED16(w_rows), DS_ERR_ALIGNMENT);
-    DS_LAUNCH(pool_fc_small_kernel, N / 4, 256, (size_t)B * K * 4, stream, a, w_rows, bias, f, B, Hr, K, N);
+    DS_LAUNCH(pool_fc_small_kernel, (N / 4) * B, 256, (size_t)K * 4, stream, a, w_rows, bias, f, Hr, K, N);
     int rc = ds_last_launch_error();
     if (rc) return rc;
     return ds_l2norm_scale_f32(f, e, B, N, alpha, eps, stream);

@@ -494,7 +494,7 @@ class Engine:
                 mask_call(a, s, h)
         k = w * cin
         n_out = pw.fc_bias.numel()
-        if low_latency and not masked and B <= DS_TAIL_SMALL_MAX_B and B * k * 4 <= 65536 and pw.fc_src is not None:
+        if low_latency and not masked and B <= DS_TAIL_SMALL_MAX_B and k * 4 <= 65536 and pw.fc_src is not None:
             # serving a few utterances: pooling + projection in one launch, then the norm (8 us instead of 30 at B = 1)
             if pw.fc_rows is None:
                 pw.fc_rows = torch.empty(pw.fc_src.numel(), dtype=torch.float32, device=dev)

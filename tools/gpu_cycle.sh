@@ -16,6 +16,8 @@ for w in $WHAT; do
            for tp in bf16x3 f16; do timeout 600 python bench.py --train --train-precision $tp --no-cpu-baseline > $OUT/train_$tp.json 2> $OUT/train_$tp.err; echo "train $tp rc=$?"; cat $OUT/train_$tp.json; done ;;
     offdist) timeout 900 python -m pytest tests/test_gpu_offdist.py -m gpu -q -s -k "trained or planted" > $OUT/pytest_offdist.log 2>&1; echo "pytest(offdist) rc=$?"; grep -E "^\[trained|passed|failed|FAILED|policy after|training losses|^E " $OUT/pytest_offdist.log | tail -30 ;;
     varlen) timeout 300 python tools/varlen_bench.py > $OUT/varlen.json 2> $OUT/varlen.err; echo "varlen rc=$?"; cat $OUT/varlen.json | cut -c1-400 ;;
+    lat) timeout 300 python tools/latency_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.txt
+         timeout 600 python -m pytest tests/test_gpu_edge_cases.py -m gpu -q -k "low_latency" 2>&1 | tail -3 ;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json | head -c 6000 ;;
     benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?"; cat $OUT/benchq.json | head -c 4000 ;;
     train) timeout 600 python bench.py --train --no-cpu-baseline > $OUT/train.json 2> $OUT/train.err; echo "train rc=$?"; cat $OUT/train.json
@@ -34,6 +36,7 @@ for w in $WHAT; do
     trainab) for i in 1 2; do for f in "" "--no-fuse-bn"; do echo "train_bench --grouped $f"; timeout 300 python tools/train_bench.py --grouped --steps 20 --warmup 5 $f 2>&1 | grep -v amdgpu.ids | tail -1; done; done | tee $OUT/train_ab.txt ;;
     traintests) timeout 1200 python -m pytest tests/test_gpu_train_parity.py tests/test_gpu_parity.py tests/test_gpu_bench_cli.py -m gpu -x -q -s > $OUT/pytest_train.log 2>&1; echo "pytest(train) rc=$?"; tail -15 $OUT/pytest_train.log ;;
     fwdstreams) timeout 300 python tools/train_fwd_streams.py 2>&1 | grep -v amdgpu.ids | tee $OUT/train_fwd_streams.txt ;;
+    pmc16) timeout 1500 tools/pmc_run.sh $TAG/pmc16 --train --train-precision f16 --repeats 0; python tools/pmc_train_summary.py $OUT/pmc16 > $OUT/pmc_train16_summary.md 2> $OUT/pmc_train16_summary.err; head -70 $OUT/pmc_train16_summary.md ;;
     pmc) timeout 1200 tools/pmc_run.sh $TAG/pmc --no-secondary; python tools/pmc_summary.py $OUT/pmc kernel 52 > $OUT/pmc_summary.md 2> $OUT/pmc_summary.err; head -60 $OUT/pmc_summary.md ;;
     *) echo "unknown step $w" ;;
   esac
