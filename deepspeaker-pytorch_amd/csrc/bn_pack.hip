@@ -86,10 +86,23 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float *x, const flo
                                                        const float *res, float *y, long long n_vec, int C,
                                                        int flags) {
     const int cvec = C >> 2;
+    // 256 threads, grid stride a multiple of 256: when C / 4 is a power of two dividing 256 (every layer of the network) a
+    // thread keeps ONE channel group for the whole pass -- table rows loaded once, no 64-bit modulo per vector (round 4:
+    // the per-vector `i % cvec` in 64-bit arithmetic was a third of the pass's instructions)
+    const bool fixed = (256 % cvec) == 0 && (cvec & (cvec - 1)) == 0;
+    const int c4f = threadIdx.x & (cvec - 1);
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+    if (fixed) {
+        sc = ((const f32x4 *)scale)[c4f];
+        sh = ((const f32x4 *)shift)[c4f];
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
-        const int c4 = (int)(i % cvec);
+        if (!fixed) {
+            const int c4 = (int)(i % cvec);
+            sc = ((const f32x4 *)scale)[c4];
+            sh = ((const f32x4 *)shift)[c4];
+        }
         f32x4 v = ((const f32x4 *)x)[i];
-        const f32x4 sc = ((const f32x4 *)scale)[c4], sh = ((const f32x4 *)shift)[c4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ds_bn_affine(v[j], sc[j], sh[j]);
         if (flags & DS_EPI_RESIDUAL) v += ((const f32x4 *)res)[i];
@@ -472,12 +485,12 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float *parti
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *gy, const float *z, const float *mean,
                                                            const float *invstd, const float *coef, float *gz,
                                                            long long n_vec, int C) {
-    const int cvec = C >> 2;
+    const int cvec = C >> 2;                    // a power of two dividing 256 (checked by the host): fixed channel group
+    const int c4 = threadIdx.x & (cvec - 1);
+    const f32x4 mu = ((const f32x4 *)mean)[c4], is = ((const f32x4 *)invstd)[c4];
+    const f32x4 k1 = ((const f32x4 *)coef)[c4], k2 = ((const f32x4 *)(coef + C))[c4],
+                k3 = ((const f32x4 *)(coef + 2 * C))[c4];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
-        const int c4 = (int)(i % cvec);
-        const f32x4 mu = ((const f32x4 *)mean)[c4], is = ((const f32x4 *)invstd)[c4];
-        const f32x4 k1 = ((const f32x4 *)coef)[c4], k2 = ((const f32x4 *)(coef + C))[c4],
-                    k3 = ((const f32x4 *)(coef + 2 * C))[c4];
         const f32x4 xh = (((const f32x4 *)z)[i] - mu) * is;
         ((f32x4 *)gz)[i] = k1 * (((const f32x4 *)gy)[i] - k2 - xh * k3);
     }
@@ -524,16 +537,18 @@ __global__ void __launch_bounds__(256) bn_member_sum_kernel(const float *ggamma_
 __global__ void __launch_bounds__(256) bn_bwd_apply_group_kernel(const float *gy, const float *z, const float *mean,
                                                                  const float *invstd, const float *coef, float *gz,
                                                                  long long n_vec_member, int G, int C) {
-    const int cvec = C >> 2;
-    const long long n_vec = n_vec_member * G;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
-        const int member = (int)(i / n_vec_member);
-        const int c4 = (int)(i % cvec);
+    const int cvec = C >> 2;                    // a power of two dividing 256 (checked by the host): fixed channel group
+    const int c4 = threadIdx.x & (cvec - 1);
+    for (int member = 0; member < G; ++member) {            // (no per-vector division: members are walked one by one)
         const float *mu_p = mean + (size_t)member * C, *is_p = invstd + (size_t)member * C, *cf = coef + (size_t)member * 3 * C;
         const f32x4 mu = ((const f32x4 *)mu_p)[c4], is = ((const f32x4 *)is_p)[c4];
         const f32x4 k1 = ((const f32x4 *)cf)[c4], k2 = ((const f32x4 *)(cf + C))[c4], k3 = ((const f32x4 *)(cf + 2 * C))[c4];
-        const f32x4 xh = (((const f32x4 *)z)[i] - mu) * is;
-        ((f32x4 *)gz)[i] = k1 * (((const f32x4 *)gy)[i] - k2 - xh * k3);
+        const size_t mbase = (size_t)member * (size_t)n_vec_member;
+        for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n_vec_member; v += (long long)gridDim.x * 256) {
+            const size_t i = mbase + (size_t)v;
+            const f32x4 xh = (((const f32x4 *)z)[i] - mu) * is;
+            ((f32x4 *)gz)[i] = k1 * (((const f32x4 *)gy)[i] - k2 - xh * k3);
+        }
     }
 }
 

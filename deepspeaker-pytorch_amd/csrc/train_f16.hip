@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256) bn_stats_f16_kernel(const h16 *z, float *
     if (p1 > n_pix) p1 = n_pix;
     f32x8 s1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (slot < slots)
+#pragma unroll 2
         for (long long p = p0 + slot; p < p1; p += slots) {
             const f32x8 v = ld8(z, (size_t)p * cvec + cg);
             s1 += v;
@@ -138,27 +139,35 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_group_kernel(const floa
     }
 }
 
+// Element-wise passes walk [G members][n_vec_member] 8-channel vectors.  256 threads per workgroup and a channel-group
+// count that divides 256 (C / 8 = 8 .. 64): with every workgroup starting at a multiple of 256 vectors inside a member, a
+// thread keeps ONE channel group for the whole pass -- its table rows are loaded once per member, and the loop carries
+// no division (the first build computed member = i / n and c = i % (C/8) in 64-bit arithmetic per vector: the passes ran
+// at 2.4 - 2.9 TB/s with the wave-cycle counters showing waits on instruction issue, not on memory).
 // y = clip(z * scale[m] + shift[m] (+ residual)), fp16 in; fp16 or f32 out
 template <bool OUT32>
 __global__ void __launch_bounds__(256) bn_apply_f16_kernel(const h16 *z, const float *scale_t, const float *shift_t,
                                                            const h16 *res, void *y, long long n_vec_member, int G, int C,
                                                            int flags) {
     const int cvec = C >> 3;
-    const long long n_vec = n_vec_member * G;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
-        const int member = (int)(i / n_vec_member);
-        const int c8 = (int)(i % cvec);
+    const int c8 = threadIdx.x & (cvec - 1);                // (cvec is a power of two dividing 256: checked by the host)
+    const bool with_res = (flags & DS_EPI_RESIDUAL) != 0;
+    const float lo = (flags & DS_EPI_CLIP) ? 0.0f : -__builtin_inff(), hi = (flags & DS_EPI_CLIP) ? 20.0f : __builtin_inff();
+    for (int member = 0; member < G; ++member) {
         const f32x8 sc = ld8f(scale_t + (size_t)member * C, c8), sh = ld8f(shift_t + (size_t)member * C, c8);
-        f32x8 v = ld8(z, (size_t)i);
+        const size_t mbase = (size_t)member * (size_t)n_vec_member;
+#pragma unroll 2
+        for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n_vec_member; v += (long long)gridDim.x * 256) {
+            const size_t i = mbase + (size_t)v;
+            f32x8 t = ld8(z, i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ds_bn_affine(v[j], sc[j], sh[j]);
-        if (flags & DS_EPI_RESIDUAL) v += ld8(res, (size_t)i);
-        if (flags & DS_EPI_CLIP) {
+            for (int j = 0; j < 8; ++j) t[j] = ds_bn_affine(t[j], sc[j], sh[j]);
+            if (with_res) t += ld8(res, i);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j], 0.0f), 20.0f);
+            for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(t[j], lo), hi);
+            if constexpr (OUT32) st8f((float *)y, i, t);
+            else st8((h16 *)y, i, t);
         }
-        if constexpr (OUT32) st8f((float *)y, (size_t)i, v);
-        else st8((h16 *)y, (size_t)i, v);
     }
 }
 
@@ -171,15 +180,15 @@ __global__ void __launch_bounds__(256) bn_apply_f16_kernel(const h16 *z, const f
 // PARITY: g1 is the output of the 5x5 stride-2 data gradient run as ONE 3x3 convolution with 4 C output channels
 // (ds_pack_conv_weight_dgrad_f16, stride 2): [B][Ho2][Wo2][2][2][C] -- pixel (h, w) of this layer's [H][W] map is parity
 // class (h & 1, w & 1) of cell (h >> 1, w >> 1).
-struct BwdGeom { long long n_pix, img_pix; int W, Ho2, Wo2, cvec; };
+struct BwdGeom { long long n_pix; int img_pix; int W, Ho2, Wo2, cvec; float rcp_img, rcp_w; };
 template <int MODE, bool PARITY, bool ACT32>
 __device__ __forceinline__ f32x8 masked_grad(const h16 *g1, const h16 *g2, const void *act, const f32x8 &zv, const f32x8 &msc,
                                              const f32x8 &msh, size_t i, long long gp, int cg, const BwdGeom &q) {
     f32x8 g;
-    if constexpr (PARITY) {
-        const long long b = gp / q.img_pix;
-        const int rem = (int)(gp - b * q.img_pix);
-        const int h = rem / q.W, w = rem - h * q.W;
+    if constexpr (PARITY) {                     // (pixel indices stay below 2^24: reciprocal division, ds_div_small)
+        const int b = ds_div_small((int)gp, q.img_pix, q.rcp_img);
+        const int rem = (int)gp - b * q.img_pix;
+        const int h = ds_div_small(rem, q.W, q.rcp_w), w = rem - h * q.W;
         const size_t cell = ((size_t)b * q.Ho2 + (h >> 1)) * q.Wo2 + (w >> 1);
         g = ld8(g1, (cell * 4 + (size_t)((h & 1) * 2 + (w & 1))) * q.cvec + cg);
     } else {
@@ -219,7 +228,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_f16_kernel(const h16 *g1, c
     const long long p0 = (long long)mblock * pix_per_block;
     long long p1 = p0 + pix_per_block;
     if (p1 > n_pix) p1 = n_pix;
-    const BwdGeom q = {n_pix, (long long)H * W, W, (H + 1) >> 1, (W + 1) >> 1, cvec};
+    const BwdGeom q = {n_pix, H * W, W, (H + 1) >> 1, (W + 1) >> 1, cvec, 1.0f / (float)(H * W), 1.0f / (float)W};
     f32x8 s1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (slot < slots) {
         const f32x8 mu = ld8f(mean + (size_t)member * C, cg), is = ld8f(invstd + (size_t)member * C, cg);
@@ -228,6 +237,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_f16_kernel(const h16 *g1, c
             msc = ld8f(msc_t + (size_t)member * C, cg);
             msh = ld8f(msh_t + (size_t)member * C, cg);
         }
+#pragma unroll 2
         for (long long p = p0 + slot; p < p1; p += slots) {
             const size_t i = moff8 + (size_t)p * cvec + cg;                 // 8-channel index in the [G * n_pix][C] tensors
             const f32x8 zv = ld8(z, i);
@@ -298,23 +308,28 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_f16_kernel(const h16 *gy, co
                                                                const float *msh_t, h16 *gz, long long n_vec_member, int G,
                                                                int C) {
     const int cvec = C >> 3;
-    const long long n_vec = n_vec_member * G;
-    const BwdGeom q = {0, 1, 1, 1, 1, cvec};
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
-        const int member = (int)(i / n_vec_member);
-        const int c8 = (int)(i % cvec);
+    const int c8 = threadIdx.x & (cvec - 1);
+    const BwdGeom q = {0, 1, 1, 1, 1, cvec, 1.0f, 1.0f};
+    const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int member = 0; member < G; ++member) {
         const float *cf = coef + (size_t)member * 3 * C;
         const f32x8 mu = ld8f(mean_t + (size_t)member * C, c8), is = ld8f(invstd_t + (size_t)member * C, c8);
         const f32x8 k1 = ld8f(cf, c8), k2 = ld8f(cf + C, c8), k3 = ld8f(cf + 2 * C, c8);
-        const f32x8 zv = ld8(z, (size_t)i);
-        f32x8 g;
+        f32x8 msc = zero8, msh = zero8;
         if constexpr (REGEN) {
-            const f32x8 msc = ld8f(msc_t + (size_t)member * C, c8), msh = ld8f(msh_t + (size_t)member * C, c8);
-            g = masked_grad<2, false, false>(gy, nullptr, nullptr, zv, msc, msh, (size_t)i, 0, c8, q);
-        } else {
-            g = ld8(gy, (size_t)i);
+            msc = ld8f(msc_t + (size_t)member * C, c8);
+            msh = ld8f(msh_t + (size_t)member * C, c8);
         }
-        st8(gz, (size_t)i, k1 * (g - k2 - ((zv - mu) * is) * k3));
+        const size_t mbase = (size_t)member * (size_t)n_vec_member;
+#pragma unroll 2
+        for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n_vec_member; v += (long long)gridDim.x * 256) {
+            const size_t i = mbase + (size_t)v;
+            const f32x8 zv = ld8(z, i);
+            f32x8 g;
+            if constexpr (REGEN) g = masked_grad<2, false, false>(gy, nullptr, nullptr, zv, msc, msh, i, 0, c8, q);
+            else g = ld8(gy, i);
+            st8(gz, i, k1 * (g - k2 - ((zv - mu) * is) * k3));
+        }
     }
 }
 
@@ -329,7 +344,8 @@ static int tf_grid(long long n) {
 }
 
 static bool tf_shape_ok(long long n_pix, int C, int G) {
-    return n_pix > 0 && G > 0 && G <= 64 && C >= 8 && (C % 8) == 0 && C <= 1024 && 256 % (C / 8) == 0;
+    const int cvec = C / 8;
+    return n_pix > 0 && G > 0 && G <= 64 && C >= 8 && (C % 8) == 0 && C <= 1024 && 256 % cvec == 0 && (cvec & (cvec - 1)) == 0;
 }
 
 // partial rows (= workgroups) per member of the reductions: ~8 pixel steps per thread, at most TF_MAX_ROWS
@@ -399,10 +415,10 @@ extern "C" int ds_bn_apply_group_f16(const void *z_f16, const float *scale_t, co
                DS_ERR_ALIGNMENT);
     const long long nvm = n_pix * (C / 8);
     if (flags & DS_EPI_OUT_F32)
-        DS_LAUNCH(bn_apply_f16_kernel<true>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)z_f16, scale_t, shift_t,
+        DS_LAUNCH(bn_apply_f16_kernel<true>, tf_grid(nvm), 256, 0, stream, (const h16 *)z_f16, scale_t, shift_t,
                   (const h16 *)res_f16, y, nvm, G, C, flags);
     else
-        DS_LAUNCH(bn_apply_f16_kernel<false>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)z_f16, scale_t, shift_t,
+        DS_LAUNCH(bn_apply_f16_kernel<false>, tf_grid(nvm), 256, 0, stream, (const h16 *)z_f16, scale_t, shift_t,
                   (const h16 *)res_f16, y, nvm, G, C, flags);
     return ds_last_launch_error();
 }
@@ -421,7 +437,8 @@ static int bwd_reduce_f16(const void *g1, int g1_parity, const void *g2, const v
                           void *stream) {
     DS_REQUIRE(g1 && z && mean_t && invstd_t && partial, DS_ERR_NULL);
     DS_REQUIRE(tf_shape_ok(n_pix, C, G), DS_ERR_BAD_SHAPE);
-    DS_REQUIRE(!g1_parity || (H > 0 && W > 0 && (n_pix * G) % ((long long)H * W) == 0), DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(!g1_parity || (H > 0 && W > 0 && (n_pix * G) % ((long long)H * W) == 0 && n_pix * G < (1ll << 24)),
+               DS_ERR_BAD_SHAPE);
     DS_REQUIRE((mask_scale_t == nullptr) == (mask_shift_t == nullptr), DS_ERR_NULL);
     DS_REQUIRE(!(act && mask_scale_t), DS_ERR_UNSUPPORTED);
     const bool maskz = mask_scale_t != nullptr;
@@ -451,10 +468,10 @@ static int bwd_apply_f16(const void *gy_or_g1, bool regen, const void *z, const 
     DS_REQUIRE(DS_ALIGNED16(gy_or_g1) && DS_ALIGNED16(gz) && DS_ALIGNED16(coef), DS_ERR_ALIGNMENT);
     const long long nvm = n_pix * (C / 8);
     if (!regen)
-        DS_LAUNCH(bn_bwd_apply_f16_kernel<false>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy_or_g1, (const h16 *)z, mean_t,
+        DS_LAUNCH(bn_bwd_apply_f16_kernel<false>, tf_grid(nvm), 256, 0, stream, (const h16 *)gy_or_g1, (const h16 *)z, mean_t,
                   invstd_t, coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
     else
-        DS_LAUNCH(bn_bwd_apply_f16_kernel<true>, tf_grid(nvm * G), 256, 0, stream, (const h16 *)gy_or_g1, (const h16 *)z, mean_t,
+        DS_LAUNCH(bn_bwd_apply_f16_kernel<true>, tf_grid(nvm), 256, 0, stream, (const h16 *)gy_or_g1, (const h16 *)z, mean_t,
                   invstd_t, coef, mask_scale_t, mask_shift_t, (h16 *)gz, nvm, G, C);
     return ds_last_launch_error();
 }

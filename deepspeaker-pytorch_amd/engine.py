@@ -281,12 +281,12 @@ class Engine:
         return (y, stats) if want_stats else y
 
     def conv_f16(self, x: torch.Tensor, w_f16: torch.Tensor, B: int, H: int, W: int, cin: int, cout: int, ks: int,
-                 stride: int, scale=None, shift=None, residual=None, flags: int = 0):
+                 stride: int, scale=None, shift=None, residual=None, flags: int = 0, out=None):
         """Forward convolution on the fp16 matrix cores: fp16 channels-last in, fp16 out (f32 with DS_EPI_OUT_F32)."""
         shp = ConvShape(B, H, W, cin, cout, ks, stride)
         ho, wo = conv_out(H, ks, stride), conv_out(W, ks, stride)
-        y = torch.empty((B, ho, wo, cout), dtype=torch.float32 if flags & DS_EPI_OUT_F32 else torch.float16,
-                        device=x.device)
+        y = out if out is not None else torch.empty((B, ho, wo, cout), dtype=torch.float32 if flags & DS_EPI_OUT_F32
+                                                    else torch.float16, device=x.device)
         prof = self.profile is not None and x.is_cuda
         if prof:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

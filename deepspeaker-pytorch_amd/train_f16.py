@@ -36,7 +36,7 @@ from .engine import ALPHA, BN_EPS, BN_MOMENTUM, L2_EPS, STAGE_CHANNELS, BNParams
 DEFAULT_LOSS_SCALE = 1024.0
 
 
-def _bn_stats(eng: Engine, z16: torch.Tensor, bn: BNParams, G: int, update_running: bool = True, reducer=None):
+def _bn_stats(eng: Engine, z16: torch.Tensor, bn: BNParams, G: int, update_running: bool = True, reducer=None, tables=None):
     """[G][C] tables (mean, invstd, scale, shift) of a train-mode BatchNorm over the G members of z16 [B,h,w,C] fp16.
     With an active `reducer` (data parallelism) the members' float64 sums travel in ONE all-reduce, so every rank
     normalises with the statistics of the global batch."""
@@ -44,7 +44,8 @@ def _bn_stats(eng: Engine, z16: torch.Tensor, bn: BNParams, G: int, update_runni
     n_pix = (z16.numel() // c) // G
     rows = eng.lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
     partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=z16.device)
-    tables = torch.empty((4, G, c), dtype=torch.float32, device=z16.device)
+    if tables is None:
+        tables = torch.empty((4, G, c), dtype=torch.float32, device=z16.device)
     st = eng._stream(z16)
     if reducer is not None and reducer.active:
         sums = torch.empty((G, 2 * c + 1), dtype=torch.float64, device=z16.device)
@@ -64,10 +65,11 @@ def _bn_stats(eng: Engine, z16: torch.Tensor, bn: BNParams, G: int, update_runni
     return tables
 
 
-def _bn_apply(eng: Engine, z16, tables, residual16, G: int, flags: int):
+def _bn_apply(eng: Engine, z16, tables, residual16, G: int, flags: int, out=None):
     c = z16.shape[-1]
     n_pix = (z16.numel() // c) // G
-    y = torch.empty(z16.shape, dtype=torch.float32 if flags & DS_EPI_OUT_F32 else torch.float16, device=z16.device)
+    y = out if out is not None else torch.empty(z16.shape, dtype=torch.float32 if flags & DS_EPI_OUT_F32 else torch.float16,
+                                                device=z16.device)
     eng.lib.call("ds_bn_apply_group_f16", eng._p(z16), eng._p(tables[2]), eng._p(tables[3]), eng._p(residual16), eng._p(y),
                  n_pix, c, G, flags, eng._stream(z16))
     return y
@@ -97,6 +99,9 @@ def forward_train_group_f16(eng: Engine, xs: List[torch.Tensor], pw: PackedWeigh
         x = torch.as_strided(xs[0], (B, 1, T, F), xs[0].stride())
     else:
         x = torch.cat(xs)
+    dp = reducer is not None and reducer.active
+    if MEMBER_STREAMS and save and x.is_cuda and G > 1 and not dp:
+        return _forward_streams_f16(eng, x, G, pw, bns, save)
     saved = SavedForward(x=x) if save else None
     n_stages = len(pw.stages)
     h, w, cin = T, F, 1
@@ -127,6 +132,83 @@ def forward_train_group_f16(eng: Engine, xs: List[torch.Tensor], pw: PackedWeigh
         if save:
             saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, tb, a
             saved.dims.append((h, w))
+    e = eng.tail(a, pw, saved)
+    return [e[g * Bm:(g + 1) * Bm] for g in range(G)], saved
+
+
+MEMBER_STREAMS = True          # forward_train_group_f16 on a GPU, single process: one HIP stream per member (see below)
+_member_streams: Dict = {}
+
+
+def _forward_streams_f16(eng: Engine, x, G: int, pw: PackedWeights, bns: Dict[str, BNParams], save: bool):
+    """forward_train_group_f16 with every member's chain -- convolution, statistics, normalise + clip, layer after layer --
+    on a HIP stream of its own (the f32-class step's Engine._forward_train_group_streams, for the fp16 tensors): a layer is
+    a matrix-core-bound convolution followed by HBM-bound passes that need the member's statistics first, and in lock-step
+    over one batch the chip alternates between the two; members are independent until the loss, so on separate streams
+    one member's BatchNorm passes run next to another's convolution.  Same kernels on slices of the same buffers as the
+    lock-step form (per-member launches), the saved state is identical in layout; running statistics are updated in call
+    order: a member's statistics kernel waits for the previous member's of the same layer."""
+    B, _, T, F = x.shape
+    Bm = B // G
+    dev = x.device
+    cur = torch.cuda.current_stream(dev)
+    key = (dev, G)
+    if key not in _member_streams:
+        _member_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(G)]
+    streams = _member_streams[key]
+    saved = SavedForward(x=x) if save else None
+    for st in streams:
+        st.wait_stream(cur)
+    n_stages = len(pw.stages)
+
+    def m(t, g):
+        return t[g * Bm:(g + 1) * Bm]
+
+    def layer(src, name, kind, bank, hh, ww, ci, co, residual, last):
+        """one convolution + BatchNorm(train) + clip layer of all members; returns (z, a, tables, ho, wo)"""
+        ks, stride = (5, 2) if kind != "3x3" else (3, 1)
+        ho, wo = conv_out(hh, ks, stride), conv_out(ww, ks, stride)
+        z = torch.empty((B, ho, wo, co), dtype=torch.float16, device=dev)           # allocated on the caller's stream
+        a = torch.empty((B, ho, wo, co), dtype=torch.float32 if last else torch.float16, device=dev)
+        tables = torch.empty((4, G, co), dtype=torch.float32, device=dev)
+        flags = DS_EPI_CLIP | (DS_EPI_RESIDUAL if residual is not None else 0) | (DS_EPI_OUT_F32 if last else 0)
+        prev_done = None
+        for g in range(G):
+            with torch.cuda.stream(streams[g]):
+                if kind == "c1":
+                    eng.conv1(m(src, g), bank, Bm, hh, ww, flags=DS_EPI_OUT_F16, lowp=True, out=m(z, g))
+                else:
+                    eng.conv_f16(m(src, g), bank, Bm, hh, ww, ci, co, ks, stride, out=m(z, g))
+                if prev_done is not None:
+                    streams[g].wait_event(prev_done)            # running statistics: a, then p, then n
+                _bn_stats(eng, m(z, g), bns[name], 1, tables=tables[:, g:g + 1])
+                prev_done = torch.cuda.Event()
+                prev_done.record(streams[g])
+                _bn_apply(eng, m(z, g), tables[:, g:g + 1], m(residual, g) if residual is not None else None, 1, flags,
+                          out=m(a, g))
+        return z, a, tables, ho, wo
+
+    h, w, cin = T, F, 1
+    a = x
+    for s_, sw in enumerate(pw.stages):
+        i, c = s_ + 1, STAGE_CHANNELS[s_]
+        last = s_ == n_stages - 1
+        name = f"model.bn{i}"
+        z, a, tb, h, w = layer(a, name, "c1" if i == 1 else "5x5", sw.conv if i == 1 else sw.conv_f16, h, w, cin, c, None, False)
+        cin = c
+        if save:
+            saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, tb, a
+        name = f"model.layer{i}.0.bn1"
+        z, y, tb, _, _ = layer(a, name, "3x3", sw.l_conv1_f16, h, w, c, c, None, False)
+        if save:
+            saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, tb, y
+        name = f"model.layer{i}.0.bn2"
+        z, a, tb, _, _ = layer(y, name, "3x3", sw.l_conv2_f16, h, w, c, c, a, last)
+        if save:
+            saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, tb, a
+            saved.dims.append((h, w))
+    for st in streams:
+        cur.wait_stream(st)
     e = eng.tail(a, pw, saved)
     return [e[g * Bm:(g + 1) * Bm] for g in range(G)], saved
 
