@@ -14,6 +14,7 @@
 // statistics: member m owns pixels [m * n_pix, (m + 1) * n_pix) and row m of every [G][C] table.
 #include <ds_device.h>
 #include "ds_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -339,8 +340,14 @@ __global__ void __launch_bounds__(256) scale_cast_f16_kernel(const float *x, h16
 }
 
 static int tf_grid(long long n) {
+    static int cap = 0;
+    if (cap == 0) {                             // DS_TF_GRID: experiment knob (tools/bn16_probe.py)
+        const char *e = getenv("DS_TF_GRID");
+        cap = e ? atoi(e) : 8192;
+        if (cap < 1) cap = 8192;
+    }
     long long g = (n + 255) / 256;
-    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
 static bool tf_shape_ok(long long n_pix, int C, int G) {
