@@ -265,17 +265,15 @@ class _FilterGradLane:
             self.side = side
             side.wait_stream(self.main)
 
-    def run(self, fn, *inputs, after=None):
-        """fn() on the side stream, ordered after everything enqueued on the main stream so far (and after the events
-        `after`: producers on other streams); `inputs` are the tensors it reads.  They are kept alive until join() --
-        after which the main stream is ordered behind the side stream, so their memory can be recycled the ordinary way.
-        (Tensor.record_stream instead made the caching allocator hold every such block back until the side stream had
-        caught up: 54 GiB reserved for a 14 GiB working set.)"""
+    def run(self, fn, *inputs):
+        """fn() on the side stream, ordered after everything enqueued on the main stream so far; `inputs` are the
+        main-stream tensors it reads.  They are kept alive until join() -- after which the main stream is ordered
+        behind the side stream, so their memory can be recycled the ordinary way.  (Tensor.record_stream instead
+        made the caching allocator hold every such block back until the side stream had caught up: 54 GiB reserved
+        for a 14 GiB working set.)"""
         if self.side is None:
             return fn()
         self.side.wait_event(self.main.record_event())
-        for ev in (after or ()):
-            self.side.wait_event(ev)
         self.keep.extend(t for t in inputs if t is not None)
         with torch.cuda.stream(self.side):
             return fn()

@@ -136,7 +136,10 @@ def forward_train_group_f16(eng: Engine, xs: List[torch.Tensor], pw: PackedWeigh
     return [e[g * Bm:(g + 1) * Bm] for g in range(G)], saved
 
 
-MEMBER_STREAMS = True          # forward_train_group_f16 on a GPU, single process: one HIP stream per member (see below)
+import os as _os
+
+# forward_train_group_f16 on a GPU, single process: one HIP stream per member (see below); DS_F16_MEMBER_STREAMS=0 for A/B runs
+MEMBER_STREAMS = _os.environ.get("DS_F16_MEMBER_STREAMS", "1") != "0"
 _member_streams: Dict = {}
 
 
@@ -266,98 +269,16 @@ def _wgrad_c1(eng: Engine, shp: ConvShape, x32, gz16, out, inv_scale: float):
     return out
 
 
-class _Chain:
-    """How the backward pass's main chain -- BatchNorm backward, data-gradient convolution, layer after layer -- is issued:
-    over the whole batch on the caller's stream, or (single process, G > 1 members on a GPU) every MEMBER's chain on a
-    HIP stream of its own.  The members are independent until the parameter gradients: one member's BatchNorm passes
-    (HBM-bound) then run next to another's data-gradient convolution (matrix-core-bound), as the forward's member streams
-    do (`_forward_streams_f16`).  Same kernels on slices of the same buffers: gy / gz / data gradients are bitwise the
-    one-stream pass's; dgamma / dbeta are the members' sums added by a fixed-order column sum instead of inside the fold
-    kernel (last-bit differences).  Every tensor the member streams touch stays alive until `join()`."""
-
-    def __init__(self, eng: Engine, device, G: int, Bm: int, enabled: bool):
-        self.eng, self.G, self.Bm = eng, G, Bm
-        self.streams = None
-        self.keep = []
-        self.pending = []               # (member sums [2][G][C], dgamma, dbeta): folded after the join
-        if enabled and device.type == "cuda" and G > 1:
-            key = (device, G)
-            if key not in _member_streams:
-                _member_streams[key] = [torch.cuda.Stream(device=device) for _ in range(G)]
-            self.streams = _member_streams[key]
-            self.cur = torch.cuda.current_stream(device)
-            for st in self.streams:
-                st.wait_stream(self.cur)
-
-    def _m(self, t, g):
-        return None if t is None else t[g * self.Bm:(g + 1) * self.Bm]
-
-    def bn_bwd(self, g1, g1_parity, g2, act, z16, tables, gamma, hw, inv, mask_from_z=False, want_gy=True, reducer=None):
-        """-> (gy or None, gz, dgamma, dbeta, events after which gz is complete or None)"""
-        if self.streams is None:
-            gy, gz, gg, gb = _bn_bwd(self.eng, g1, g1_parity, g2, act, z16, tables, gamma, self.G, hw, inv, mask_from_z, want_gy,
-                                     reducer)
-            return gy, gz, gg, gb, None
-        eng, G = self.eng, self.G
-        c = z16.shape[-1]
-        dev = z16.device
-        n_pix = (z16.numel() // c) // G
-        rows = eng.lib.raw("ds_bn_f16_partial_rows")(n_pix, c)
-        gz = torch.empty_like(z16)
-        gy = torch.empty_like(z16) if want_gy else None
-        partial = torch.empty((G, rows, c, 2), dtype=torch.float32, device=dev)
-        coef = torch.empty((G, 3 * c), dtype=torch.float32, device=dev)
-        msums = torch.empty((2, G, c), dtype=torch.float32, device=dev)
-        gg, gb = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
-        self.keep += [g1, g2, act, z16, gz, gy, partial, coef, msums, tables]
-        act32 = int(act is not None and act.dtype == torch.float32)
-        events = []
-        for g in range(G):
-            with torch.cuda.stream(self.streams[g]):
-                eng.lib.call("ds_bn_bwd_group_f16", eng._p(self._m(g1, g)), int(g1_parity), eng._p(self._m(g2, g)),
-                             None if mask_from_z else eng._p(self._m(act, g)), act32,
-                             eng._p(tables[2][g]) if mask_from_z else None, eng._p(tables[3][g]) if mask_from_z else None,
-                             eng._p(self._m(z16, g)), eng._p(tables[0][g]), eng._p(tables[1][g]), eng._p(gamma.detach()),
-                             eng._p(self._m(gy, g)), eng._p(partial[g]), eng._p(coef[g]), eng._p(msums[0][g]), eng._p(msums[1][g]),
-                             eng._p(self._m(gz, g)), n_pix, hw[0], hw[1], c, 1, float(inv), eng._stream(z16))
-                ev = torch.cuda.Event()
-                ev.record(self.streams[g])
-                events.append(ev)
-        self.pending.append((msums, gg, gb))
-        return gy, gz, gg, gb, events
-
-    def conv(self, x16, bank, B, h, w, cin, cout):
-        """3x3 stride-1 fp16 convolution of the whole batch (per member on its stream)"""
-        if self.streams is None:
-            return self.eng.conv_f16(x16, bank, B, h, w, cin, cout, 3, 1)
-        y = torch.empty((B, h, w, cout), dtype=torch.float16, device=x16.device)
-        self.keep += [x16, y]
-        for g in range(self.G):
-            with torch.cuda.stream(self.streams[g]):
-                self.eng.conv_f16(self._m(x16, g), bank, self.Bm, h, w, cin, cout, 3, 1, out=self._m(y, g))
-        return y
-
-    def join(self):
-        if self.streams is not None:
-            for st in self.streams:
-                self.cur.wait_stream(st)
-            eng = self.eng
-            for msums, gg, gb in self.pending:          # dgamma / dbeta: the members' sums, added in member order
-                G, c = msums.shape[1], msums.shape[2]
-                eng.lib.call("ds_colsum_f32", eng._p(msums[0]), eng._p(gg), G, c, eng._stream(gg))
-                eng.lib.call("ds_colsum_f32", eng._p(msums[1]), eng._p(gb), G, c, eng._stream(gg))
-            self.pending = []
-        self.keep = []
-
-
 def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
                        ge: torch.Tensor, loss_scale: float = DEFAULT_LOSS_SCALE,
                        overlap_filter_gradients=None, reducer=None, reduce_gradients: bool = False) -> Dict[str, torch.Tensor]:
     """Parameter gradients (reference key names and shapes, f32, un-scaled) given dL/d(embedding) `ge` [B,512] f32, from
     the fp16 tensors `forward_train_group_f16` saved.  Filter gradients run on the second stream like the f32-class
-    pass's (backward._FilterGradLane); the main chain runs per member on the members' streams (`_Chain`) unless data
-    parallel.  `reducer` / `reduce_gradients` (data parallelism): global BatchNorm sums (one all-reduce per layer) and
-    the per-stage f32 gradient buckets summed over the ranks, as backward.backward_train does."""
+    pass's (backward._FilterGradLane); the main chain stays on ONE stream over the whole batch (measured: every member's
+    BatchNorm-backward / data-gradient chain on a stream of its own, as the forward does, is bitwise the same and SLOWER --
+    9.9 against 8.9 ms per step: three times the launches, and 256-utterance convolutions fill the persistent grids
+    worse than one 768-utterance launch).  `reducer` / `reduce_gradients` (data parallelism): global BatchNorm sums (one
+    all-reduce per layer) and the per-stage f32 gradient buckets summed over the ranks, as backward.backward_train does."""
     from .backward import OVERLAP_FILTER_GRADIENTS, _FilterGradLane, _GradBuckets, _wgrad as _wgrad_f32
     lib = eng.lib
     lane = _FilterGradLane(ge.device, OVERLAP_FILTER_GRADIENTS if overlap_filter_gradients is None else overlap_filter_gradients)
@@ -398,8 +319,6 @@ def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: Pac
     lib.call("ds_avgpool_time_bwd_f32", eng._p(gpooled), eng._p(out), eng._p(g32), B, hr, wc, c, st)
     g = torch.empty(out.shape, dtype=torch.float16, device=out.device)
     lib.call("ds_scale_cast_f32_to_f16", eng._p(g32), eng._p(g), g32.numel(), float(loss_scale), st)
-    dp = reducer is not None and reducer.active
-    chain = _Chain(eng, ge.device, G, B // G, MEMBER_STREAMS and not dp)         # forks AFTER the tail above
     g_parity, g_masked = False, True
     for s in reversed(range(n_stages)):
         i, c = s + 1, STAGE_CHANNELS[s]
@@ -410,41 +329,40 @@ def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: Pac
         shp3 = ConvShape(B, h, w, c, c, 3, 1)
         # out = clip(bn2(conv2(y)) + r)            (model.py:73-80)
         name = f"model.layer{i}.0.bn2"
-        g_out, gz, gg, gbeta, evs = chain.bn_bwd(g, g_parity, None, None if g_masked else c_act, saved.raws[name],
-                                                 saved.stats[name], bn_weights[name], (h, w), inv, reducer=reducer)
+        g_out, gz, gg, gbeta = _bn_bwd(eng, g, g_parity, None, None if g_masked else c_act, saved.raws[name],
+                                       saved.stats[name], bn_weights[name], G, (h, w), inv, reducer=reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv2.weight"] = lane.run(
-            lambda gz=gz: _wgrad(eng, shp3, b_act, gz, buckets.views[f"model.layer{i}.0.conv2.weight"], inv), gz, after=evs)
+            lambda gz=gz: _wgrad(eng, shp3, b_act, gz, buckets.views[f"model.layer{i}.0.conv2.weight"], inv), gz)
         # y = clip(bn1(conv1(r)))                  (model.py:69-71)
         name = f"model.layer{i}.0.bn1"
-        g_y = chain.conv(gz, sw.l_conv2_dgrad_f16, B, h, w, c, c)
+        g_y = eng.conv_f16(gz, sw.l_conv2_dgrad_f16, B, h, w, c, c, 3, 1)
         # (no residual was added before this clip: its mask is re-derived from z; nobody else needs the masked gradient)
-        _, gz, gg, gbeta, evs = chain.bn_bwd(g_y, False, None, None, saved.raws[name], saved.stats[name], bn_weights[name],
-                                             (h, w), inv, mask_from_z=True, want_gy=False, reducer=reducer)
+        _, gz, gg, gbeta = _bn_bwd(eng, g_y, False, None, None, saved.raws[name], saved.stats[name], bn_weights[name], G,
+                                   (h, w), inv, mask_from_z=True, want_gy=False, reducer=reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         grads[f"model.layer{i}.0.conv1.weight"] = lane.run(
-            lambda gz=gz: _wgrad(eng, shp3, a_act, gz, buckets.views[f"model.layer{i}.0.conv1.weight"], inv), gz, after=evs)
+            lambda gz=gz: _wgrad(eng, shp3, a_act, gz, buckets.views[f"model.layer{i}.0.conv1.weight"], inv), gz)
         # r = clip(bn_i(conv_i(x)));  dL/dr = conv path + residual path   (model.py:187-189, 67, 79)
         name = f"model.bn{i}"
-        g_r = chain.conv(gz, sw.l_conv1_dgrad_f16, B, h, w, c, c)
-        _, gz, gg, gbeta, evs = chain.bn_bwd(g_r, False, g_out, None, saved.raws[name], saved.stats[name], bn_weights[name],
-                                             (h, w), inv, mask_from_z=True, reducer=reducer)
+        g_r = eng.conv_f16(gz, sw.l_conv1_dgrad_f16, B, h, w, c, c, 3, 1)
+        _, gz, gg, gbeta = _bn_bwd(eng, g_r, False, g_out, None, saved.raws[name], saved.stats[name], bn_weights[name], G,
+                                   (h, w), inv, mask_from_z=True, reducer=reducer)
         grads[name + ".weight"], grads[name + ".bias"] = gg, gbeta
         h_in, w_in = (saved.x.shape[2], saved.x.shape[3]) if s == 0 else saved.dims[s - 1]
         shp5 = ConvShape(B, h_in, w_in, cin, c, 5, 2)
         if s == 0:
             grads["model.conv1.weight"] = lane.run(
-                lambda gz=gz: _wgrad_c1(eng, shp5, saved.x, gz, buckets.views["model.conv1.weight"], inv), gz, after=evs)
+                lambda gz=gz: _wgrad_c1(eng, shp5, saved.x, gz, buckets.views["model.conv1.weight"], inv), gz)
         else:
             x_in = saved.acts[f"stage{s}.c"]
             grads[f"model.conv{i}.weight"] = lane.run(
-                lambda gz=gz, x_in=x_in: _wgrad(eng, shp5, x_in, gz, buckets.views[f"model.conv{i}.weight"], inv), gz, after=evs)
+                lambda gz=gz, x_in=x_in: _wgrad(eng, shp5, x_in, gz, buckets.views[f"model.conv{i}.weight"], inv), gz)
             # dL/d(stage-below output): ONE 3x3 convolution over dL/dz whose 4 cin output channels are the parity classes
             # of the stride-2 data gradient; the layer below reads that layout in place and masks it itself
-            g = chain.conv(gz, sw.conv_dgrad_f16, B, h, w, c, 4 * cin)
+            g = eng.conv_f16(gz, sw.conv_dgrad_f16, B, h, w, c, 4 * cin, 3, 1)
             g_parity, g_masked = True, False
         lane.run(lambda: buckets.done(s))       # this stage's three filter gradients are enqueued: reduce them now
-    chain.join()
     lane.join()
     buckets.finish()
     return grads

@@ -166,8 +166,8 @@ def test_fp16_training_converges_like_the_f32_class_step():
 
 
 def test_member_streams_forward_is_bitwise_the_lock_step_forward():
-    """train_f16._forward_streams_f16 / _Chain (one HIP stream per member, forward and backward) launch per member what the
-    lock-step pass launches over the whole batch: the fp16 convolution's results do not depend on the batch a row is in,
+    """train_f16._forward_streams_f16 (one HIP stream per member in the forward) launches per member what the lock-step
+    forward launches over the whole batch: the fp16 convolution's results do not depend on the batch a row is in,
     the statistics kernels fold the same rows in the same order -- embeddings, running statistics and filter / fc gradients
     must be BITWISE equal (which also makes this the race detector of the stream choreography), run after run."""
     import deepspeaker_pytorch_amd.train_f16 as TF
@@ -190,9 +190,4 @@ def test_member_streams_forward_is_bitwise_the_lock_step_forward():
         for k, v in res["lock_step"][2].items():
             assert torch.equal(v, res[other][2][k]), (other, k)
         for k, v in res["lock_step"][3].items():
-            if ".bn" in k and other == "streams":       # dgamma / dbeta: the members' sums added by a column sum, not in the fold
-                assert rel_l2(res[other][3][k], v) < 1e-6, (other, k)
-            elif ".bn" not in k:
-                assert torch.equal(v, res[other][3][k]), (other, k)
-    for k, v in res["streams"][3].items():              # ... and run after run the same bits
-        assert torch.equal(v, res["streams_again"][3][k]), k
+            assert torch.equal(v, res[other][3][k]), (other, k)

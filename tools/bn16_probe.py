@@ -52,7 +52,7 @@ def main():
         mb = n * 2 / 1e6                                        # MB per fp16 tensor pass
 
         def report(name, us, passes):
-            print(f"  [{h}x{w}x{c}] {name:34s} {us:8.1f} us  {passes} passes  {passes * mb / us * 1e-3:6.2f} TB/s")
+            print(f"  [{h}x{w}x{c}] {name:34s} {us:8.1f} us  {passes} passes  {passes * mb / us:6.2f} TB/s")
 
         report("stats (partials + fold)", timeit(lambda: eng.lib.call(
             "ds_bn_stats_group_f16", P(z), P(partial), n_pix, P(gamma), P(beta), 1e-5, 0.1, P(rm), P(rv), P(tables[0]), P(tables[1]),
