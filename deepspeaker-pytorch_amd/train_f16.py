@@ -79,7 +79,10 @@ def forward_train_group_f16(eng: Engine, xs: List[torch.Tensor], pw: PackedWeigh
                             save: bool = True, reducer=None):
     """The train-mode forwards of the G = len(xs) members in lock-step over one concatenated batch, fp16 tensors between
     the layers.  One convolution launch per layer over ALL members (the statistics are a separate pass, so tiles may
-    straddle members), one statistics launch pair, one normalise + clip launch.  `reducer` (data parallelism): one
+    straddle members), one statistics launch pair, one normalise + clip launch.  (Measured and dropped: one HIP stream per
+    member, as the f32-class forward runs -- bitwise the same results, 8.89 against 8.86 ms per step and 5.4 instead of 3.8
+    ms of host enqueue: the fp16 passes are short enough that three times the launches cost what the overlap gains; the
+    same for the backward chain, 9.9 ms.)  `reducer` (data parallelism): one
     float64 all-reduce per BatchNorm layer carrying all members' sums.  Returns ([embeddings per member],
     SavedForward with fp16 `raws` / `acts` -- the last stage's output is f32 -- and `stats[name]` = the [4][G][C] tables)."""
     G = len(xs)
@@ -99,9 +102,6 @@ def forward_train_group_f16(eng: Engine, xs: List[torch.Tensor], pw: PackedWeigh
         x = torch.as_strided(xs[0], (B, 1, T, F), xs[0].stride())
     else:
         x = torch.cat(xs)
-    dp = reducer is not None and reducer.active
-    if MEMBER_STREAMS and save and x.is_cuda and G > 1 and not dp:
-        return _forward_streams_f16(eng, x, G, pw, bns, save)
     saved = SavedForward(x=x) if save else None
     n_stages = len(pw.stages)
     h, w, cin = T, F, 1
@@ -132,86 +132,6 @@ def forward_train_group_f16(eng: Engine, xs: List[torch.Tensor], pw: PackedWeigh
         if save:
             saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, tb, a
             saved.dims.append((h, w))
-    e = eng.tail(a, pw, saved)
-    return [e[g * Bm:(g + 1) * Bm] for g in range(G)], saved
-
-
-import os as _os
-
-# forward_train_group_f16 on a GPU, single process: one HIP stream per member (see below); DS_F16_MEMBER_STREAMS=0 for A/B runs
-MEMBER_STREAMS = _os.environ.get("DS_F16_MEMBER_STREAMS", "1") != "0"
-_member_streams: Dict = {}
-
-
-def _forward_streams_f16(eng: Engine, x, G: int, pw: PackedWeights, bns: Dict[str, BNParams], save: bool):
-    """forward_train_group_f16 with every member's chain -- convolution, statistics, normalise + clip, layer after layer --
-    on a HIP stream of its own (the f32-class step's Engine._forward_train_group_streams, for the fp16 tensors): a layer is
-    a matrix-core-bound convolution followed by HBM-bound passes that need the member's statistics first, and in lock-step
-    over one batch the chip alternates between the two; members are independent until the loss, so on separate streams
-    one member's BatchNorm passes run next to another's convolution.  Same kernels on slices of the same buffers as the
-    lock-step form (per-member launches), the saved state is identical in layout; running statistics are updated in call
-    order: a member's statistics kernel waits for the previous member's of the same layer."""
-    B, _, T, F = x.shape
-    Bm = B // G
-    dev = x.device
-    cur = torch.cuda.current_stream(dev)
-    key = (dev, G)
-    if key not in _member_streams:
-        _member_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(G)]
-    streams = _member_streams[key]
-    saved = SavedForward(x=x) if save else None
-    for st in streams:
-        st.wait_stream(cur)
-    n_stages = len(pw.stages)
-
-    def m(t, g):
-        return t[g * Bm:(g + 1) * Bm]
-
-    def layer(src, name, kind, bank, hh, ww, ci, co, residual, last):
-        """one convolution + BatchNorm(train) + clip layer of all members; returns (z, a, tables, ho, wo)"""
-        ks, stride = (5, 2) if kind != "3x3" else (3, 1)
-        ho, wo = conv_out(hh, ks, stride), conv_out(ww, ks, stride)
-        z = torch.empty((B, ho, wo, co), dtype=torch.float16, device=dev)           # allocated on the caller's stream
-        a = torch.empty((B, ho, wo, co), dtype=torch.float32 if last else torch.float16, device=dev)
-        tables = torch.empty((4, G, co), dtype=torch.float32, device=dev)
-        flags = DS_EPI_CLIP | (DS_EPI_RESIDUAL if residual is not None else 0) | (DS_EPI_OUT_F32 if last else 0)
-        prev_done = None
-        for g in range(G):
-            with torch.cuda.stream(streams[g]):
-                if kind == "c1":
-                    eng.conv1(m(src, g), bank, Bm, hh, ww, flags=DS_EPI_OUT_F16, lowp=True, out=m(z, g))
-                else:
-                    eng.conv_f16(m(src, g), bank, Bm, hh, ww, ci, co, ks, stride, out=m(z, g))
-                if prev_done is not None:
-                    streams[g].wait_event(prev_done)            # running statistics: a, then p, then n
-                _bn_stats(eng, m(z, g), bns[name], 1, tables=tables[:, g:g + 1])
-                prev_done = torch.cuda.Event()
-                prev_done.record(streams[g])
-                _bn_apply(eng, m(z, g), tables[:, g:g + 1], m(residual, g) if residual is not None else None, 1, flags,
-                          out=m(a, g))
-        return z, a, tables, ho, wo
-
-    h, w, cin = T, F, 1
-    a = x
-    for s_, sw in enumerate(pw.stages):
-        i, c = s_ + 1, STAGE_CHANNELS[s_]
-        last = s_ == n_stages - 1
-        name = f"model.bn{i}"
-        z, a, tb, h, w = layer(a, name, "c1" if i == 1 else "5x5", sw.conv if i == 1 else sw.conv_f16, h, w, cin, c, None, False)
-        cin = c
-        if save:
-            saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.a"] = z, tb, a
-        name = f"model.layer{i}.0.bn1"
-        z, y, tb, _, _ = layer(a, name, "3x3", sw.l_conv1_f16, h, w, c, c, None, False)
-        if save:
-            saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.b"] = z, tb, y
-        name = f"model.layer{i}.0.bn2"
-        z, a, tb, _, _ = layer(y, name, "3x3", sw.l_conv2_f16, h, w, c, c, a, last)
-        if save:
-            saved.raws[name], saved.stats[name], saved.acts[f"stage{i}.c"] = z, tb, a
-            saved.dims.append((h, w))
-    for st in streams:
-        cur.wait_stream(st)
     e = eng.tail(a, pw, saved)
     return [e[g * Bm:(g + 1) * Bm] for g in range(G)], saved
 

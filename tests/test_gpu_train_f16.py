@@ -163,31 +163,3 @@ def test_fp16_training_converges_like_the_f32_class_step():
     d = np.abs(curves["f16"] - curves["bf16x3"]) / np.maximum(curves["bf16x3"], 5e-3)
     assert d[:5].max() < 0.05 and np.median(d) < 0.15          # chaotic beyond the first steps: hinge set changes
     assert curves["f16"][10:].mean() < curves["f16"][:10].mean()
-
-
-def test_member_streams_forward_is_bitwise_the_lock_step_forward():
-    """train_f16._forward_streams_f16 (one HIP stream per member in the forward) launches per member what the lock-step
-    forward launches over the whole batch: the fp16 convolution's results do not depend on the batch a row is in,
-    the statistics kernels fold the same rows in the same order -- embeddings, running statistics and filter / fc gradients
-    must be BITWISE equal (which also makes this the race detector of the stream choreography), run after run."""
-    import deepspeaker_pytorch_amd.train_f16 as TF
-    sd = O.make_state_dict(seed=31, num_classes=16)
-    xs = [torch.from_numpy(O.make_input(seed=32 + i, batch=48, frames=160)).cuda() for i in range(3)]
-    res = {}
-    try:
-        for mode in ("lock_step", "streams", "streams_again"):
-            TF.MEMBER_STREAMS = mode != "lock_step"
-            m = build(sd, 16)
-            loss, embs, _, grads, _ = hip_step(m, xs)
-            torch.cuda.synchronize()
-            res[mode] = (loss, embs, {k: v.clone() for k, v in m.state_dict().items()}, grads)
-    finally:
-        TF.MEMBER_STREAMS = True
-    for other in ("streams", "streams_again"):
-        assert res[other][0] == res["lock_step"][0]
-        for a, b in zip(res[other][1], res["lock_step"][1]):
-            assert torch.equal(a, b), other
-        for k, v in res["lock_step"][2].items():
-            assert torch.equal(v, res[other][2][k]), (other, k)
-        for k, v in res["lock_step"][3].items():
-            assert torch.equal(v, res[other][3][k]), (other, k)
