@@ -403,6 +403,7 @@ def main():
             refine = {"band": last[-1].band, "band_floor": REFINE_BAND, "band_observed_max": pol.err_max_window,
                       "band_observed_max_timed_steps": max(errs, default=None), "band_samples_total": pol.err_samples,
                       "band_violations_total": pol.band_violations,
+                      "embedding_error_observed": pol.embedding_error_observed,
                       "slots": [s_.amb_cap for s_ in last][-1], "near_ties_mean": round(sum(ties) / len(ties), 2),
                       "near_ties_max": max(ties), "overflow_steps": sum(int(s_.refine_overflow) for s_ in last),
                       "band_violation_steps": sum(int(s_.band_exceeded) for s_ in last),

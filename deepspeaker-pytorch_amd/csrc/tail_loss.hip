@@ -208,18 +208,33 @@ __global__ void __launch_bounds__(256) triplet_scan_kernel(const float *d_p, con
 // re-embedded at f32-class precision into e_ref rows (s, cap + s, 2 cap + s); its distances are replaced.
 // PROBES: with err != nullptr (ONE workgroup then) EVERY slot is live (the scan filled the unused ones with probe
 // triplets) and err[0] = the largest |(d_n - d_p)_f32-class - (d_n - d_p)_before| over all slots -- the error the fp16
-// forward made on the filter's decision variable, sampled on near ties and probes alike; err[1] = the slot count.
+// forward made on the filter's decision variable, sampled on near ties and probes alike; err[1] = the slot count;
+// and, given the fp16 path's own embeddings emb_a / emb_p / emb_n [N][D], err[2] = max |e_ref - emb| and err[3] =
+// max |e_ref| over the 3 * cap sampled rows (their ratio is the tests' embedding-error measure, max |d| / max |ref|, on
+// the sample: how the path watches its own distance to the 1e-3 contract).
 __global__ void __launch_bounds__(256) refine_distances_kernel(const float *e_ref, const long long *amb_idx,
                                                                const int *amb_count, int cap, float *d_p, float *d_n,
                                                                int D, float eps, float *err, const float *d_p0,
-                                                               const float *d_n0) {
+                                                               const float *d_n0, const float *emb_a, const float *emb_p,
+                                                               const float *emb_n) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int live_n = err ? cap : (amb_count[0] < cap ? amb_count[0] : cap);
-    float worst = 0.f;
+    float worst = 0.f, ediff = 0.f, emax = 0.f;
     for (int s = blockIdx.x * 4 + wave; s < cap; s += gridDim.x * 4) {
         const float *a = e_ref + (size_t)s * D, *p = e_ref + (size_t)(cap + s) * D, *n = e_ref + (size_t)(2 * cap + s) * D;
         const float sp = row_sqdist(a, p, D, lane);
         const float sn = row_sqdist(a, n, D, lane);
+        if (err && emb_a) {                     // (every slot is live here)
+            const long long i = amb_idx[s];
+            const float *r3[3] = {a, p, n}, *m3[3] = {emb_a + (size_t)i * D, emb_p + (size_t)i * D, emb_n + (size_t)i * D};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                for (int k = lane; k < D; k += 64) {
+                    const float rv = r3[t][k];
+                    ediff = fmaxf(ediff, fabsf(rv - m3[t][k]));
+                    emax = fmaxf(emax, fabsf(rv));
+                }
+        }
         if (s < live_n && lane == 0) {
             const long long i = amb_idx[s];
             const float dp = sqrtf(sp + eps), dn = sqrtf(sn + eps);
@@ -231,12 +246,23 @@ __global__ void __launch_bounds__(256) refine_distances_kernel(const float *e_re
         }
     }
     if (err) {                                  // gridDim.x == 1
-        float *scratch = ds_dynamic_lds();
-        if (lane == 0) scratch[wave] = worst;
+        float *scratch = ds_dynamic_lds();      // [3][4]
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {     // (lanes hold partial maxima of the embedding comparison)
+            ediff = fmaxf(ediff, ds_shfl_xor(ediff, m));
+            emax = fmaxf(emax, ds_shfl_xor(emax, m));
+        }
+        if (lane == 0) {
+            scratch[wave] = worst;
+            scratch[4 + wave] = ediff;
+            scratch[8 + wave] = emax;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             err[0] = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
             err[1] = (float)cap;
+            err[2] = fmaxf(fmaxf(scratch[4], scratch[5]), fmaxf(scratch[6], scratch[7]));
+            err[3] = fmaxf(fmaxf(scratch[8], scratch[9]), fmaxf(scratch[10], scratch[11]));
         }
     }
 }
@@ -655,30 +681,36 @@ extern "C" int ds_triplet_scan_f32(const float *d_p, const float *d_n, float mar
 }
 
 static int refine_distances(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
-                            float *d_n, int D, float *err, const float *d_p0, const float *d_n0, void *stream) {
+                            float *d_n, int D, float *err, const float *d_p0, const float *d_n0, const float *emb_a,
+                            const float *emb_p, const float *emb_n, void *stream) {
     DS_REQUIRE(e_ref && amb_idx && amb_count && d_p && d_n, DS_ERR_NULL);
     DS_REQUIRE(cap > 0 && D > 0, DS_ERR_BAD_SHAPE);
     const float eps = (float)(1e-4 / (double)D);
     const int blocks = err ? 1 : ds_ceil_div(cap, 4);       // the error read-out folds inside one workgroup: no atomics
     DS_LAUNCH(refine_distances_kernel, blocks, 256, 64, stream, e_ref, amb_idx, amb_count, cap, d_p, d_n, D, eps, err, d_p0,
-              d_n0);
+              d_n0, emb_a, emb_p, emb_n);
     return ds_last_launch_error();
 }
 
 extern "C" int ds_refine_distances_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap,
                                        float *d_p, float *d_n, int D, void *stream) {
-    return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, nullptr, nullptr, nullptr, stream);
+    return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            stream);
 }
 
 // ... over ALL cap slots (near ties and the probe triplets ds_triplet_tail_probe_f32 put into the unused ones), also
-// reporting err[0] = max |change of d_n - d_p| and err[1] = the number of slots sampled (both float).  d_p / d_n are
-// patched; d_p_before / d_n_before are the unpatched distances the slots were chosen on (other buffers than d_p / d_n).
+// reporting err[0] = max |change of d_n - d_p|, err[1] = the number of slots sampled and -- emb_a / emb_p / emb_n given
+// (the path's own embeddings [N][D]; all three or none) -- err[2] = max |e_ref - emb|, err[3] = max |e_ref| over the sampled
+// rows (all float; err holds 4).  d_p / d_n are patched; d_p_before / d_n_before are the unpatched distances the slots were
+// chosen on (other buffers than d_p / d_n).
 extern "C" int ds_refine_distances_probe_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap,
                                              float *d_p, float *d_n, const float *d_p_before, const float *d_n_before,
-                                             int D, float *err, void *stream) {
+                                             const float *emb_a, const float *emb_p, const float *emb_n, int D, float *err,
+                                             void *stream) {
     DS_REQUIRE(err && d_p_before && d_n_before, DS_ERR_NULL);
     DS_REQUIRE(d_p_before != d_p && d_n_before != d_n, DS_ERR_UNSUPPORTED);
-    return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, err, d_p_before, d_n_before, stream);
+    DS_REQUIRE((emb_a != nullptr) == (emb_p != nullptr) && (emb_a != nullptr) == (emb_n != nullptr), DS_ERR_NULL);
+    return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, err, d_p_before, d_n_before, emb_a, emb_p, emb_n, stream);
 }
 
 // ---- softmax cross-entropy over the classifier logits (reference train_triplet.py:281-287:

@@ -74,6 +74,7 @@ class RefinePolicy:
         self.errs = []                  # per-call max fp16 error of d_n - d_p, last BAND_WINDOW calls that sampled any
         self.err_samples = 0            # slots sampled so far (near ties + probes)
         self.err_max_ever = 0.0
+        self.emb_errs = []              # per-call embedding error of the fp16 path on the sampled rows (max |d| / max |ref|)
         self.band_violations = 0
         self.pending = []               # read-back records of calls whose count has not been taken in yet
         self.calls = self.overflows = 0
@@ -81,7 +82,7 @@ class RefinePolicy:
         self._ring = self._ring_err = None
         self._next = 0
 
-    def observe(self, count: int, err: float = None, n_samples: int = 0):
+    def observe(self, count: int, err: float = None, n_samples: int = 0, emb_err: float = None):
         self.seen = (self.seen + [int(count)])[-self.HISTORY:]
         self.max_seen = max(self.max_seen, int(count))
         self.n_seen += 1
@@ -89,6 +90,16 @@ class RefinePolicy:
             self.errs = (self.errs + [float(err)])[-BAND_WINDOW:]
             self.err_samples += int(n_samples)
             self.err_max_ever = max(self.err_max_ever, float(err))
+        if emb_err is not None:
+            self.emb_errs = (self.emb_errs + [float(emb_err)])[-BAND_WINDOW:]
+
+    @property
+    def embedding_error_observed(self) -> float:
+        """Largest embedding error (max |fp16 - f32-class| / max |f32-class| over a call's 3 x slots sampled rows) of the
+        last BAND_WINDOW calls: the fp16 path's measured distance to north_star's 1e-3 on whatever it has been embedding
+        (0.0 before any call sampled).  On seeded weights 4e-4 - 5e-4; a trained network with spread embeddings reaches
+        1e-3 -- `precision="bf16x3"` is the answer when this says so."""
+        return max(self.emb_errs, default=0.0)
 
     @property
     def err_max_window(self) -> float:
@@ -104,7 +115,7 @@ class RefinePolicy:
         pinned slot; the returned record carries the event after which `value()` is valid."""
         if self._ring is None:
             self._ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
-            self._ring_err = torch.zeros((self.RING, 2), dtype=torch.float32).pin_memory()
+            self._ring_err = torch.zeros((self.RING, 4), dtype=torch.float32).pin_memory()
         slot = self._next % self.RING
         self._next += 1
         self._ring[slot:slot + 1].copy_(amb_count, non_blocking=True)
@@ -123,7 +134,9 @@ class RefinePolicy:
         else:
             cnt = int(self._ring[rec["slot"]])
             e = self._ring_err[rec["slot"]].tolist() if rec["device_err"] is not None else None
-        return (cnt, None, 0) if e is None else (cnt, float(e[0]), int(e[1]))
+        if e is None:
+            return (cnt, None, 0, None)
+        return (cnt, float(e[0]), int(e[1]), (float(e[2]) / float(e[3])) if e[3] > 0 else None)
 
     def take(self, rec: dict):
         v = self.value(rec)
@@ -177,6 +190,7 @@ class TripletSelection:
         self._ready = ready          # event on the refinement stream, or None
         self._readback = readback    # RefinePolicy.readback record of amb_count (pinned slot + its event)
         self._n_amb = None
+        self.embedding_error = None
         self._err = None             # (max observed fp16 error of d_n - d_p over this call's slots, slots sampled)
         self._fallback = fallback    # () -> dict of replacement tensors: the whole batch at f32-class precision
         self._policy = policy
@@ -187,8 +201,9 @@ class TripletSelection:
     def _take(self):
         if self._n_amb is None:
             self._readback["event"].synchronize()
-            self._n_amb, err, n_s = self._policy.take(self._readback)
+            self._n_amb, err, n_s, emb_err = self._policy.take(self._readback)
             self._err = (err, n_s)
+            self.embedding_error = emb_err      # fp16 vs f32-class embeddings on this call's sampled rows (None: not sampled)
         return self._n_amb
 
     def resolve(self):
@@ -347,7 +362,7 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
         side.wait_stream(main)
     with torch.cuda.stream(side):
         if side_stream:
-            for v in list(t.values()) + xs:         # main-stream memory the side stream reads
+            for v in list(t.values()) + xs + [a, p, n]:     # main-stream memory the side stream reads
                 if isinstance(v, torch.Tensor):
                     v.record_stream(side)
         if whole:
@@ -363,9 +378,10 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
                              rows, st)
             e_ref = eng.forward_eval_planned(xr, pw_ref, folded_ref, precision="bf16x3")
             d_p, d_n = t["d_p"].clone(), t["d_n"].clone()
-            err = torch.empty(2, dtype=torch.float32, device=a.device)
+            err = torch.empty(4, dtype=torch.float32, device=a.device)
             eng.lib.call("ds_refine_distances_probe_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
-                         eng._p(d_p), eng._p(d_n), eng._p(t["d_p"]), eng._p(t["d_n"]), a.shape[1], eng._p(err), st)
+                         eng._p(d_p), eng._p(d_n), eng._p(t["d_p"]), eng._p(t["d_n"]), eng._p(a), eng._p(p), eng._p(n),
+                         a.shape[1], eng._p(err), st)
             rb = policy.readback(t["amb_count"], err)
             idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
             mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])

@@ -241,14 +241,16 @@ int ds_refine_distances_f32(const float *e_ref, const long long *amb_idx, const 
  * and ds_refine_distances_probe_f32 patches ALL cap slots and reports err[0] = max over the slots of
  * |(d_n - d_p) at f32-class precision - (d_n - d_p) before| (the fp16 forward's error on the filter's decision variable,
  * train_triplet.py:251-253) and err[1] = the number of slots sampled (as float); "before" is read from d_p_before /
- * d_n_before, the unpatched distances the scan chose the slots on (buffers other than d_p / d_n).  One workgroup, no
- * atomics. */
+ * d_n_before, the unpatched distances the scan chose the slots on (buffers other than d_p / d_n).  With the path's own
+ * embeddings emb_a / emb_p / emb_n [N][D] (all or none) also err[2] = max |e_ref - emb| and err[3] = max |e_ref| over the
+ * 3 * cap sampled rows: the path's distance to the 1e-3 embedding contract, watched on the same sample (err holds 4 floats).
+ * One workgroup, no atomics. */
 int ds_triplet_tail_probe_f32(const float *a, const float *p, const float *n, float margin, float band, float *d_p,
                               float *d_n, float *loss, long long *idx, int *count, float *mean_diff, long long *amb_idx,
                               int *amb_count, int amb_cap, int probe_base, int N, int D, void *stream);
 int ds_refine_distances_probe_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
-                                  float *d_n, const float *d_p_before, const float *d_n_before, int D, float *err,
-                                  void *stream);
+                                  float *d_n, const float *d_p_before, const float *d_n_before, const float *emb_a,
+                                  const float *emb_p, const float *emb_n, int D, float *err, void *stream);
 
 
 /* ---- backward of the convolution stack (torch autograd of nn.Conv2d / nn.BatchNorm2d under

@@ -158,10 +158,12 @@ def test_triplet_tail_probe_slots_and_error_readout(N, cap, base):
     np.testing.assert_array_equal(slots[k:], (base + np.arange(cap - k)) % N)
     e_ref = rs.randn(3 * cap, D).astype(np.float32)
     dp2, dn2 = t["d_p"].clone(), t["d_n"].clone()
-    err = torch.full((2,), -1.0)
-    eng.lib.call("ds_refine_distances_probe_f32", eng._p(torch.from_numpy(e_ref)), eng._p(t["amb_idx"]),
-                 eng._p(t["amb_count"]), cap, eng._p(dp2), eng._p(dn2), eng._p(t["d_p"]), eng._p(t["d_n"]), D, eng._p(err),
-                 None)
+    err = torch.full((4,), -1.0)
+    ta_, tp_, tn_ = (torch.from_numpy(v) for v in (a, p, n))
+    te_ref = torch.from_numpy(e_ref)
+    eng.lib.call("ds_refine_distances_probe_f32", eng._p(te_ref), eng._p(t["amb_idx"]),
+                 eng._p(t["amb_count"]), cap, eng._p(dp2), eng._p(dn2), eng._p(t["d_p"]), eng._p(t["d_n"]), eng._p(ta_), eng._p(tp_),
+                 eng._p(tn_), D, eng._p(err), None)
     exp_p, exp_n = t["d_p"].numpy().copy(), t["d_n"].numpy().copy()
     worst = 0.0
     for s_ in range(cap):
@@ -171,13 +173,22 @@ def test_triplet_tail_probe_slots_and_error_readout(N, cap, base):
         worst = max(worst, abs(float(np.float32(new_n) - np.float32(new_p)) - float(t["d_n"][i] - t["d_p"][i])))
         exp_p[i], exp_n[i] = new_p, new_n           # (repeated indices: the last slot's values; all slots agree below)
     assert int(err[1]) == cap and abs(float(err[0]) - worst) < 1e-5 * max(1.0, worst)
+    # the embedding comparison on the sampled rows: max |e_ref - emb| and max |e_ref| over anchors | positives | negatives
+    ediff = max(np.abs(e_ref[k_ * cap + s_] - src[slots[s_]]).max() for s_ in range(cap) for k_, src in enumerate((a, p, n)))
+    assert abs(float(err[2]) - ediff) < 1e-6 * max(1.0, ediff) and abs(float(err[3]) - np.abs(e_ref).max()) < 1e-6
+    err_no = torch.full((4,), -1.0)         # without the path's embeddings: nothing compared
+    dpx, dnx = t["d_p"].clone(), t["d_n"].clone()
+    eng.lib.call("ds_refine_distances_probe_f32", eng._p(te_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap, eng._p(dpx),
+                 eng._p(dnx), eng._p(t["d_p"]), eng._p(t["d_n"]), None, None, None, D, eng._p(err_no), None)
+    assert float(err_no[2]) == 0.0 and float(err_no[0]) == float(err[0])
     untouched = np.setdiff1d(np.arange(N), slots)
     np.testing.assert_array_equal(dp2.numpy()[untouched], t["d_p"].numpy()[untouched])
     if len(set(slots.tolist())) == cap:                         # no index twice: every patched value is determined
         assert rel_err(dp2.numpy(), exp_p) < 1e-6 and rel_err(dn2.numpy(), exp_n) < 1e-6
     # the same buffers as "before" and patched are refused
-    rc = eng.lib.raw("ds_refine_distances_probe_f32")(eng._p(torch.from_numpy(e_ref)), eng._p(t["amb_idx"]), eng._p(t["amb_count"]),
-                                                      cap, eng._p(dp2), eng._p(dn2), eng._p(dp2), eng._p(dn2), D, eng._p(err), None)
+    rc = eng.lib.raw("ds_refine_distances_probe_f32")(eng._p(te_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]),
+                                                      cap, eng._p(dp2), eng._p(dn2), eng._p(dp2), eng._p(dn2), None, None, None, D,
+                                                      eng._p(err), None)
     assert rc != 0
 
 

@@ -72,6 +72,11 @@ def run_case(m, x, precision, ref_emb, ref_dp, ref_dn, ref_loss, ref_sel, tag, e
           f"{float(ref_dn.mean()):.3f}")
     assert err < (emb_bar or EMB_BAR[precision]), err
     assert loss_rel < CONTRACT
+    if precision == "f16" and sel.embedding_error is not None:
+        # the path's own estimate of its embedding error (fp16 vs f32-class on the 3 x slots sampled rows) is of the size
+        # of the true error over all rows: the same measure on a sample can only be smaller, and not by much
+        print(f"    embedding error the call observed on its {3 * sel.amb_cap} sampled rows: {sel.embedding_error:.3e} (all rows: {err:.3e})")
+        assert 0.3 * err < sel.embedding_error < 1.2 * err, (sel.embedding_error, err)
     np.testing.assert_array_equal(sel.indices.cpu().numpy(), ref_sel)         # identical selection
     if precision == "f16":
         # the band covers what fp16 does -- or the call's own probes noticed that it does not and it fell back

@@ -121,11 +121,13 @@ def test_refine_policy_band_follows_the_observed_error():
     from deepspeaker_pytorch_amd.mining import BAND_SAFETY, BAND_WINDOW, REFINE_BAND, RefinePolicy
     pol = RefinePolicy()
     assert pol.band_for() == REFINE_BAND and pol.err_samples == 0
-    pol.observe(1, 2e-4, 30)
+    pol.observe(1, 2e-4, 30, 4.1e-4)
     assert pol.band_for() == REFINE_BAND                               # 2.5 x 2e-4 is still under the floor
+    assert pol.embedding_error_observed == 4.1e-4                      # the path's distance to the 1e-3 contract, as sampled
     pol.observe(0, None, 0)                                            # a whole-batch call sampled nothing
     assert pol.err_samples == 30 and len(pol.errs) == 1
-    pol.observe(2, 3e-3, 4)                                            # weights that spread the embeddings apart
+    pol.observe(2, 3e-3, 4, 1.1e-3)                                    # weights that spread the embeddings apart
+    assert pol.embedding_error_observed == 1.1e-3
     assert abs(pol.band_for() - BAND_SAFETY * 3e-3) < 1e-12 and pol.err_max_ever == 3e-3 and pol.err_samples == 34
     for _ in range(BAND_WINDOW):
         pol.observe(1, 1e-4, 4)
