@@ -518,6 +518,9 @@ def main():
                                        "256 triplets = 768 x [1,160,64] utterances per GPU, triplet loss, backward, "
                                        "gradient all-reduce, fused Adagrad",
                            "batch_triplets": BATCH_TRIPLETS, "parallelism": f"dp{world}"}}
+            tfl = emb_per_step * args.steps / elapsed * 3 * FWD_FLOPS_PER_EMB / 1e12
+            line["algorithmic_tflops"] = round(tfl, 1)         # ~3x the forward's FLOPs per utterance
+            line["frac_of_mfma_peak"] = round(tfl / (157.3 if tprec == "f32" else 2500.0), 4)
             if ar_per_step is not None:
                 # 12 BatchNorm layers x {forward, backward} + 5 gradient buckets + the logged loss
                 line["all_reduce_per_step"] = ar_per_step
