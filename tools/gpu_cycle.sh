@@ -19,6 +19,7 @@ for w in $WHAT; do
     lat) timeout 300 python tools/latency_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.txt
          timeout 600 python -m pytest tests/test_gpu_edge_cases.py -m gpu -q -k "low_latency" 2>&1 | tail -3 ;;
     bn16) for g in 8192 2048 32768; do DS_TF_GRID=$g timeout 300 python tools/bn16_probe.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/bn16_probe.txt; done ;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 ;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json | head -c 6000 ;;
     benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?"; cat $OUT/benchq.json | head -c 4000 ;;
     train) timeout 600 python bench.py --train --no-cpu-baseline > $OUT/train.json 2> $OUT/train.err; echo "train rc=$?"; cat $OUT/train.json
