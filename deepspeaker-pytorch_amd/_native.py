@@ -98,6 +98,7 @@ _SIGNATURES = {
     "ds_bn_bwd_group_f16": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong,
                                     c_int, c_int, c_int, c_int, c_float, _P]),
     "ds_bn_stats_partial_f16": (c_int, [_P, _P, c_longlong, c_int, c_int, _P]),
+    "ds_bn_stats_from_sums_group_f32": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_bn_bwd_group_reduce_f16": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int,
                                            c_int, c_int, _P]),
     "ds_bn_bwd_group_apply_f16": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int,

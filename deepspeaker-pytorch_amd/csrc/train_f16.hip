@@ -279,6 +279,35 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_f16_kernel(const float *p
     }
 }
 
+// data-parallel forward: the [G][2C+1] float64 sums (per member C pairs { sum z, sum z^2 } and the pixel count) have been
+// all-reduced over the ranks; tables per member, running statistics member after member (call order) -- one launch
+__global__ void __launch_bounds__(256) bn_stats_from_sums_group_kernel(const double *sums, const float *gamma, const float *beta,
+                                                                       float eps, float momentum, float *running_mean,
+                                                                       float *running_var, float *mean_t, float *invstd_t,
+                                                                       float *scale_t, float *shift_t, int C, int G) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int m = 0; m < G; ++m) {
+        const double *sm = sums + (size_t)m * (2 * C + 1);
+        const double count = sm[2 * C];
+        const double mean = sm[c * 2] / count;
+        double var = sm[c * 2 + 1] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        if (running_mean) {
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+        const size_t o = (size_t)m * C + c;
+        mean_t[o] = (float)mean;
+        invstd_t[o] = (float)invstd;
+        const double sc = (double)gamma[c] * invstd;
+        scale_t[o] = (float)sc;
+        shift_t[o] = (float)((double)beta[c] - mean * sc);
+    }
+}
+
 // data-parallel fold: the [G][2C+1] float64 sums (per member C pairs { sum gy, sum gy * xhat } and the pixel count) have
 // been all-reduced over the ranks; coefficients per member, dgamma / dbeta summed over the members and un-scaled
 __global__ void __launch_bounds__(256) bn_bwd_from_sums_f16_kernel(const double *sums, const float *gamma, const float *invstd_t,
@@ -408,6 +437,18 @@ extern "C" int ds_bn_stats_partial_f16(const void *z_f16, float *partial, long l
     const int slots = 256 / (C / 8);
     DS_LAUNCH(bn_stats_f16_kernel, blocks * G, 256, (size_t)slots * C * 2 * 4, stream, (const h16 *)z_f16, partial, n_pix, C,
               ppb, blocks);
+    return ds_last_launch_error();
+}
+
+// ... and the second half: [G][C] tables (and the running statistics, members in call order) from the all-reduced sums
+extern "C" int ds_bn_stats_from_sums_group_f32(const double *sums, const float *gamma, const float *beta, float eps,
+                                               float momentum, float *running_mean, float *running_var, float *mean_t,
+                                               float *invstd_t, float *scale_t, float *shift_t, int C, int G, void *stream) {
+    DS_REQUIRE(sums && gamma && beta && mean_t && invstd_t && scale_t && shift_t, DS_ERR_NULL);
+    DS_REQUIRE(C > 0 && G > 0 && G <= 64, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DS_ERR_NULL);
+    DS_LAUNCH(bn_stats_from_sums_group_kernel, ds_ceil_div(C, 256), 256, 0, stream, sums, gamma, beta, eps, momentum, running_mean,
+              running_var, mean_t, invstd_t, scale_t, shift_t, C, G);
     return ds_last_launch_error();
 }
 

@@ -52,11 +52,10 @@ def _bn_stats(eng: Engine, z16: torch.Tensor, bn: BNParams, G: int, update_runni
         eng.lib.call("ds_bn_stats_partial_f16", eng._p(z16), eng._p(partial), n_pix, c, G, st)
         eng.lib.call("ds_partial_sum_f64_group", eng._p(partial), rows, eng._p(sums), n_pix, c, G, st)
         reducer.all_reduce_sum_(sums)
-        for g in range(G):                                  # running statistics: members in call order
-            eng.lib.call("ds_bn_stats_from_sums_f32", eng._p(sums[g]), 0, eng._p(bn.weight.detach()), eng._p(bn.bias.detach()),
-                         BN_EPS, BN_MOMENTUM, eng._p(bn.running_mean) if update_running else None,
-                         eng._p(bn.running_var) if update_running else None, eng._p(tables[0][g]), eng._p(tables[1][g]),
-                         eng._p(tables[2][g]), eng._p(tables[3][g]), c, st)
+        eng.lib.call("ds_bn_stats_from_sums_group_f32", eng._p(sums), eng._p(bn.weight.detach()), eng._p(bn.bias.detach()),
+                     BN_EPS, BN_MOMENTUM, eng._p(bn.running_mean) if update_running else None,
+                     eng._p(bn.running_var) if update_running else None, eng._p(tables[0]), eng._p(tables[1]),
+                     eng._p(tables[2]), eng._p(tables[3]), c, G, st)      # members in call order inside the kernel
         return tables
     eng.lib.call("ds_bn_stats_group_f16", eng._p(z16), eng._p(partial), n_pix, eng._p(bn.weight.detach()),
                  eng._p(bn.bias.detach()), BN_EPS, BN_MOMENTUM, eng._p(bn.running_mean) if update_running else None,

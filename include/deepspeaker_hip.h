@@ -466,6 +466,9 @@ int ds_bn_bwd_group_f16(const void *g1, int g1_parity, const void *g2, const voi
  * coefficients, dgamma / dbeta, gz from the GLOBAL sums; regen: gy was not stored, gy_or_g1 is g1 and the mask tables
  * are given).  An N-rank step then equals the single-process step on the global batch. */
 int ds_bn_stats_partial_f16(const void *z_f16, float *partial, long long n_pix, int C, int G, void *stream);
+int ds_bn_stats_from_sums_group_f32(const double *sums, const float *gamma, const float *beta, float eps, float momentum,
+                                    float *running_mean, float *running_var, float *mean_t, float *invstd_t,
+                                    float *scale_t, float *shift_t, int C, int G, void *stream);   /* all G members, one launch */
 int ds_bn_bwd_group_reduce_f16(const void *g1, int g1_parity, const void *g2, const void *act, int act_is_f32,
                                const float *mask_scale_t, const float *mask_shift_t, const void *z, const float *mean_t,
                                const float *invstd_t, void *gy, float *partial, long long n_pix, int H, int W, int C, int G,
