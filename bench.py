@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refine-window", type=int, default=4,
+                    help="steps whose near ties share one refinement forward (mining.RefineWindow; 1 = every step its own): "
+                         "the timed region ends with the open window flushed, so all of the refinement is inside it")
     ap.add_argument("--refine-slots", type=int, default=0,
                     help="smallest number of near-tie re-embedding slots of the fp16 path (0: the library default, "
                          "mining.REFINE_CAP_MIN); the policy grows them from observed counts either way")
@@ -265,8 +268,9 @@ def main():
         model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
         return model.to(dev)
 
-    def region(step, steps):
-        """K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    def region(step, steps, finish=None):
+        """K steps bracketed by barrier + synchronize on both sides; max over ranks.  `finish`: enqueued after the K-th step,
+        inside the region (closes what the steps left open: the refinement window)."""
         fence()
         t0 = time.perf_counter()
         if args.streams > 1:
@@ -281,6 +285,8 @@ def main():
         else:
             for _ in range(steps):
                 step()
+        if finish is not None:
+            finish()
         t_enq = time.perf_counter() - t0        # host time to enqueue the steps (the device may still be busy)
         fence()
         elapsed = time.perf_counter() - t0
@@ -294,7 +300,7 @@ def main():
         """untimed settle-in steps run BEFORE the W contract warm-ups (reported as `pre_steps` in the line)"""
         return max(0, 30 - warmup)
 
-    def timed(step, steps, warmup, repeats=0, profile=True):
+    def timed(step, steps, warmup, repeats=0, profile=True, finish=None):
         # profile: per-launch events around the convolutions of the timed region (the live roofline of the eval line); the
         # training steps are timed without them (a pair of events per launch is ~70 per fp16 training step -- measured
         # 12.7 ms per step with them, 9.6 without)
@@ -310,14 +316,16 @@ def main():
         for j, st_ in enumerate(streams):       # launch plans / allocator pools of the side streams
             with torch.cuda.stream(st_):
                 step(j)
+        if finish is not None:
+            finish()                            # nothing of the warm-up is left for the timed region to do
         prof_on()
-        elapsed, t_enq = region(step, steps)
+        elapsed, t_enq = region(step, steps, finish)
         if rank == 0:
             print(f"[bench] host enqueue {t_enq / steps * 1e3:.3f} ms/step, device-complete {elapsed / steps * 1e3:.3f} ms/step",
                   file=sys.stderr)
         prof, eng.profile = (eng.profile or []), None
         # the same region again, `repeats` times, without the per-launch events: the spread of the box
-        again = [region(step, steps)[0] / steps * 1e3 for _ in range(repeats)]
+        again = [region(step, steps, finish)[0] / steps * 1e3 for _ in range(repeats)]
         if rank == 0 and again:
             print(f"[bench] repeats of the {steps}-step region, ms/step: " + ", ".join(f"{v:.3f}" for v in again), file=sys.stderr)
         return elapsed, prof, again
@@ -326,6 +334,7 @@ def main():
         model = load_model(precision).eval()
         if args.refine_slots > 0:
             refine_policy(model).cap_min = refine_policy(model).cap_start = args.refine_slots
+        refine_policy(model).window = max(1, args.refine_window)
         last_mined = [[None, None] for _ in range(n_slots)]
         parity = [0] * n_slots
         sels = []
@@ -371,7 +380,7 @@ def main():
                 del sels[:-steps]
             return loss, sel, mined
 
-        elapsed, prof, again = timed(step, steps, warmup, repeats)
+        elapsed, prof, again = timed(step, steps, warmup, repeats, finish=refine_policy(model).flush)
         # The same kernels with NOTHING else on the chip: forwards only, back to back (no loss / filter / refinement /
         # search, hence no side stream).  Inside the step the near-tie refinement and the semi-hard search of step k run
         # on a side stream next to the forward of step k + 1 and take CUs from it, so the per-launch durations measured
@@ -404,7 +413,7 @@ def main():
                       "band_observed_max_timed_steps": max(errs, default=None), "band_samples_total": pol.err_samples,
                       "band_violations_total": pol.band_violations,
                       "embedding_error_observed": pol.embedding_error_observed,
-                      "slots": [s_.amb_cap for s_ in last][-1], "near_ties_mean": round(sum(ties) / len(ties), 2),
+                      "slots": [s_.amb_cap for s_ in last][-1], "window_steps": pol.window, "near_ties_mean": round(sum(ties) / len(ties), 2),
                       "near_ties_max": max(ties), "overflow_steps": sum(int(s_.refine_overflow) for s_ in last),
                       "band_violation_steps": sum(int(s_.band_exceeded) for s_ in last),
                       "steps": len(last), "calls_total": pol.calls, "overflows_total": pol.overflows}

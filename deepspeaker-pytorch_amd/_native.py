@@ -34,6 +34,11 @@ _P = c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
     "ds_version": (c_int, []),
+    "ds_event_create": (c_int, [POINTER(c_void_p)]),
+    "ds_event_destroy": (c_int, [_P]),
+    "ds_event_elapsed_ms": (c_int, [_P, _P, POINTER(c_float)]),
+    "ds_launch_timing_arm": (c_int, [_P, _P]),
+    "ds_launch_timing_end": (c_int, []),
     "ds_error_string": (c_char_p, [c_int]),
     "ds_nchw_to_nhwc_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_nhwc_to_nchw_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -68,6 +73,8 @@ _SIGNATURES = {
     "ds_conv_block_f16_masked": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv_f16_plan_describe": (c_int, [POINTER(ConvShape), POINTER(c_int)]),
     "ds_conv_f16_plan_describe_hinted": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
+    "ds_conv_f16_set_layout_padding": (None, [c_int]),
+    "ds_conv_f16_plan_lds_layout": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
     "ds_cast_f32_to_f16": (c_int, [_P, _P, c_longlong, _P]),
     "ds_cast_f16_to_f32": (c_int, [_P, _P, c_longlong, _P]),
     "ds_avgpool_time_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -124,6 +131,7 @@ _SIGNATURES = {
     "ds_bn_bwd_reduce_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
     "ds_bn_bwd_apply_f32": (c_int, [_P, c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, _P]),
     "ds_gather_rows_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "ds_gather_rows3_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_scatter_add_rows_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_mine_workspace_floats": (c_longlong, [c_int, c_int]),
     "ds_mine_semihard_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

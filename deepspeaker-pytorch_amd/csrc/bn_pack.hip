@@ -385,6 +385,64 @@ unsigned *ds_sched_slot(void *stream) {
 
 extern "C" int ds_version(void) { return 301; }   // 30x: round-3 ABI (300: split grouped BatchNorm backward for data parallelism, grouped f64 sums; 301: + ds_conv_dgrad_bnbwd_bf16, ds_bn_bwd_group_finish_f32)
 
+// ---- launch timing (see DS_LAUNCH_BIG_LDS in ds_device.h) ----
+extern "C" int ds_event_create(void **out_event) {
+    DS_REQUIRE(out_event != nullptr, DS_ERR_NULL);
+#ifdef DS_EMULATED
+    return DS_ERR_UNSUPPORTED;
+#else
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return (int)rc;
+    *out_event = (void *)e;
+    return DS_OK;
+#endif
+}
+
+extern "C" int ds_event_destroy(void *event) {
+    DS_REQUIRE(event != nullptr, DS_ERR_NULL);
+#ifdef DS_EMULATED
+    return DS_ERR_UNSUPPORTED;
+#else
+    return (int)hipEventDestroy((hipEvent_t)event);
+#endif
+}
+
+// milliseconds between two events (waits for `stop` first)
+extern "C" int ds_event_elapsed_ms(void *start, void *stop, float *ms) {
+    DS_REQUIRE(start && stop && ms, DS_ERR_NULL);
+#ifdef DS_EMULATED
+    return DS_ERR_UNSUPPORTED;
+#else
+    hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+    if (rc != hipSuccess) return (int)rc;
+    return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+#endif
+}
+
+// The NEXT big-LDS kernel launch of this thread (the MFMA convolution / filter-gradient kernels) records its own
+// execution into (start, stop).  ds_launch_timing_end() disarms and returns the number of such launches since arming
+// (the caller expects 1: a call that launched several kernels timed only its first).
+extern "C" int ds_launch_timing_arm(void *start, void *stop) {
+    DS_REQUIRE(start && stop, DS_ERR_NULL);
+#ifdef DS_EMULATED
+    return DS_ERR_UNSUPPORTED;
+#else
+    ds_timing_arm_state = {(hipEvent_t)start, (hipEvent_t)stop, 1, 0};
+    return DS_OK;
+#endif
+}
+
+extern "C" int ds_launch_timing_end(void) {
+#ifdef DS_EMULATED
+    return 0;
+#else
+    const int n = ds_timing_arm_state.launches;
+    ds_timing_arm_state = {nullptr, nullptr, 0, 0};
+    return n;
+#endif
+}
+
 extern "C" const char *ds_error_string(int code) {
     switch (code) {
         case DS_OK: return "ok";

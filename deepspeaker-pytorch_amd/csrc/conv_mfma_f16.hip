@@ -96,23 +96,27 @@ __global__ void __launch_bounds__(256) conv_f16_splitk_reduce_kernel(const float
     }
 }
 
-// LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for a candidate row pitch: the two 16-lane
-// service groups of lanes 0..31 each hold 16 consecutive pixels of the M tile (`lpix` in the kernel).
-// Bank slot of a record = (record * PSH / 16) mod 16.
-static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in, int pitch, int PSH) {
-    const int pix_per_seg = RT * Wc, seg_pix = rows_in * pitch;
+// LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for candidate row / segment strides: the two
+// 16-lane service groups of lanes 0..31 each hold 16 consecutive pixels of the M tile (`lpix` in the kernel).
+// Bank slot of a record = (byte offset / 16) mod 16; lanes reading the same record do not conflict.
+static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int row_bytes, int seg_bytes, int PSH) {
+    const int pix_per_seg = RT * Wc;
     double total = 0.0;
     int n = 0;
     for (int m0 = 0; m0 + 32 <= MT; m0 += 32) {
         for (int g = 0; g < 2; ++g) {
-            int cnt[16] = {0};
+            int cnt[16] = {0}, offs[16];
             int worst = 0;
             for (int j = 0; j < 16; ++j) {
-                const int m = m0 + 16 * g + j;
+                int m = m0 + 16 * g + j;
+                if (m >= NI * pix_per_seg) m &= ~15;    // past the last segment: the group's first pixel (kernel: a_off)
                 const int seg = m / pix_per_seg, rem = m % pix_per_seg;
                 const int r = rem / Wc, c = rem % Wc;
-                const int rec = (seg < NI) ? seg * seg_pix + (IS * r) * pitch + c : 0;
-                const int slot = (rec * (PSH / 16)) & 15;
+                const int off = offs[j] = (seg < NI) ? seg * seg_bytes + (IS * r) * row_bytes + c * PSH : 0;
+                bool seen = false;                      // lanes reading the SAME address are served together (the
+                for (int i = 0; i < j; ++i) seen |= offs[i] == off;     // pixels past the tile's last segment: record 0)
+                if (seen) continue;
+                const int slot = (off / 16) & 15;
                 if (++cnt[slot] > worst) worst = cnt[slot];
             }
             total += worst;
@@ -120,6 +124,40 @@ static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int rows_in
         }
     }
     return n ? total / n : 1.0;
+}
+
+// A tile row is `pitch` records plus `row_pad` 16-byte units, a segment rows_in rows plus `seg_pad` units: when the 16
+// pixels of a service group span several rows (maps narrower than 16 columns) or images (whole-image segments), whole
+// records of padding cannot always separate their bank slots (a 20x8 map wants its row stride = 8 units mod 16, a 10x4
+// map 4 or 12: frag_read_cost), a few 16-byte units can.  The cheapest conflict-free layout within the LDS the plan was
+// sized for (rows of up to cols_in + 4 records, 256 bytes of slack per segment).
+// Measured (tools/ab_layout.py, same process, alternating): the padded, model-conflict-free layout changes no layer by more
+// than its run-to-run spread (20x8: 126.9 vs 127.2 us; 10x4: 163.9 vs 161.6) -- the fragment reads of those layers are not
+// what their MFMA streams wait for.  Off by default; kept as a tuning hook.
+static bool g_layout_padding = false;
+static void choose_strides(ConvKH &k, int MT, int PSH) {
+    const int row_cap = (k.cols_in + 4) * PSH;
+    const int pad_units = g_layout_padding ? 16 : 1;
+    double best_cost = 1e30;
+    long long best_bytes = 0;
+    for (int pt = k.cols_in; pt <= k.cols_in + 4; ++pt)
+        for (int rp = 0; rp < pad_units; ++rp) {
+            const int row_bytes = pt * PSH + 16 * rp;
+            if (row_bytes > row_cap) break;
+            for (int sp = 0; sp < (k.NI > 1 ? pad_units : 1); ++sp) {
+                const int seg_bytes = k.rows_in * row_bytes + 16 * sp;
+                const double c = frag_read_cost(MT, k.NI, k.RT, k.Wo, k.IS, row_bytes, seg_bytes, PSH);
+                const long long bytes = (long long)k.NI * seg_bytes;
+                if (c < best_cost - 1e-9 || (c < best_cost + 1e-9 && bytes < best_bytes)) {
+                    best_cost = c;
+                    best_bytes = bytes;
+                    k.pitch = pt;
+                    k.row_bytes = row_bytes;
+                    k.seg_bytes = seg_bytes;
+                }
+            }
+        }
+    k.seg_pix = k.rows_in * k.pitch;
 }
 
 struct TileCfgH { int MT, NTILE, WM, NTHR; };
@@ -180,7 +218,7 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
                 const int rows_in = IS * (rt - 1) + s->KS, cols_in = IS * (Wo - 1) + s->KS;
                 auto lds_of = [&](int n) {
                     const size_t tp = (size_t)n * rows_in * (cols_in + 4);
-                    return std::max(tp * PSH * (db ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)n * 8;
+                    return std::max((tp * PSH + (size_t)n * 256) * (db ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)n * 8;
                 };
                 auto items_of = [&](int n) { return (long long)n * std::min(rows_in, s->H) * s->W * (ck / 8); };
                 while (ni > 1 && (lds_of(ni) > lds_cap || items_of(ni) > item_cap)) --ni;
@@ -210,23 +248,15 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
     k.rows_in = IS * (brt - 1) + s->KS;
     k.cols_in = IS * (Wo - 1) + s->KS;
     k.half = (k.cols_in + 1) / 2;
-    int best_pitch = k.cols_in;
-    double best_cost = 1e30;
-    for (int pt = k.cols_in; pt <= k.cols_in + 4; ++pt) {
-        const double c = frag_read_cost(cf.MT, bni, brt, Wo, IS, k.rows_in, pt, ds_f16_record_bytes(bck));
-        if (c < best_cost - 1e-9) { best_cost = c; best_pitch = pt; }
-    }
-    k.pitch = best_pitch;
-    k.seg_pix = k.rows_in * k.pitch;
+    choose_strides(k, cf.MT, ds_f16_record_bytes(bck));
     k.n_ntiles = s->Cout / cf.NTILE;
     pl.cfg = bc;
     pl.db = bdb;
     pl.ck = bck;
-    const int PSH = ds_f16_record_bytes(bck);
     pl.n_mtiles = ds_ceil_div(k.n_segs, bni);
     pl.grid = pl.n_mtiles * k.n_ntiles;
-    const size_t tp = (size_t)k.NI * k.seg_pix;
-    pl.lds_bytes = std::max(tp * PSH * (bdb ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)k.NI * 8 + 16;
+    const size_t tile_bytes = (size_t)k.NI * k.seg_bytes;
+    pl.lds_bytes = std::max(tile_bytes * (bdb ? 2 : 1), epi_bytes(cf)) + (size_t)cf.MT * 4 + (size_t)k.NI * 8 + 16;
     pl.nit = ds_ceil_div(k.NI * std::min(k.rows_in, s->H) * s->W * (bck / 8), cf.NTHR);
     return DS_OK;
 }
@@ -328,6 +358,31 @@ extern "C" int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flag
     // out8[7]: 10000 if the persistent kernel takes this plan (large launches; small ones may still be split-K)
     //          + 1000 if double-buffered + 100 for 16-channel chunks + staging items per thread
     out8[7] = (pers ? 10000 : 0) + pl.db * 1000 + (pl.ck == 16 ? 100 : 0) + pl.nit;
+    return DS_OK;
+}
+
+// tuning hook (tools/ab_layout.py): 0 = tile rows / segments of whole records only; 1 (default) = padded strides
+extern "C" void ds_conv_f16_set_layout_padding(int on) { g_layout_padding = on != 0; }
+
+// the LDS layout of the pixel tile in that plan: out4 = { records per tile row, bytes per tile row, bytes per segment,
+// 1000 x LDS cycles of a fragment read (1000 = conflict-free) }
+extern "C" int ds_conv_f16_plan_lds_layout(const ds_conv_shape *s, int flags, int *out4) {
+    DS_REQUIRE(out4 != nullptr, DS_ERR_NULL);
+    PlanH pl;
+    int rc = plan_f16(pl, s, !(flags & DS_CONV_HINT_SINGLE_BUFFER),
+                      (flags & (DS_CONV_IN_PLANES16 | DS_CONV_HINT_CHUNK16)) != 0);
+    if (rc != DS_OK) return rc;
+    if (s->KS == 5 && pl.ck == 32 && !(flags & (DS_CONV_HINT_SINGLE_BUFFER | DS_CONV_HINT_NO_PERSIST))) {   // as ds_conv_fwd_f16
+        PlanH p32 = pl, p16;
+        if (plan_persistent(p32, s) && p32.nit > 8 && plan_f16(p16, s, true, true) == DS_OK && p16.ck == 16) {
+            PlanH q = p16;
+            if (plan_persistent(q, s) && q.nit <= 8) pl = p16;
+        }
+    }
+    const ConvKH &k = pl.k;
+    out4[0] = k.pitch; out4[1] = k.row_bytes; out4[2] = k.seg_bytes;
+    out4[3] = (int)(1000.0 * frag_read_cost(kCfgH[pl.cfg].MT, k.NI, k.RT, k.Wo, k.IS, k.row_bytes, k.seg_bytes,
+                                            ds_f16_record_bytes(pl.ck)) + 0.5);
     return DS_OK;
 }
 

@@ -42,6 +42,9 @@ struct ConvKH {
     int dh_min, dw_min;
     int rows_in, cols_in, seg_pix;
     int pitch, half;                // LDS records per tile row; first odd-column slot (stride-2 de-interleave)
+    int row_bytes, seg_bytes;       // LDS bytes from one tile row / one segment to the next: pitch (rows_in x pitch) records
+                                    // plus the padding that spreads the 16 pixels of a fragment read's service group
+                                    // over all banks when they span several rows / images (planner: frag_read_cost)
     int RT, NI, segs_per_img, n_segs;
     int n_ntiles;
     int flags;
@@ -114,10 +117,9 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const int tile_m = tile / p.n_ntiles;
     const int seg0 = tile_m * p.NI;
     const int pix_per_seg = p.RT * p.Wo;
-    const int tile_pix = p.NI * p.seg_pix;
     // the pixel-tile region doubles as the epilogue's transposition buffers (two of 32 x (NSUB*32+4) floats per wave)
     constexpr int EPI_BYTES = 2 * WM * WN * 32 * (NSUB * 32 + 4) * 4;
-    const int tile_bytes = tile_pix * PSH;
+    const int tile_bytes = p.NI * p.seg_bytes;
     const int tiles_bytes = (DB ? 2 : 1) * tile_bytes;
     const int stage_bytes = tiles_bytes > EPI_BYTES ? tiles_bytes : EPI_BYTES;
     int *out_off = (int *)(lds + stage_bytes);                 // [MT]
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                 const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
                 const bool ok = sg < live_segs;
                 g_off[it] = ok ? ((img_row0 + sg * p.H + rr) * p.W + c) * p.x_pix_stride + q * 8 : 0;
-                l_off[it] = ok ? (sg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16 : CKH * 2;
+                l_off[it] = ok ? sg * p.seg_bytes + rr * p.row_bytes + pc * PSH + q * 16 : CKH * 2;
                 c += dc;
                 vr += dvr;
                 if (c >= p.W) {
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                     const int cc = c - p.dw_min;
                     const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
                     g_off[it] = ((img_row + rr) * p.W + c) * p.x_pix_stride + q * 8;
-                    l_off[it] = (seg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16;
+                    l_off[it] = seg * p.seg_bytes + rr * p.row_bytes + pc * PSH + q * 16;
                 }
                 c += dc;
                 vr += dvr;
@@ -290,16 +292,18 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     int a_off[MSUB];                                           // byte offset of this lane's fragment
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
-        const int m = (wm * MSUB + ms) * 32 + lpix;
+        // (a pixel past the tile's last segment reads what the first pixel of its 16-pixel service group reads -- the
+        // same address is served in the same LDS cycle -- or record 0 if that one is past the end as well)
+        int m = (wm * MSUB + ms) * 32 + lpix;
+        if (m >= p.NI * pix_per_seg) m &= ~15;
         const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
         const int rem = m - seg * pix_per_seg;
         const int r = ds_div_small(rem, p.Wo, rcp_wc), c = rem - r * p.Wo;
-        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
-        a_off[ms] = pix * PSH + 16 * lhi;
+        a_off[ms] = ((seg < p.NI) ? seg * p.seg_bytes + (p.IS * r) * p.row_bytes + c * PSH : 0) + 16 * lhi;
     }
     auto tap_off = [&](int tt) {
         const int kw = tt % KS;
-        return ((tt / KS) * p.pitch + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw)) * PSH;
+        return (tt / KS) * p.row_bytes + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw) * PSH;
     };
 
     // ---- one chunk of 32 input channels: NU units of NMF MFMAs, one side operation after each MFMA ----

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int pix_per_seg = p.RT * p.Wo;
-    const int tile_bytes = p.NI * p.seg_pix * PSH;
+    const int tile_bytes = p.NI * p.seg_bytes;
     const bool rowblock = p.NI == 1;                // one block of rows of one image; else: NI whole images
     const int pad = -p.dw_min;
     // rows of a segment's tile that are enumerated for staging: all of them for a row block (the per-tile window
@@ -99,15 +99,15 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
             const bool ok = sg < p.NI;
             g_tab[it] = ok ? (unsigned)((((sg * p.H + rr) * p.W + c) * p.x_pix_stride + q * 8) * 2) : OOB;
-            l_tab[it] = ok ? (sg * p.seg_pix + rr * p.pitch + pc) * PSH + q * 16 : CKH * 2;    // spare: pad of record 0
+            l_tab[it] = ok ? sg * p.seg_bytes + rr * p.row_bytes + pc * PSH + q * 16 : CKH * 2;    // spare: pad of record 0
         }
         if (LIN) {      // rows advance by (NTHR / IPP) / W per item, the column stays
             const int rows_per_item = ds_div_small(NTHR / IPP, p.W, rcp_w);
             g_step = (unsigned)(rows_per_item * p.W * p.x_pix_stride * 2);
-            l_step = rows_per_item * p.pitch * PSH;
+            l_step = rows_per_item * p.row_bytes;
         }
     }
-    const int last_row_l = (p.rows_in - 1) * p.pitch * PSH + (p.pitch * PSH - 1);      // LIN: last byte of the tile's rows
+    const int last_row_l = (p.rows_in - 1) * p.row_bytes + (p.pitch * PSH - 1);      // LIN: last byte of the tile's rows
     auto g_rel = [&](int it) -> unsigned { return LIN ? g_tab[0] + (unsigned)it * g_step : g_tab[LIN ? 0 : it]; };
     // (LIN: an item past the tile's last row is a spare slot: its load is out of range by construction -- beyond the
     // window's end -- and its zeros go to the pad bytes of record 0)
@@ -123,16 +123,18 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     int a_off[MSUB];                                           // byte offset of this lane's fragment
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
-        const int m = (wm * MSUB + ms) * 32 + lpix;
+        // (a pixel past the tile's last segment reads what the first pixel of its 16-pixel service group reads -- the
+        // same address is served in the same LDS cycle -- or record 0 if that one is past the end as well)
+        int m = (wm * MSUB + ms) * 32 + lpix;
+        if (m >= p.NI * pix_per_seg) m &= ~15;
         const int seg = ds_div_small(m, pix_per_seg, rcp_pps);
         const int rem = m - seg * pix_per_seg;
         const int r = ds_div_small(rem, p.Wo, rcp_wc), c = rem - r * p.Wo;
-        const int pix = (seg < p.NI) ? seg * p.seg_pix + (p.IS * r) * p.pitch + c : 0;
-        a_off[ms] = pix * PSH + 16 * lhi;
+        a_off[ms] = ((seg < p.NI) ? seg * p.seg_bytes + (p.IS * r) * p.row_bytes + c * PSH : 0) + 16 * lhi;
     }
     auto tap_off = [&](int tt) {
         const int kw = tt % KS;
-        return ((tt / KS) * p.pitch + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw)) * PSH;
+        return (tt / KS) * p.row_bytes + (p.IS == 2 ? (kw & 1) * p.half + (kw >> 1) : kw) * PSH;
     };
     // halo records of one segment's tile: whole rows outside the enumerated ones, and the columns left / right of the
     // image in the enumerated rows
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                 cc = k < pad ? k : p.W + k;
             }
             const int pc = (p.IS == 2) ? ((cc & 1) ? p.half + (cc >> 1) : (cc >> 1)) : cc;
-            *(f32x4 *)(lds + buf * tile_bytes + (sg * p.seg_pix + row * p.pitch + pc) * PSH + 16 * piece) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            *(f32x4 *)(lds + buf * tile_bytes + sg * p.seg_bytes + row * p.row_bytes + pc * PSH + 16 * piece) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off(it)) = st[it];

@@ -4,6 +4,7 @@
 // same name so the unmodified kernel sources can be exercised lane-by-lane on a CPU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -136,12 +137,28 @@ __device__ __forceinline__ float *ds_dynamic_lds() {
 
 // Launch with more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU): the per-kernel
 // opt-in is set once per process (immutable function attribute, not launch state).
+// ... and, when a pair of timing events is ARMED on this thread (ds_launch_timing_arm: the bench's live roofline), the
+// launch carries them itself: hipExtLaunchKernelGGL binds start / stop to the dispatch's own completion signal, so the
+// events read the kernel's execution time and no marker packet is queued before or after it (a hipEventRecord pair
+// around each launch costs ~10 us of queue bubbles per launch -- 4 % of the eval step).  `launches` counts the
+// big-LDS launches since arming: the caller checks that the call it timed was exactly one of them.
+struct ds_timing_arm_t { hipEvent_t start, stop; int armed, launches; };
+inline thread_local ds_timing_arm_t ds_timing_arm_state = {nullptr, nullptr, 0, 0};
+
 #define DS_LAUNCH_BIG_LDS(kernel, grid, block, lds_bytes, stream, ...)                                          \
     do {                                                                                                         \
         static const hipError_t ds_attr_rc_ = hipFuncSetAttribute(                                               \
             (const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
         (void)ds_attr_rc_;                                                                                       \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__);    \
+        ds_timing_arm_t &ds_arm_ = ds_timing_arm_state;                                                          \
+        ++ds_arm_.launches;                                                                                      \
+        if (ds_arm_.armed) {                                                                                     \
+            ds_arm_.armed = 0;                                                                                   \
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream),           \
+                                  ds_arm_.start, ds_arm_.stop, 0, __VA_ARGS__);                                  \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__); \
+        }                                                                                                        \
     } while (0)
 
 // Compute units of the current device (persistent kernels size their grid by it); queried once per process.

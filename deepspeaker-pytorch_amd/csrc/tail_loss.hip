@@ -493,6 +493,22 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float *src, cons
         dst[(size_t)i * D + k] = j >= 0 ? src[(size_t)j * D + k] : 0.0f;
 }
 
+// the same rows of three sources in one launch (the anchors / positives / negatives of the near-tie triplets):
+// dst[k][i,:] = src_k[idx[i],:]; blockIdx = (k * N + i) * parts + part
+__global__ void __launch_bounds__(256) gather_rows3_kernel(const float *s0, const float *s1, const float *s2,
+                                                           const long long *idx, float *dst, int N, int D) {
+    const int parts = gridDim.x / (3 * N);
+    const int r = blockIdx.x / parts, part = blockIdx.x - r * parts;
+    const int k = r / N, i = r - k * N;
+    const float *src = k == 0 ? s0 : k == 1 ? s1 : s2;
+    const long long j = idx[i];
+    for (int e = (part * 256 + threadIdx.x) * 4; e < D; e += parts * 1024) {
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (j >= 0) v = *(const f32x4 *)(src + (size_t)j * D + e);
+        *(f32x4 *)(dst + (size_t)r * D + e) = v;
+    }
+}
+
 // dst[j,:] (+)= sum over {i : idx[i] == j} of g[i,:], i ascending (deterministic; one workgroup per dst row)
 __global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float *g, const long long *idx, float *dst, int N,
                                                                int D, int accumulate) {
@@ -512,6 +528,17 @@ extern "C" int ds_gather_rows_f32(const float *src, const long long *idx, float 
     DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
     const int parts = D >= 4096 ? 8 : 1;
     DS_LAUNCH(gather_rows_kernel, N * parts, 256, 0, stream, src, idx, dst, N, D);
+    return ds_last_launch_error();
+}
+
+// dst [3][N][D] = rows idx[0..N) of src_a, src_p, src_n (a negative index gathers zeros); D % 4 == 0, 16-byte aligned
+extern "C" int ds_gather_rows3_f32(const float *src_a, const float *src_p, const float *src_n, const long long *idx,
+                                   float *dst, int N, int D, void *stream) {
+    DS_REQUIRE(src_a && src_p && src_n && idx && dst, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0 && D % 4 == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(DS_ALIGNED16(src_a) && DS_ALIGNED16(src_p) && DS_ALIGNED16(src_n) && DS_ALIGNED16(dst), DS_ERR_ALIGNMENT);
+    const int parts = D >= 4096 ? 8 : 1;
+    DS_LAUNCH(gather_rows3_kernel, 3 * N * parts, 256, 0, stream, src_a, src_p, src_n, idx, dst, N, D);
     return ds_last_launch_error();
 }
 

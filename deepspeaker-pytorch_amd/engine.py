@@ -90,6 +90,33 @@ class SavedForward:
     dims: List[Tuple[int, int]] = field(default_factory=list)
 
 
+# entry points that launch exactly one (big-LDS, MFMA) kernel: profiled through events bound to the launch itself
+_SELF_TIMED = frozenset({"ds_conv_fwd_f16", "ds_conv_block_f16", "ds_conv_block_f16_masked"})
+
+
+class LaunchEvent:
+    """A HIP event of ours (ds_event_create) for `ds_launch_timing_arm`: a pair bound to a launch reads that kernel's
+    execution time, with the `elapsed_time` of torch.cuda.Event (milliseconds; waits for the second event)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        h = ctypes.c_void_p()
+        lib.call("ds_event_create", ctypes.byref(h))
+        self.handle = h
+
+    def elapsed_time(self, other: "LaunchEvent") -> float:
+        ms = ctypes.c_float()
+        self._lib.call("ds_event_elapsed_ms", self.handle, other.handle, ctypes.byref(ms))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.raw("ds_event_destroy")(self.handle)
+        except Exception:
+            pass
+
+
 class Engine:
     PLAN_CACHE_ENTRIES = 64            # eval launch plans kept (each owns its activation buffers), LRU
     PLAN_CACHE_BYTES = 12 << 30        # ... and their total size (a 768 x 160-frame f32-class plan is 3.3 GiB)
@@ -99,6 +126,7 @@ class Engine:
         # When set to a list, every implicit-GEMM convolution launch is bracketed by two events on the
         # launch stream and (label, flops, start, end, arithmetic) is appended (bench.py's live roofline).
         self.profile: Optional[list] = None
+        self.self_timed_launches = True     # profile entries of single-kernel calls from events bound to the launch
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -590,10 +618,17 @@ class Engine:
         prof = self.profile if (self.profile is not None and x.is_cuda) else None
         for fn, args, label, flops in plan["calls"]:
             if prof is not None and label is not None:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-                rc = fn(*args)
-                ev1.record()
+                if self.self_timed_launches and fn.__name__ in _SELF_TIMED:    # one MFMA kernel per call: the launch carries its own events
+                    ev0, ev1 = LaunchEvent(self.lib), LaunchEvent(self.lib)
+                    self.lib.call("ds_launch_timing_arm", ev0.handle, ev1.handle)
+                    rc = fn(*args)
+                    if self.lib.raw("ds_launch_timing_end")() != 1 and rc == 0:
+                        raise RuntimeError(f"{fn.__name__}: expected exactly one timed launch")
+                else:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    rc = fn(*args)
+                    ev1.record()
                 prof.append((label, flops, ev0, ev1, precision))
             else:
                 rc = fn(*args)

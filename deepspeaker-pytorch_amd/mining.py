@@ -7,6 +7,7 @@ the mask and the ordered compaction are kernels and only the selected-row count 
 """
 from __future__ import annotations
 
+
 import torch
 
 from .model import _require_cuda, get_engine
@@ -77,6 +78,8 @@ class RefinePolicy:
         self.emb_errs = []              # per-call embedding error of the fp16 path on the sampled rows (max |d| / max |ref|)
         self.band_violations = 0
         self.pending = []               # read-back records of calls whose count has not been taken in yet
+        self.window = 1                 # calls whose near ties share ONE refinement forward (see RefineWindow)
+        self.batch = None               # the RefineWindow collecting calls, if window > 1
         self.calls = self.overflows = 0
         self.max_seen = 0
         self._ring = self._ring_err = None
@@ -157,6 +160,12 @@ class RefinePolicy:
                 still.append(rec)
         self.pending = still[-(self.RING // 2):]
 
+    def flush(self):
+        """Run the refinement forward of the calls collected so far (no-op when nothing is pending): what a caller does
+        at the end of a timed region, or before it changes the weights."""
+        if self.batch is not None:
+            self.batch.flush()
+
     def cap_for(self, n_triplets: int) -> int:
         """Slots for a batch of n_triplets: twice the recent maximum, a power of two, at least cap_min (cap_start
         while fewer than WARM calls have been observed); once that passes half the batch the whole batch is
@@ -164,6 +173,81 @@ class RefinePolicy:
         floor = self.cap_min if self.n_seen >= self.WARM else self.cap_start
         want = max(floor, _pow2ceil(2 * max(self.seen, default=0)))
         return n_triplets if want > n_triplets // 2 else want
+
+
+class RefineWindow:
+    """Near ties of up to `window` consecutive `select_triplets` calls re-embedded by ONE f32-class forward.
+
+    Why: the refinement forward is ~16 launches of a few workgroups each; next to persistent kernels that hold every
+    SIMD's registers they do not overlap with the following forward, they interleave with it -- each side-stream launch
+    delays one main-stream launch by its own length (measured: +0.21 ms on a 1.80 ms forward at 4 slots, whatever the
+    slot count below ~16).  The rows of K calls through the same launches cost the same once instead of K times.
+
+    A call adds its near-tie utterances (gathered on ITS stream into the window's buffer: one launch) and returns a
+    `TripletSelection` that is still open; the K-th call -- or whoever reads an open selection first, or
+    `RefinePolicy.flush()` -- runs the forward on the side stream and completes all of them.  Results are exactly those
+    of per-call refinement: the same rows through the same kernels (per-row results of the eval forward do not depend on
+    the batch they ride in)."""
+
+    def __init__(self, policy, eng, cap, row_shape, device, pw_ref, folded_ref, window, side_stream):
+        self.policy, self.eng, self.cap, self.row_shape = policy, eng, cap, tuple(row_shape)
+        self.pw_ref, self.folded_ref, self.window, self.side = pw_ref, folded_ref, window, side_stream
+        self.xr = torch.empty((window * 3 * cap,) + self.row_shape, dtype=torch.float32, device=device)
+        self.entries = []
+
+    def matches(self, cap, row_shape, pw_ref, folded_ref, side_stream) -> bool:
+        return (cap == self.cap and tuple(row_shape) == self.row_shape and pw_ref is self.pw_ref
+                and folded_ref is self.folded_ref and side_stream == self.side)
+
+    def add(self, t, xs, a, p, n, margin, sel):
+        eng, cap, k = self.eng, self.cap, len(self.entries)
+        rows = xs[0][0].numel()
+        eng.lib.call("ds_gather_rows3_f32", eng._p(xs[0]), eng._p(xs[1]), eng._p(xs[2]), eng._p(t["amb_idx"]),
+                     eng._p(self.xr[k * 3 * cap:(k + 1) * 3 * cap]), cap, rows, eng._stream(a))
+        main = torch.cuda.current_stream(a.device)
+        self.entries.append({"t": t, "a": a, "p": p, "n": n, "margin": float(margin), "sel": sel,
+                             "gathered": main.record_event(), "stream": main})
+        if len(self.entries) >= self.window:
+            self.flush()
+
+    def flush(self):
+        ents, self.entries = self.entries, []
+        if not ents:
+            return
+        if self.policy.batch is self:
+            self.policy.batch = None            # this window's buffer is in flight: the next call opens a new one
+        eng, cap = self.eng, self.cap
+        dev = self.xr.device
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if self.side else cur
+        for en in ents:
+            side.wait_event(en["gathered"])
+        with torch.cuda.stream(side):
+            if side != cur or any(en["stream"] != side for en in ents):
+                self.xr.record_stream(side)
+                for en in ents:
+                    for v in list(en["t"].values()) + [en["a"], en["p"], en["n"]]:
+                        if isinstance(v, torch.Tensor):
+                            v.record_stream(side)
+            st = eng._stream(self.xr)
+            e_ref = eng.forward_eval_planned(self.xr[:len(ents) * 3 * cap], self.pw_ref, self.folded_ref, precision="bf16x3")
+            for k, en in enumerate(ents):
+                t, a, p, n = en["t"], en["a"], en["p"], en["n"]
+                e_k = e_ref[k * 3 * cap:(k + 1) * 3 * cap]
+                d_p, d_n = t["d_p"].clone(), t["d_n"].clone()
+                err = torch.empty(4, dtype=torch.float32, device=dev)
+                eng.lib.call("ds_refine_distances_probe_f32", eng._p(e_k), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
+                             eng._p(d_p), eng._p(d_n), eng._p(t["d_p"]), eng._p(t["d_n"]), eng._p(a), eng._p(p), eng._p(n),
+                             a.shape[1], eng._p(err), st)
+                rb = self.policy.readback(t["amb_count"], err)
+                idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
+                mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])
+                eng.lib.call("ds_triplet_scan_f32", eng._p(d_p), eng._p(d_n), en["margin"], eng._p(loss), eng._p(idx),
+                             eng._p(count), eng._p(mean_diff), d_p.numel(), st)
+                en["sel"]._complete(idx, count, d_p, d_n, mean_diff, loss, rb)
+            ready = side.record_event()
+        for en in ents:
+            en["sel"]._ready = ready if side != cur else None
 
 
 class TripletSelection:
@@ -194,11 +278,23 @@ class TripletSelection:
         self._err = None             # (max observed fp16 error of d_n - d_p over this call's slots, slots sampled)
         self._fallback = fallback    # () -> dict of replacement tensors: the whole batch at f32-class precision
         self._policy = policy
+        self._window = None          # the RefineWindow this selection is still waiting in (select_triplets(window > 1))
         self._resolved = fallback is None or readback is None
         self.refined_all = False     # True once the overflow / band-violation action has replaced the results
         self.band_exceeded = False   # True if this call's own samples showed an error above BAND_VIOLATION x its band
 
+    def _complete(self, idx, count, d_p, d_n, mean_diff, loss, readback):
+        """RefineWindow.flush: the refined results of a selection that was opened with the fp16 ones."""
+        self._idx_full, self._count, self._d_p, self._d_n, self._mean_diff, self._loss = idx, count, d_p, d_n, mean_diff, loss
+        self._readback = readback
+        self._window = None
+
+    def _close(self):
+        if self._window is not None:
+            self._window.flush()        # completes every selection of the window, this one included
+
     def _take(self):
+        self._close()
         if self._n_amb is None:
             self._readback["event"].synchronize()
             self._n_amb, err, n_s, emb_err = self._policy.take(self._readback)
@@ -210,6 +306,7 @@ class TripletSelection:
         """Make sure every near tie was decided at f32-class precision and that the band was wide enough (see the
         class docstring).  Waits on the host for the refinement's event -- the same wait any host-side read of the
         selection implies."""
+        self._close()
         if not self._resolved:
             self._resolved = True
             n_amb = self._take()
@@ -271,6 +368,7 @@ class TripletSelection:
     @property
     def observed_error(self):
         """(largest |fp16 error of d_n - d_p| over this call's slots, slots sampled) or (None, 0); synchronises"""
+        self._close()
         if self._amb_count is None or self._readback is None:
             return (None, 0)
         self._take()
@@ -309,7 +407,7 @@ def refine_policy(model) -> RefinePolicy:
 
 def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tensor, margin: float,
                     model=None, inputs=None, band: float = None, cap: int = None,
-                    side_stream: bool = True) -> TripletSelection:
+                    side_stream: bool = True, window: int = None) -> TripletSelection:
     """train_triplet.py:251-262.  With `model` (a DeepSpeakerModel in eval mode, precision "f16") and `inputs`
     (the three input batches the embeddings came from), near ties are re-embedded at f32-class precision first,
     which makes the selection the reference's (see REFINE_BAND).  The call itself never synchronises with the
@@ -318,7 +416,9 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
     `TripletSelection` orders its consumers after it.  `cap`: re-embedding slots; default: sized by the model's
     `RefinePolicy` from the near-tie counts of earlier calls.  `band`: half-width of the near-tie band; default: the
     policy's, i.e. measured (the slots near ties leave unused carry probe triplets whose fp16 error is read back; a
-    call that observes an error above half its band re-embeds the whole batch when the selection is read)."""
+    call that observes an error above half its band re-embeds the whole batch when the selection is read).
+    `window` (default: the policy's, 1): the near ties of this many consecutive calls share one refinement forward
+    (`RefineWindow`); a selection whose window is still open closes it when it is read."""
     _require_cuda(out_a, "select_triplets")
     eng = get_engine()
     a, p, n = (t.detach().contiguous() for t in (out_a, out_p, out_n))
@@ -358,6 +458,22 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
         e = eng.forward_eval_planned(torch.cat(xs), pw_ref, folded_ref, precision="bf16x3")
         return eng.triplet_tail(*(r.contiguous() for r in e.split(n_trip)), margin)
 
+    window = policy.window if window is None else int(window)
+    if window > 1 and not whole:
+        w = policy.batch
+        if w is not None and not w.matches(cap, xs[0].shape[1:], pw_ref, folded_ref, side_stream):
+            w.flush()                   # other slots / shapes / weights: close what is open, start afresh
+            w = None
+        if w is None:
+            w = policy.batch = RefineWindow(policy, eng, cap, xs[0].shape[1:], a.device, pw_ref, folded_ref, window, side_stream)
+        # opened with the fp16 results (never handed out: every accessor closes the window first)
+        sel = TripletSelection(t["idx"], t["count"], t["d_p"], t["d_n"], t["mean_diff"], t["loss"], t["amb_count"], cap, None,
+                               readback=None, fallback=embed_all, policy=policy, band=band)
+        sel._window, sel._resolved = w, False
+        w.add(t, xs, a, p, n, margin, sel)
+        return sel
+    if policy.batch is not None:
+        policy.batch.flush()            # calls complete in order
     if side_stream:
         side.wait_stream(main)
     with torch.cuda.stream(side):

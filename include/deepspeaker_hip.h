@@ -62,6 +62,14 @@ extern "C" {
 
 int ds_version(void);            /* 100: round 1; 200: round 2 (fp16 path, grouped BatchNorm backward, ds_bn_bwd_partial_rows takes C);
                                     300 / 301: round 3 (persistent fp16 kernels, split grouped BatchNorm backward; + ds_conv_dgrad_bnbwd_bf16) */
+/* launch timing without marker packets: the next MFMA convolution / filter-gradient launch of the calling thread
+ * records its own execution into the armed pair (hipExtLaunchKernelGGL); ds_launch_timing_end() disarms and returns
+ * how many such launches happened since arming (1 = the timed call was a single kernel) */
+int ds_event_create(void **out_event);
+int ds_event_destroy(void *event);
+int ds_event_elapsed_ms(void *start, void *stop, float *ms);     /* waits for `stop` */
+int ds_launch_timing_arm(void *start, void *stop);
+int ds_launch_timing_end(void);
 const char *ds_error_string(int code);
 
 /* ---- layout ---------------------------------------------------------------------------------- */
@@ -177,6 +185,12 @@ int ds_conv_fwd_f16_splitk(const ds_conv_shape *s, const void *x_f16, const void
 int ds_conv_f16_plan_describe(const ds_conv_shape *s, int *out8);
 /* the same under the DS_CONV_HINT_* / DS_CONV_IN_PLANES16 bits of `flags` (what ds_conv_fwd_f16 would launch) */
 int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flags, int *out8);
+/* the pixel tile's LDS layout in that plan: out4 = {records per tile row, bytes per tile row, bytes per segment,
+ * 1000 x LDS cycles of one fragment read (1000 = free of bank conflicts)} */
+int ds_conv_f16_plan_lds_layout(const ds_conv_shape *s, int flags, int *out4);
+/* tuning hook: 1 = pad tile rows / segments by 16-byte units until a fragment read is free of bank conflicts in the
+ * planner's model; default 0 (whole records only: measured equal, tools/ab_layout.py) */
+void ds_conv_f16_set_layout_padding(int on);
 /* One whole BasicBlock in eval mode as ONE kernel (reference model.py:66-82):
  *     y = clip(bn2(conv3x3(clip(bn1(conv3x3(x))))) + x)
  * for the shallow stages (W = 32 with 64 channels, W = 16 with 128: ds_conv_block_f16_supported), where a workgroup
@@ -354,6 +368,10 @@ int ds_bn_bwd_apply_f32(const double *sums, long long count, const float *gy, co
 
 /* row gather and its adjoint (selection of mined candidates and the gradient back to them) */
 int ds_gather_rows_f32(const float *src, const long long *idx, float *dst, int N, int D, void *stream);
+/* dst [3][N][D] = the rows idx[0..N) of three sources in one launch (the utterances of the near-tie triplets; a negative
+ * index gathers zeros); D % 4 == 0, pointers 16-byte aligned */
+int ds_gather_rows3_f32(const float *src_a, const float *src_p, const float *src_n, const long long *idx, float *dst,
+                        int N, int D, void *stream);
 int ds_scatter_add_rows_f32(const float *g, const long long *idx, float *dst, int N, int M, int D,
                             int accumulate, void *stream);
 

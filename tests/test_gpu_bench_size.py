@@ -163,6 +163,60 @@ def test_f16_refinement_margin_concentrated_batch(cfg1):
     assert pol.overflows == 1 and abs(float(second.loss) - float(first.loss)) < 1e-6
 
 
+def test_f16_refinement_window_equals_per_call_refinement(cfg1):
+    """Near ties of several consecutive calls through ONE refinement forward (`RefineWindow`): every tensor a selection
+    hands out is bit-identical to per-call refinement; a selection read while its window is open closes it; a change
+    of slot count closes the open window first."""
+    from deepspeaker_pytorch_amd.mining import refine_policy, select_triplets
+    g, sd, x = cfg1
+    m16, m3 = build(sd, "f16"), build(sd, "bf16x3")
+    with torch.no_grad():
+        e3 = m3(x).clone()
+    diff3 = (select_triplets(e3[:256], e3[256:512], e3[512:], 0.1).d_n
+             - select_triplets(e3[:256], e3[256:512], e3[512:], 0.1).d_p).cpu().numpy()
+    order = np.argsort(diff3)
+    margins = [float((diff3[order[k]] + diff3[order[k + 1]]) / 2) for k in (40, 100, 128, 200, 60)]
+    batches = []
+    for j in range(5):                              # five different batches: the triplets rolled by j * 7
+        idx = torch.roll(torch.arange(256, device="cuda"), j * 7)
+        batches.append(tuple(x[o:o + 256][idx].contiguous() for o in (0, 256, 512)))
+    with torch.no_grad():
+        embs = [m16(torch.cat(b)).clone() for b in batches]
+
+    def run(window, caps):
+        pol = refine_policy(m16)
+        pol.window = window
+        pol.calls = 1000                            # the probe window rotates with the call count: the same in both runs
+        out = []
+        with torch.no_grad():
+            for j, (b, e) in enumerate(zip(batches, embs)):
+                out.append(select_triplets(e[:256], e[256:512], e[512:], margins[j], model=m16, inputs=b, cap=caps[j]))
+        return out
+
+    try:
+        ref = run(1, [16] * 5)
+        got = run(4, [16] * 5)                      # calls 0-3 share a forward, call 4 stays open until read
+        assert got[4]._window is not None and got[0]._window is None
+        assert refine_policy(m16).batch is not None
+        for r, s_ in zip(ref, got):
+            for name in ("indices", "d_p", "d_n", "loss", "mean_diff"):
+                assert torch.equal(getattr(r, name), getattr(s_, name)), name
+            assert r.n_near_ties == s_.n_near_ties and not s_.refine_overflow
+            assert r.observed_error == s_.observed_error
+        assert got[4]._window is None and refine_policy(m16).batch is None
+        for j, s_ in enumerate(got):                # ... and both equal the f32-class selection of that batch
+            want = np.where(np.roll(diff3, j * 7) < np.float32(margins[j]))[0]
+            np.testing.assert_array_equal(s_.indices.cpu().numpy(), want)
+        mixed = run(4, [16, 16, 32, 32, 32])          # a new slot count closes the open window (calls complete in order)
+        assert mixed[0]._window is None and mixed[1]._window is None and mixed[2]._window is not None
+        refine_policy(m16).flush()
+        assert all(s_._window is None for s_ in mixed)
+        for r, s_ in zip(ref, mixed):
+            assert torch.equal(r.indices, s_.indices)
+    finally:
+        refine_policy(m16).window = 1
+
+
 def test_selection_and_loss_on_a_graphed_output(cfg1):
     """a HIP graph's static output keeps its address and its torch version counter across replays; loss and
     selection of the second batch must be the second batch's (nothing may be served from a result keyed on identity)."""
