@@ -82,6 +82,8 @@ _SIGNATURES = {
     "ds_fc_workspace_floats": (c_longlong, [c_int, c_int, c_int]),
     "ds_fc_l2norm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "ds_pairwise_distance_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "ds_pairwise_distance_p_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
+    "ds_pairwise_distance_p_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "ds_triplet_margin_fwd_f32": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_filter_f32": (c_int, [_P, _P, c_float, _P, _P, _P, c_int, _P]),
     "ds_triplet_tail_f32": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -71,6 +71,38 @@ __global__ void __launch_bounds__(256) pairwise_distance_kernel(const float *x1,
     if (row < N && lane == 0) d[row] = sqrtf(s + eps);
 }
 
+// any norm p > 0 (reference model.py:16-18: pow(pow(|x1 - x2|, p).sum(1) + eps, 1 / p)); the reference itself only uses 2
+__global__ void __launch_bounds__(256) pairwise_distance_p_kernel(const float *x1, const float *x2, float *d, int N,
+                                                                  int D, float eps, float p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = row < N ? row : 0;
+    const float *a = x1 + (size_t)r * D, *b = x2 + (size_t)r * D;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += powf(fabsf(a[k] - b[k]), p);
+    s = wave_sum(s);
+    if (row < N && lane == 0) d[row] = powf(s + eps, 1.0f / p);
+}
+
+// d/dx1 of the above = d^(1 - p) * |x1 - x2|^(p - 1) * sign(x1 - x2) (0 where x1 == x2, as torch.abs' gradient); g2 = -g1
+__global__ void __launch_bounds__(256) pairwise_distance_p_bwd_kernel(const float *x1, const float *x2, const float *d,
+                                                                      const float *gd, float *g1, float *g2, int N,
+                                                                      int D, float p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < N) {
+        const float c = gd[row] * powf(d[row], 1.0f - p);
+        const size_t o = (size_t)row * D;
+        for (int k = lane; k < D; k += 64) {
+            const float df = x1[o + k] - x2[o + k];
+            const float ad = fabsf(df);
+            const float g = df == 0.0f ? 0.0f : c * powf(ad, p - 1.0f) * (df > 0.0f ? 1.0f : -1.0f);
+            g1[o + k] = g;
+            g2[o + k] = -g;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) triplet_dist_kernel(const float *a, const float *p, const float *n, float *d_p,
                                                            float *d_n, int N, int D, float eps) {
     const int lane = threadIdx.x & 63;
@@ -647,6 +679,23 @@ extern "C" int ds_pairwise_distance_f32(const float *x1, const float *x2, float 
     DS_REQUIRE(N > 0 && D > 0, DS_ERR_BAD_SHAPE);
     const float eps = (float)(1e-4 / (double)D);     // model.py:15
     DS_LAUNCH(pairwise_distance_kernel, ds_ceil_div(N, 4), 256, 0, stream, x1, x2, d, N, D, eps);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_pairwise_distance_p_f32(const float *x1, const float *x2, float *d, int N, int D, float p,
+                                          void *stream) {
+    DS_REQUIRE(x1 && x2 && d, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0 && p > 0.0f, DS_ERR_BAD_SHAPE);
+    const float eps = (float)(1e-4 / (double)D);     // model.py:15
+    DS_LAUNCH(pairwise_distance_p_kernel, ds_ceil_div(N, 4), 256, 0, stream, x1, x2, d, N, D, eps, p);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_pairwise_distance_p_bwd_f32(const float *x1, const float *x2, const float *d, const float *gd,
+                                              float *g1, float *g2, int N, int D, float p, void *stream) {
+    DS_REQUIRE(x1 && x2 && d && gd && g1 && g2, DS_ERR_NULL);
+    DS_REQUIRE(N > 0 && D > 0 && p > 0.0f, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(pairwise_distance_p_bwd_kernel, ds_ceil_div(N, 4), 256, 0, stream, x1, x2, d, gd, g1, g2, N, D, p);
     return ds_last_launch_error();
 }
 

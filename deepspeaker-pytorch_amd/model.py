@@ -61,19 +61,46 @@ class _PairwiseDistanceFn(torch.autograd.Function):
         return g1, g2
 
 
+class _PairwiseDistancePFn(torch.autograd.Function):
+    """any norm p > 0 (the p = 2 of the reference's call sites has its own kernels above)"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, p):
+        eng = get_engine()
+        x1c, x2c = x1.contiguous().float(), x2.contiguous().float()
+        d = torch.empty(x1c.shape[0], dtype=torch.float32, device=x1c.device)
+        eng.lib.call("ds_pairwise_distance_p_f32", eng._p(x1c), eng._p(x2c), eng._p(d), x1c.shape[0], x1c.shape[1],
+                     float(p), eng._stream(x1c))
+        ctx.save_for_backward(x1c, x2c, d)
+        ctx.p = float(p)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        x1, x2, d = ctx.saved_tensors
+        eng = get_engine()
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
+        gd = gd.contiguous().float()
+        eng.lib.call("ds_pairwise_distance_p_bwd_f32", eng._p(x1), eng._p(x2), eng._p(d), eng._p(gd), eng._p(g1),
+                     eng._p(g2), x1.shape[0], x1.shape[1], ctx.p, eng._stream(x1))
+        return g1, g2, None
+
+
 class PairwiseDistance:
-    """reference model.py:8-18.  `PairwiseDistance(2).forward(x1, x2)` -> [N] distances
-    sqrt(sum |x1-x2|^2 + 1e-4/D).  Only p = 2 exists in the reference's call sites
-    (train_triplet.py:119, model.py:24)."""
+    """reference model.py:8-18.  `PairwiseDistance(p).forward(x1, x2)` -> [N] distances
+    pow(sum |x1-x2|^p + 1e-4/D, 1/p).  The reference's call sites pass 2 (train_triplet.py:119, model.py:24): that is
+    the fused path; any other p > 0 runs the general kernel pair."""
 
     def __init__(self, p):
-        if p != 2:
-            raise NotImplementedError("only the L2 distance (p=2) is used by the reference and implemented")
+        if not float(p) > 0:
+            raise ValueError("the norm p must be positive")
         self.norm = p
 
     def forward(self, x1, x2):
         assert x1.size() == x2.size()                       # reference model.py:14
         _require_cuda(x1, "PairwiseDistance")
+        if self.norm != 2:
+            return _PairwiseDistancePFn.apply(x1, x2, self.norm)
         return _PairwiseDistanceFn.apply(x1, x2)
 
     __call__ = forward

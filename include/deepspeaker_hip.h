@@ -229,6 +229,11 @@ int ds_fc_l2norm_fwd_f32(const float *pooled, const float *w_packed, const float
 /* d[i] = sqrt(sum_k (x1[i,k]-x2[i,k])^2 + 1e-4/D)   (PairwiseDistance, model.py:13-18, p = 2) */
 int ds_pairwise_distance_f32(const float *x1, const float *x2, float *d, int N, int D,
                              void *stream);
+/* the same for any norm p > 0: pow(sum_k |x1 - x2|^p + 1e-4 / D, 1 / p) (reference model.py:13-18 with self.norm = p;
+ * the reference's own call sites pass 2), and its gradient */
+int ds_pairwise_distance_p_f32(const float *x1, const float *x2, float *d, int N, int D, float p, void *stream);
+int ds_pairwise_distance_p_bwd_f32(const float *x1, const float *x2, const float *d, const float *gd, float *g1,
+                                   float *g2, int N, int D, float p, void *stream);
 /* TripletMarginLoss.forward (model.py:27-33): writes d_p[N], d_n[N] and loss[1] = mean hinge. */
 int ds_triplet_margin_fwd_f32(const float *a, const float *p, const float *n, float margin,
                               float *d_p, float *d_n, float *loss, int N, int D, void *stream);

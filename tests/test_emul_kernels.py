@@ -389,6 +389,14 @@ def test_mine_semihard(N, M):
     sel = aligned((N, 512), fill=np.nan)
     lib.call("ds_gather_rows_f32", ptr(cand), ptr(out), ptr(sel), N, 512, None)
     np.testing.assert_array_equal(sel, cand[ref])
+    # the same rows of three sources in one launch (the refinement window's gather); a negative index gathers zeros
+    srcs = [to_aligned(rs.randn(M, 512).astype(np.float32)) for _ in range(3)]
+    pick = to_aligned(np.concatenate([ref[:max(1, N - 1)], [-1]])[:N].astype(np.int64), np.int64)
+    sel3 = aligned((3, N, 512), fill=np.nan)
+    lib.call("ds_gather_rows3_f32", ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]), ptr(pick), ptr(sel3), N, 512, None)
+    for k in range(3):
+        want = np.where(pick[:, None] >= 0, srcs[k][np.maximum(pick, 0)], 0.0).astype(np.float32)
+        np.testing.assert_array_equal(sel3[k], want)
     g = to_aligned(rs.randn(N, 512).astype(np.float32))
     idx = to_aligned(np.array([0, 0, 3, 7, 3][:N] + [1] * max(0, N - 5), np.int64), np.int64)
     dst = aligned((M, 512), fill=np.nan)
@@ -396,6 +404,35 @@ def test_mine_semihard(N, M):
     ref_s = np.zeros((M, 512), np.float32)
     np.add.at(ref_s, idx, g)
     np.testing.assert_allclose(dst, ref_s, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("p", [1.0, 2.0, 3.0, 1.5])
+def test_pairwise_distance_any_norm(p):
+    """reference model.py:13-18 with self.norm = p (its own call sites pass 2): forward against the oracle, the
+    gradient against a central difference of the oracle in float64."""
+    lib = emul_lib()
+    rs = np.random.RandomState(int(p * 10))
+    N, D = 6, 512
+    x1 = to_aligned(rs.randn(N, D).astype(np.float32))
+    x2 = to_aligned(rs.randn(N, D).astype(np.float32))
+    x2[0, :5] = x1[0, :5]                                    # exact zeros of the difference: gradient 0 there
+    d = aligned(N, fill=np.nan)
+    lib.call("ds_pairwise_distance_p_f32", ptr(x1), ptr(x2), ptr(d), N, D, p, None)
+    ref = O.pairwise_distance(x1, x2, p)
+    assert rel_err(d, ref) < 2e-6
+    if p == 2.0:
+        d2 = aligned(N, fill=np.nan)
+        lib.call("ds_pairwise_distance_f32", ptr(x1), ptr(x2), ptr(d2), N, D, None)
+        assert rel_err(d, d2) < 1e-6
+    gd = to_aligned(rs.randn(N).astype(np.float32))
+    g1, g2 = aligned((N, D), fill=np.nan), aligned((N, D), fill=np.nan)
+    lib.call("ds_pairwise_distance_p_bwd_f32", ptr(x1), ptr(x2), ptr(d), ptr(gd), ptr(g1), ptr(g2), N, D, p, None)
+    np.testing.assert_array_equal(g2, -g1)
+    assert np.all(g1[0, :5] == 0.0)
+    diff = x1.astype(np.float64) - x2.astype(np.float64)
+    s = (np.abs(diff) ** p).sum(1) + 1e-4 / D
+    want = gd[:, None] * (s ** (1.0 / p - 1.0))[:, None] * np.abs(diff) ** (p - 1.0) * np.sign(diff)
+    assert rel_err(g1, want.astype(np.float32)) < 5e-6
 
 
 BF16_CASES = [

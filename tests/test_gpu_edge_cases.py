@@ -75,6 +75,26 @@ def test_filter_selects_nothing_and_everything():
     assert one.n_selected == 1
 
 
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_pairwise_distance_any_norm_with_autograd(p):
+    """reference model.py:8-18 accepts any norm (its call sites pass 2): forward and both gradients against the same
+    formula in plain torch on the CPU."""
+    from deepspeaker_pytorch_amd.model import PairwiseDistance
+    g = torch.Generator().manual_seed(5 + p)
+    x1 = torch.randn(37, 512, generator=g)
+    x2 = torch.randn(37, 512, generator=g)
+    w = torch.randn(37, generator=g)
+    r1, r2 = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+    ref = torch.pow(torch.pow(torch.abs(r1 - r2), p).sum(dim=1) + 1e-4 / 512, 1.0 / p)       # model.py:15-18
+    (ref * w).sum().backward()
+    d1, d2 = x1.cuda().requires_grad_(), x2.cuda().requires_grad_()
+    out = PairwiseDistance(p).forward(d1, d2)
+    (out * w.cuda()).sum().backward()
+    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=2e-6, atol=1e-6)
+    assert torch.allclose(d1.grad.cpu(), r1.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(d2.grad.cpu(), r2.grad, rtol=1e-5, atol=1e-6)
+
+
 def test_hinge_exactly_zero_has_subgradient_one():
     """TripletMarginLoss at the kink (model.py:30-31, clamp(min=0)): with margin 0 and positive == negative the hinge
     argument is exactly 0; torch's clamp passes the gradient there, so d_p and d_n still get +-1/N."""

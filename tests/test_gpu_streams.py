@@ -72,3 +72,40 @@ def test_graph_replay_next_to_eager_f16_launches():
         assert torch.equal(e, ref_a)
     for e in got_b:
         assert torch.equal(e, ref_b)
+
+
+def test_launch_bound_events_read_the_kernel_and_leave_results_alone():
+    """Per-launch timing of the bench's live roofline: events bound to the launch itself (ds_launch_timing_arm ->
+    hipExtLaunchKernelGGL) instead of an event pair recorded around it.  Same results bit for bit, one timed launch per
+    call, durations that agree with the event-pair measurement of the same launches (which contains them)."""
+    from deepspeaker_pytorch_amd.model import get_engine
+    sd = O.make_state_dict(seed=11, num_classes=16)
+    m = build(sd)
+    x = torch.from_numpy(O.make_input(seed=903, batch=192, frames=160)).cuda()
+    eng = get_engine()
+    with torch.no_grad():
+        ref = m(x).clone()
+        torch.cuda.synchronize()
+        out = {}
+        for bound in (True, False):
+            eng.self_timed_launches = bound
+            for _ in range(3):
+                m(x)
+            torch.cuda.synchronize()
+            eng.profile = []
+            e = m(x).clone()
+            torch.cuda.synchronize()
+            prof, eng.profile = eng.profile, None
+            assert torch.equal(e, ref)
+            out[bound] = [(label, e0.elapsed_time(e1)) for label, _, e0, e1, prec in prof if prec == "f16"]
+        eng.self_timed_launches = True
+    assert [l for l, _ in out[True]] == [l for l, _ in out[False]] and len(out[True]) == 9
+    from deepspeaker_pytorch_amd.engine import LaunchEvent
+    for (label, t_bound), (_, t_pair) in zip(out[True], out[False]):
+        print(f"{label:32s} launch-bound {t_bound * 1e3:7.1f} us   event pair {t_pair * 1e3:7.1f} us")
+        assert 0.003 < t_bound < 5.0 and t_bound < t_pair * 1.25 + 0.01
+    assert sum(t for _, t in out[True]) <= sum(t for _, t in out[False]) * 1.1
+    # an armed pair that no launch consumed is simply dropped
+    a, b = LaunchEvent(eng.lib), LaunchEvent(eng.lib)
+    eng.lib.call("ds_launch_timing_arm", a.handle, b.handle)
+    assert eng.lib.raw("ds_launch_timing_end")() == 0

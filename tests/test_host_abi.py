@@ -56,8 +56,9 @@ def test_python_surface_matches_reference_contract():
     m2 = DeepSpeakerModel(512, 1211)
     m2.load_state_dict(ck["state_dict"])
     assert TripletMarginLoss(0.1).margin == 0.1 and PairwiseDistance(2).norm == 2
-    with pytest.raises(NotImplementedError):
-        PairwiseDistance(1)
+    assert PairwiseDistance(1).norm == 1                     # any positive norm, as the reference's constructor
+    with pytest.raises(ValueError):
+        PairwiseDistance(0)
 
 
 def test_no_cpu_fallback():

@@ -111,14 +111,14 @@ def main():
     # ---- what each part of the step costs on top of the forward ----
     mining._side_streams[dev] = normal
 
-    def variant(refine, loss, mine):
+    def variant(refine, loss, mine, mine_side=True):
         def one():
             with torch.no_grad():
                 e_all = model(data_all)
                 embs = list(e_all.split(256))
                 sel = select_triplets(*embs, margin=0.1, model=model if refine else None, inputs=data)
                 l_ = loss_fn.forward(*embs) if loss else None
-                m_ = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels, side_stream=True) if mine else None
+                m_ = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels, side_stream=mine_side) if mine else None
             return sel, l_, m_
 
         def run(n):
@@ -136,6 +136,8 @@ def main():
                       ("forward + filter + loss", (False, True, False)),
                       ("forward + filter + refinement", (True, False, False)),
                       ("forward + filter + search", (False, False, True)),
+                      ("forward + filter + search on main", (False, False, True, False)),
+                      ("whole step, search on main", (True, True, True, False)),
                       ("whole step", (True, True, True))):
         print(f"{name:36s} {variant(*cfg):.4f} ms")
     def prof_steps(n):
@@ -170,6 +172,7 @@ def main():
     for w in (2, 4, 8):
         refine_policy(model).window = w
         print(f"whole step, refinement window {w:2d}      {variant(True, True, True):.4f} ms")
+        print(f"  ... and the search on the main stream  {variant(True, True, True, False):.4f} ms")
         print(f"forward + filter + refinement, w {w:2d}  {variant(True, False, False):.4f} ms")
     refine_policy(model).flush()
     refine_policy(model).window = 1
