@@ -247,7 +247,7 @@ def main():
     c2 = (c1 + 1 + torch.randint(0, 63, (BATCH_TRIPLETS,), generator=g)) % 64
     c1, c2 = c1.to(dev), c2.to(dev)
     labels_loc = torch.cat([c1, c1, c2])
-    n_slots = max(1, args.streams)              # steps in flight, each with its own gather buffers
+    n_slots = max(2, args.streams)              # steps in flight, each with its own gather buffers (2: the `pipelined` secondary)
     # two sets of gather buffers per slot, used alternately: the search over one set (side stream, overlapped with the
     # next forward) is long done when that set is gathered into again two steps later
     emb_globs = [[torch.empty(world * 3 * BATCH_TRIPLETS, 512, device=dev) if multi else None for _ in range(2)]
@@ -255,7 +255,7 @@ def main():
     lab_globs = [[torch.empty(world * 3 * BATCH_TRIPLETS, dtype=torch.int64, device=dev) if multi else None
                   for _ in range(2)] for _ in range(n_slots)]
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(2, args.streams))]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -268,19 +268,21 @@ def main():
         model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()})
         return model.to(dev)
 
-    def region(step, steps, finish=None):
+    def region(step, steps, finish=None, in_flight=None):
         """K steps bracketed by barrier + synchronize on both sides; max over ranks.  `finish`: enqueued after the K-th step,
-        inside the region (closes what the steps left open: the refinement window)."""
+        inside the region (closes what the steps left open: the refinement window).  `in_flight` (default --streams):
+        consecutive steps alternate over this many HIP streams."""
+        in_flight = args.streams if in_flight is None else in_flight
         fence()
         t0 = time.perf_counter()
-        if args.streams > 1:
+        if in_flight > 1:
             cur = torch.cuda.current_stream(dev)
-            for st_ in streams:
+            for st_ in streams[:in_flight]:
                 st_.wait_stream(cur)
             for i in range(steps):
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    step(i % len(streams))
-            for st_ in streams:
+                with torch.cuda.stream(streams[i % in_flight]):
+                    step(i % in_flight)
+            for st_ in streams[:in_flight]:
                 cur.wait_stream(st_)
         else:
             for _ in range(steps):
@@ -313,7 +315,7 @@ def main():
         prof_on()
         for _ in range(warmup):
             step()
-        for j, st_ in enumerate(streams):       # launch plans / allocator pools of the side streams
+        for j, st_ in enumerate(streams[:args.streams] if args.streams > 1 else []):   # launch plans / allocator pools
             with torch.cuda.stream(st_):
                 step(j)
         if finish is not None:
@@ -422,9 +424,27 @@ def main():
                 # re-embeds the whole batch when its selection is READ (after the timed region): say so in the line
                 refine["flag"] = (f"{fallbacks} of the {len(last)} timed steps fell back to a whole-batch f32-class "
                                   "re-embedding at read time; that work is NOT inside `value`")
+        # The same step with TWO steps in flight: consecutive (independent) steps alternate over two HIP streams, so one
+        # step's HBM- / latency-bound launches (conv1, pooling + projection, loss, filter, refinement, search) and the drain
+        # of each persistent kernel run beside the other step's matrix kernels.  Reported as `pipelined`, never as `value`:
+        # launches of two steps then share the chip, which the per-launch roofline of the contract line must not see.
+        if repeats > 0 and not multi and args.streams == 1 and not args.split_apn and precision == args.precision:
+            for j in range(2):
+                with torch.cuda.stream(streams[j]):
+                    step(j)
+                    step(j)
+            fence()
+            refine_policy(model).flush()
+            runs = [region(step, steps, refine_policy(model).flush, in_flight=2)[0] / steps * 1e3 for _ in range(3)]
+            extras["pipelined"] = {"steps_in_flight": 2, "ms_per_step": round(float(np.median(runs)), 3),
+                                   "value": round(emb_per_step / float(np.median(runs)) * 1e3, 1), "unit": "embeddings/s",
+                                   "runs_ms_per_step": [round(v, 3) for v in runs],
+                                   "what": "the same K-step region with consecutive steps alternating over two HIP streams "
+                                           "(every step complete inside the bracket); results are the same tensors"}
         return elapsed, prof, again, refine, isolated
 
     red_modes = [None, None]
+    extras = {}
 
     def measure_train(precision, steps, warmup, repeats=0):
         """The training step of the triplet regime (train_triplet.py:215-224): train-mode forwards of a / p / n
@@ -586,6 +606,8 @@ def main():
                                           "max": round(max(again), 3), "n": len(again)}
         if refine is not None:
             out["refine"] = refine
+        if "pipelined" in extras:
+            out["pipelined"] = extras["pipelined"]
         if isolated is not None:
             iso_ms, iso_prof = isolated
             ir = roofline_of(args.precision, iso_prof, 10)

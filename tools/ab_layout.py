@@ -168,7 +168,58 @@ def main():
         print(f"per-launch timing {k:20s}: step ms median {statistics.median(a for a, _ in v):.4f}, timed convolutions "
               f"{statistics.median(b for _, b in v):.4f} ms/step")
 
+    # ---- the batch's forward as concurrent parts on their own streams (per-utterance results do not depend on batching) ----
     from deepspeaker_pytorch_amd.mining import refine_policy
+    refine_policy(model).window = 4
+    part_streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+
+    def parts_step(n_parts):
+        cur = torch.cuda.current_stream(dev)
+        xs = list(data_all.split(768 // n_parts))
+        outs = []
+        with torch.no_grad():
+            for k, xk in enumerate(xs):
+                st_ = part_streams[k]
+                st_.wait_stream(cur)
+                with torch.cuda.stream(st_):
+                    outs.append(model(xk))
+            for k in range(len(xs)):
+                cur.wait_stream(part_streams[k])
+                outs[k].record_stream(cur)
+            e_all = torch.cat(outs)
+            embs = list(e_all.split(256))
+            sel = select_triplets(*embs, margin=0.1, model=model, inputs=data)
+            loss = loss_fn.forward(*embs)
+            mined = mine_semihard_negatives(embs[0], embs[1], c1, e_all, labels, side_stream=True)
+        return loss, sel, mined, e_all
+
+    def run_parts(n_parts, n):
+        keep = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            keep.append(parts_step(n_parts) if n_parts > 1 else step())
+        refine_policy(model).flush()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    with torch.no_grad():
+        whole = model(data_all).clone()
+    for n_parts in (2, 3, 4):
+        e_parts = parts_step(n_parts)[3]
+        torch.cuda.synchronize()
+        print(f"forward as {n_parts} concurrent parts: embeddings bit-identical to the single launch sequence:",
+              bool(torch.equal(e_parts, whole)))
+    res_p = {1: [], 2: [], 3: [], 4: []}
+    for r in range(args.rounds):
+        for n_parts in res_p:
+            run_parts(n_parts, 5)
+            res_p[n_parts].append(run_parts(n_parts, 20))
+    for n_parts, v in res_p.items():
+        print(f"whole step, forward as {n_parts} concurrent part(s): median {statistics.median(v):.4f} ms  all "
+              + " ".join(f"{t:.3f}" for t in v))
+    refine_policy(model).window = 1
+
     for w in (2, 4, 8):
         refine_policy(model).window = w
         print(f"whole step, refinement window {w:2d}      {variant(True, True, True):.4f} ms")
