@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--refine-window", type=int, default=4,
+    ap.add_argument("--refine-window", type=int, default=8,
                     help="steps whose near ties share one refinement forward (mining.RefineWindow; 1 = every step its own): "
                          "the timed region ends with the open window flushed, so all of the refinement is inside it")
     ap.add_argument("--refine-slots", type=int, default=0,

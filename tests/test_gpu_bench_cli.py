@@ -32,7 +32,7 @@ def test_bench_line_contract_single_gpu():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "workload" in d["config"]
     # round 4: the refinement window is reported, and the same region with two steps in flight as a secondary
-    assert d["refine"]["window_steps"] == 4 and d["config"]["steps_in_flight"] == 1
+    assert d["refine"]["window_steps"] == 8 and d["config"]["steps_in_flight"] == 1
     p = d["pipelined"]
     assert p["steps_in_flight"] == 2 and p["value"] > 0.95 * d["value"], (p, d["value"])
 

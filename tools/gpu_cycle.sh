@@ -24,7 +24,7 @@ for w in $WHAT; do
     benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?"; cat $OUT/benchq.json | head -c 4000 ;;
     train) timeout 600 python bench.py --train --no-cpu-baseline > $OUT/train.json 2> $OUT/train.err; echo "train rc=$?"; cat $OUT/train.json
            MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 timeout 600 python bench.py --train --force-collectives --no-cpu-baseline > $OUT/train_dp.json 2> $OUT/train_dp.err; echo "train_dp rc=$?"; cat $OUT/train_dp.json ;;
-    prof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/prof.log 2>&1); echo "prof rc=$?"
+    prof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -- python $R/bench.py --steps 10 --warmup 2 --repeats 0 --no-cpu-baseline --no-secondary > $OUT/prof.log 2>&1); echo "prof rc=$?"
           python tools/rocpd_stats.py $(find $OUT/prof -name "*.db") > $OUT/kernel_stats.md 2>$OUT/kernel_stats.err; head -40 $OUT/kernel_stats.md
           python tools/step_timeline.py $(find $OUT/prof -name "*.db") > $OUT/step_timeline.txt 2>&1; tail -4 $OUT/step_timeline.txt ;;
     trainprof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trainprof -- python $R/bench.py --train --steps 6 --warmup 2 --repeats 0 --no-cpu-baseline > $OUT/trainprof.log 2>&1); echo "trainprof rc=$?"
@@ -40,7 +40,7 @@ for w in $WHAT; do
     traintests) timeout 1200 python -m pytest tests/test_gpu_train_parity.py tests/test_gpu_parity.py tests/test_gpu_bench_cli.py -m gpu -x -q -s > $OUT/pytest_train.log 2>&1; echo "pytest(train) rc=$?"; tail -15 $OUT/pytest_train.log ;;
     fwdstreams) timeout 300 python tools/train_fwd_streams.py 2>&1 | grep -v amdgpu.ids | tee $OUT/train_fwd_streams.txt ;;
     pmc16) timeout 1500 tools/pmc_run.sh $TAG/pmc16 --train --train-precision f16 --repeats 0; python tools/pmc_train_summary.py $OUT/pmc16 > $OUT/pmc_train16_summary.md 2> $OUT/pmc_train16_summary.err; head -70 $OUT/pmc_train16_summary.md ;;
-    pmc) timeout 1200 tools/pmc_run.sh $TAG/pmc --no-secondary; python tools/pmc_summary.py $OUT/pmc kernel 52 > $OUT/pmc_summary.md 2> $OUT/pmc_summary.err; head -60 $OUT/pmc_summary.md ;;
+    pmc) timeout 1200 tools/pmc_run.sh $TAG/pmc --no-secondary --repeats 0; python tools/pmc_summary.py $OUT/pmc kernel 52 > $OUT/pmc_summary.md 2> $OUT/pmc_summary.err; head -60 $OUT/pmc_summary.md ;;
     sideprio) for i in 1 2; do for m in normal low; do DS_SIDE_STREAM_PRIORITY=$m timeout 300 python bench.py --no-secondary --no-cpu-baseline --repeats 3 > $OUT/sideprio_$m.json 2> $OUT/sideprio_$m.err; python -c "import json;d=json.load(open('$OUT/sideprio_$m.json'));print('side stream priority','$m',d['value'],d['ms_per_step'],d['repeats_ms_per_step'],d['roofline']['achieved'],d['roofline']['isolated']['achieved'])"; done; done ;;
     hostprof) timeout 300 python tools/host_profile.py > $OUT/host_profile.txt 2>&1; echo "hostprof rc=$?"; grep -E "host enqueue" $OUT/host_profile.txt
               timeout 300 python tools/host_profile.py --events 2>&1 | grep -E "host enqueue" ;;
