@@ -26,6 +26,12 @@ class ConvShape(Structure):
                 ("Cout", c_int), ("KS", c_int), ("stride", c_int)]
 
 
+class PackJob(Structure):
+    """struct ds_pack_job"""
+    _fields_ = [("w_oihw", c_void_p), ("out", c_void_p), ("out2", c_void_p),
+                ("Cout", c_int), ("Cin", c_int), ("KS", c_int), ("mode", c_int)]
+
+
 class DeepSpeakerHipError(RuntimeError):
     pass
 
@@ -65,6 +71,8 @@ _SIGNATURES = {
     "ds_conv_bf16_plan_describe": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
     "ds_conv_fwd_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_pack_conv_weight_f16": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_pack_conv_weights_f16_batch": (c_int, [POINTER(PackJob), c_int, _P]),
+    "ds_pack_conv_weights_bf16_batch": (c_int, [POINTER(PackJob), c_int, _P]),
     "ds_conv_fwd_f16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_conv_f16_splitk_workspace_bytes": (c_longlong, [POINTER(ConvShape)]),
     "ds_conv_fwd_f16_splitk": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, c_int, _P, c_longlong, _P]),

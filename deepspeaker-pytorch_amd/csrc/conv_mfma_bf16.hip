@@ -24,12 +24,12 @@ namespace {
 
 // OIHW f32 -> [Cin/16][tap][Cout][16] bf16 hi (+ lo = bf16(w - hi))
 // dgrad != 0: the transposed, spatially flipped bank of the stride-1 data gradient (N = Cin, K = Cout)
-__global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float *w, __bf16 *hi, __bf16 *lo, int Cout,
-                                                                    int Cin, int KS, int dgrad) {
+__device__ __forceinline__ void pack_conv_weight_bf16_body(const float *w, __bf16 *hi, __bf16 *lo, int Cout, int Cin, int KS,
+                                                           int dgrad, int block, int n_blocks) {
     const int T = KS * KS;
     const long long n = (long long)Cout * Cin * T;
     const int N = dgrad ? Cin : Cout;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    for (long long i = (long long)block * 256 + threadIdx.x; i < n; i += (long long)n_blocks * 256) {
         const int kk = (int)(i & 15);
         long long r = i >> 4;
         const int nn = (int)(r % N);
@@ -45,6 +45,27 @@ __global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float 
         hi[i] = h;
         if (lo) lo[i] = (__bf16)(v - (float)h);
     }
+}
+
+__global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float *w, __bf16 *hi, __bf16 *lo, int Cout,
+                                                                    int Cin, int KS, int dgrad) {
+    pack_conv_weight_bf16_body(w, hi, lo, Cout, Cin, KS, dgrad, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// all filters of a weight version in one launch: job j owns the workgroups [first[j], first[j + 1])
+struct PackBatchB {
+    const float *w[DS_PACK_BATCH_MAX];
+    __bf16 *hi[DS_PACK_BATCH_MAX], *lo[DS_PACK_BATCH_MAX];
+    int Cout[DS_PACK_BATCH_MAX], Cin[DS_PACK_BATCH_MAX], KS[DS_PACK_BATCH_MAX], dgrad[DS_PACK_BATCH_MAX];
+    int first[DS_PACK_BATCH_MAX + 1];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) pack_conv_weight_bf16_batch_kernel(const PackBatchB J) {
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;
+    pack_conv_weight_bf16_body(J.w[j], J.hi[j], J.lo[j], J.Cout[j], J.Cin[j], J.KS[j], J.dgrad[j], (int)blockIdx.x - J.first[j],
+                               J.first[j + 1] - J.first[j]);
 }
 
 // LDS cycles (1 = conflict-free) of one ds_read_b128 fragment read for a candidate row pitch: simulates
@@ -212,6 +233,30 @@ static int pack_bf16(const float *w_oihw, void *w_hi, void *w_lo, int Cout, int 
     long long g = (n + 255) / 256;
     DS_LAUNCH(pack_conv_weight_bf16_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w_oihw, (__bf16 *)w_hi,
               (__bf16 *)w_lo, Cout, Cin, KS, dgrad);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_pack_conv_weights_bf16_batch(const ds_pack_job *jobs, int n_jobs, void *stream) {
+    DS_REQUIRE(jobs != nullptr, DS_ERR_NULL);
+    DS_REQUIRE(n_jobs > 0 && n_jobs <= DS_PACK_BATCH_MAX, DS_ERR_BAD_SHAPE);
+    PackBatchB J;
+    J.n = n_jobs;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const ds_pack_job &b = jobs[j];
+        DS_REQUIRE(b.w_oihw && b.out, DS_ERR_NULL);
+        DS_REQUIRE((b.mode == 0 || b.mode == 1) && b.Cout > 0 && b.Cin > 0, DS_ERR_BAD_SHAPE);
+        DS_REQUIRE(b.KS == 3 || b.KS == 5, DS_ERR_UNSUPPORTED);
+        DS_REQUIRE((b.mode ? b.Cout : b.Cin) % 16 == 0, DS_ERR_BAD_SHAPE);
+        J.w[j] = b.w_oihw; J.hi[j] = (__bf16 *)b.out; J.lo[j] = (__bf16 *)b.out2;
+        J.Cout[j] = b.Cout; J.Cin[j] = b.Cin; J.KS[j] = b.KS; J.dgrad[j] = b.mode;
+        const long long n = (long long)b.Cout * b.Cin * b.KS * b.KS;
+        const long long g = (n + 255) / 256;
+        J.first[j] = blocks;
+        blocks += (int)(g > 512 ? 512 : g);
+    }
+    J.first[n_jobs] = blocks;
+    DS_LAUNCH(pack_conv_weight_bf16_batch_kernel, blocks, 256, 0, stream, J);
     return ds_last_launch_error();
 }
 

@@ -18,12 +18,12 @@ namespace {
 //           4 Cin output channels, one block of Cin per parity class (a, b) of the input pixel (2i + a, 2j + b):
 //           dX[2i+a, 2j+b, ci] = sum_{r,c,co} dY[i-1+r, j-1+c, co] * w[co][ci][a + 2(2-r)][b + 2(2-c)]   (taps with a
 //           kernel index of 5 do not exist: zero).  K = Cout, N = 4 Cin (n = (2a + b) Cin + ci), taps = 3 x 3.
-__global__ void __launch_bounds__(256) pack_conv_weight_f16_kernel(const float *w, _Float16 *out, int Cout, int Cin,
-                                                                   int KS, int mode) {
+__device__ __forceinline__ void pack_conv_weight_f16_body(const float *w, _Float16 *out, int Cout, int Cin, int KS, int mode,
+                                                          int block, int n_blocks) {
     const int TK = mode == 2 ? 3 : KS, T = TK * TK;
     const int N = mode == 0 ? Cout : (mode == 1 ? Cin : 4 * Cin), K = mode == 0 ? Cin : Cout;
     const long long n = (long long)N * K * T;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    for (long long i = (long long)block * 256 + threadIdx.x; i < n; i += (long long)n_blocks * 256) {
         const int kk = (int)(i & 15);
         long long r = i >> 4;
         const int nn = (int)(r % N);
@@ -47,6 +47,27 @@ __global__ void __launch_bounds__(256) pack_conv_weight_f16_kernel(const float *
         }
         out[i] = (_Float16)v;
     }
+}
+
+__global__ void __launch_bounds__(256) pack_conv_weight_f16_kernel(const float *w, _Float16 *out, int Cout, int Cin,
+                                                                   int KS, int mode) {
+    pack_conv_weight_f16_body(w, out, Cout, Cin, KS, mode, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// all filters of a weight version in one launch: job j owns the workgroups [first[j], first[j + 1])
+struct PackBatchH {
+    const float *w[DS_PACK_BATCH_MAX];
+    _Float16 *out[DS_PACK_BATCH_MAX];
+    int Cout[DS_PACK_BATCH_MAX], Cin[DS_PACK_BATCH_MAX], KS[DS_PACK_BATCH_MAX], mode[DS_PACK_BATCH_MAX];
+    int first[DS_PACK_BATCH_MAX + 1];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) pack_conv_weight_f16_batch_kernel(const PackBatchH J) {
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;
+    pack_conv_weight_f16_body(J.w[j], J.out[j], J.Cout[j], J.Cin[j], J.KS[j], J.mode[j], (int)blockIdx.x - J.first[j],
+                              J.first[j + 1] - J.first[j]);
 }
 
 __global__ void __launch_bounds__(256) cast_f32_to_f16_kernel(const float *x, _Float16 *y, long long n) {
@@ -297,6 +318,31 @@ static int pack_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS,
     long long g = (n + 255) / 256;
     DS_LAUNCH(pack_conv_weight_f16_kernel, (int)(g > 4096 ? 4096 : g), 256, 0, stream, w_oihw, (_Float16 *)w_f16, Cout,
               Cin, KS, mode);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_pack_conv_weights_f16_batch(const ds_pack_job *jobs, int n_jobs, void *stream) {
+    DS_REQUIRE(jobs != nullptr, DS_ERR_NULL);
+    DS_REQUIRE(n_jobs > 0 && n_jobs <= DS_PACK_BATCH_MAX, DS_ERR_BAD_SHAPE);
+    PackBatchH J;
+    J.n = n_jobs;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const ds_pack_job &b = jobs[j];
+        DS_REQUIRE(b.w_oihw && b.out, DS_ERR_NULL);
+        DS_REQUIRE(b.mode >= 0 && b.mode <= 2 && b.Cout > 0 && b.Cin > 0, DS_ERR_BAD_SHAPE);
+        DS_REQUIRE(b.KS == 3 || b.KS == 5, DS_ERR_UNSUPPORTED);
+        DS_REQUIRE((b.mode == 0 ? b.Cin : b.Cout) % 16 == 0, DS_ERR_BAD_SHAPE);
+        DS_REQUIRE(b.mode != 2 || b.KS == 5, DS_ERR_UNSUPPORTED);
+        J.w[j] = b.w_oihw; J.out[j] = (_Float16 *)b.out;
+        J.Cout[j] = b.Cout; J.Cin[j] = b.Cin; J.KS[j] = b.KS; J.mode[j] = b.mode;
+        const long long n = (long long)b.Cout * b.Cin * (b.mode == 2 ? 36 : b.KS * b.KS);
+        const long long g = (n + 255) / 256;
+        J.first[j] = blocks;
+        blocks += (int)(g > 512 ? 512 : g);
+    }
+    J.first[n_jobs] = blocks;
+    DS_LAUNCH(pack_conv_weight_f16_batch_kernel, blocks, 256, 0, stream, J);
     return ds_last_launch_error();
 }
 

@@ -77,6 +77,19 @@ int ds_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W, vo
 int ds_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
 
 /* ---- weight packing (one-off per weight version; not on the per-batch path) ------------------- */
+/* Many filters in ONE launch (a training step re-packs every filter after every optimizer step: 22 launches of ~5 us
+ * each in the fp16 mode, 19 in the bf16x3 mode, became one each).  A job = one ds_pack_conv_weight_{f16,bf16} call:
+ * mode 0 forward bank, 1 stride-1 data-gradient bank (transposed, flipped), 2 (f16 only) the 5x5 stride-2 layer's
+ * parity-class data-gradient bank.  out2: the bf16 "lo" bank (bf16 family; may be NULL), unused by the f16 family.
+ * At most DS_PACK_BATCH_MAX jobs per call. */
+#define DS_PACK_BATCH_MAX 32
+typedef struct ds_pack_job {
+    const float *w_oihw;
+    void *out, *out2;
+    int Cout, Cin, KS, mode;
+} ds_pack_job;
+int ds_pack_conv_weights_f16_batch(const ds_pack_job *jobs, int n_jobs, void *stream);
+int ds_pack_conv_weights_bf16_batch(const ds_pack_job *jobs, int n_jobs, void *stream);
 /* OIHW [Cout,Cin,KS,KS] -> [Cin/8][KS*KS][Cout][8].  dgrad != 0 packs the transposed, spatially
  * flipped filter bank used by ds_conv_dgrad_f32 (Cout and Cin swap roles).
  * Replaces: nothing in the reference (cuDNN picks its own filter layout, model.py:47-50,93-106). */
