@@ -326,6 +326,17 @@ def main():
             print(f"[bench] host enqueue {t_enq / steps * 1e3:.3f} ms/step, device-complete {elapsed / steps * 1e3:.3f} ms/step",
                   file=sys.stderr)
         prof, eng.profile = (eng.profile or []), None
+        try:                                    # the launch-bound events of the region must all read back
+            for p_ in prof:
+                p_[2].elapsed_time(p_[3])
+        except Exception as exc:                # (never seen; a driver that does not bind them must not cost the line)
+            if rank == 0:
+                print(f"[bench] launch-bound events failed ({exc}); the roofline is timed with event pairs over one more "
+                      f"region -- `value` stays the first region's", file=sys.stderr)
+            eng.self_timed_launches = False
+            prof_on()
+            region(step, steps, finish)
+            prof, eng.profile = (eng.profile or []), None
         # the same region again, `repeats` times, without the per-launch events: the spread of the box
         again = [region(step, steps, finish)[0] / steps * 1e3 for _ in range(repeats)]
         if rank == 0 and again:

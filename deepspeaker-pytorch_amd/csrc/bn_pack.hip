@@ -4,6 +4,7 @@
 //   * elementwise normalise (+residual, +clipped ReLU) for the train-mode path
 //   * OIHW -> packed filter layouts, NCHW <-> channels-last conversion
 #include <ds_device.h>
+#include <unistd.h>
 #include "ds_common.h"
 #include <map>
 #include <mutex>
@@ -408,15 +409,25 @@ extern "C" int ds_event_destroy(void *event) {
 #endif
 }
 
-// milliseconds between two events (waits for `stop` first)
+// milliseconds between two events (waits for `stop` first, at most 2 s)
 extern "C" int ds_event_elapsed_ms(void *start, void *stop, float *ms) {
     DS_REQUIRE(start && stop && ms, DS_ERR_NULL);
 #ifdef DS_EMULATED
     return DS_ERR_UNSUPPORTED;
 #else
-    hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
-    if (rc != hipSuccess) return (int)rc;
-    return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    // bounded wait (2 s): an event that was armed but never bound to a launch must not hang the caller
+    hipError_t rc = hipEventQuery((hipEvent_t)stop);
+    for (int i = 0; rc == hipErrorNotReady && i < 20000; ++i) {
+        usleep(100);
+        rc = hipEventQuery((hipEvent_t)stop);
+    }
+    if (rc != hipSuccess) {
+        (void)hipGetLastError();
+        return (int)rc;
+    }
+    rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    if (rc != hipSuccess) (void)hipGetLastError();
+    return (int)rc;
 #endif
 }
 

@@ -109,3 +109,8 @@ def test_launch_bound_events_read_the_kernel_and_leave_results_alone():
     a, b = LaunchEvent(eng.lib), LaunchEvent(eng.lib)
     eng.lib.call("ds_launch_timing_arm", a.handle, b.handle)
     assert eng.lib.raw("ds_launch_timing_end")() == 0
+    import time
+    t0 = time.perf_counter()
+    with pytest.raises(Exception):              # ... and reading it is an error, not a hang (bench.py falls back to pairs)
+        a.elapsed_time(b)
+    assert time.perf_counter() - t0 < 5.0
