@@ -21,6 +21,14 @@ def run_bench(*flags, port):
     return json.loads(lines[0])
 
 
+def settled_ms(d):
+    """ms per step of a run: the timed region, or the median of its repeats if that is lower -- the first region of a
+    process started right after another one exits has been seen 15 - 30 % slow on the host side (11 ms of enqueue per step
+    instead of 7.6), the repeats of the same run at the usual 18.8 ms"""
+    rep = d.get("repeats_ms_per_step")
+    return min(d["ms_per_step"], rep["median"]) if rep else d["ms_per_step"]
+
+
 def test_bench_line_contract_single_gpu():
     d = run_bench(port=29541)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -55,7 +63,7 @@ def test_bench_train_mode_collective_path():
     assert d["all_reduce_per_step"] == 2 * 12 + 5 + 1, d["all_reduce_per_step"]
     # measured 18.8 against 18.2 ms (the collectives of a group of one are latency only); the bound leaves room for
     # box-to-box spread
-    assert d["ms_per_step"] < 1.10 * plain["ms_per_step"], (d["ms_per_step"], plain["ms_per_step"])
+    assert settled_ms(d) < 1.10 * settled_ms(plain), (d["ms_per_step"], plain["ms_per_step"], d.get("repeats_ms_per_step"))
 
 
 def test_bench_gpus_2_on_a_one_gpu_box_is_a_clear_refusal():
@@ -87,4 +95,4 @@ def test_bench_fp16_train_mode_and_its_collective_path():
     assert forced["all_reduce_per_step"] == 2 * 12 + 5 + 1, forced["all_reduce_per_step"]
     # (24 small collectives sit serially on the lock-step chain of a 9 ms step: measured +15 % with one rank, +3 % on the 18 ms
     # f32-class step whose forward hides them behind the other members' streams)
-    assert forced["ms_per_step"] < 1.25 * plain["ms_per_step"], (forced["ms_per_step"], plain["ms_per_step"])
+    assert settled_ms(forced) < 1.25 * settled_ms(plain), (forced["ms_per_step"], plain["ms_per_step"])
