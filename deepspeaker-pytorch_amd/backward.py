@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 from typing import Dict
 
+
 import torch
 
 from ._native import ConvShape
@@ -241,7 +242,7 @@ def _dgrad(eng: Engine, shp: ConvShape, gz, w_dgrad, w_dgrad_bf16=None):
     return gx
 
 
-_wgrad_streams: Dict[torch.device, "torch.cuda.Stream"] = {}
+_wgrad_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 OVERLAP_FILTER_GRADIENTS = True        # module default of backward_train(overlap_filter_gradients=None); tools flip it for A/B runs
 
 
@@ -254,14 +255,19 @@ class _FilterGradLane:
     instead of queueing behind each other.  Results are those of the one-stream order (same kernels, same inputs).
     On the host emulator (CPU tensors) everything stays in program order."""
 
-    def __init__(self, device: torch.device, enabled: bool = True):
+    def __init__(self, device: torch.device, enabled: bool = True, priority: int = 0):
+        """`priority` -1: a high-priority stream.  HIP deals normal-priority streams to its (4) hardware queues round-robin
+        in creation order, so whether this lane shares a queue -- and then serialises -- with the caller's stream depends
+        on how many streams the process made before; a high-priority stream lives on queues of its own.  The fp16 step
+        uses it (8.8 ms whatever the order; 9.6 in the unlucky one without); the bf16x3 step does not: its filter
+        gradients are 7 ms of matrix work, and dispatched ahead of the data-gradient chain they cost it 5 ms."""
         self.main = self.side = None
         self.keep = []                  # main-stream tensors the side stream reads: alive until the join
         if device.type == "cuda" and enabled:
             self.main = torch.cuda.current_stream(device)
-            side = _wgrad_streams.get(device)
+            side = _wgrad_streams.get((device, priority))
             if side is None:
-                side = _wgrad_streams[device] = torch.cuda.Stream(device=device)
+                side = _wgrad_streams[(device, priority)] = torch.cuda.Stream(device=device, priority=priority)
             self.side = side
             side.wait_stream(self.main)
 
