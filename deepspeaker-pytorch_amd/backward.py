@@ -256,11 +256,12 @@ class _FilterGradLane:
     On the host emulator (CPU tensors) everything stays in program order."""
 
     def __init__(self, device: torch.device, enabled: bool = True, priority: int = 0):
-        """`priority` -1: a high-priority stream.  HIP deals normal-priority streams to its (4) hardware queues round-robin
-        in creation order, so whether this lane shares a queue -- and then serialises -- with the caller's stream depends
-        on how many streams the process made before; a high-priority stream lives on queues of its own.  The fp16 step
-        uses it (8.8 ms whatever the order; 9.6 in the unlucky one without); the bf16x3 step does not: its filter
-        gradients are 7 ms of matrix work, and dispatched ahead of the data-gradient chain they cost it 5 ms."""
+        """`priority` -1: a high-priority stream (tuning probe).  HIP deals normal-priority streams to its (4) hardware
+        queues round-robin in creation order, so whether this lane shares a queue -- and then serialises -- with the
+        caller's stream depends on how many streams the process made before (fp16 step: 8.8 ms in three alignments of
+        four, 9.6 in the fourth; `bench.py --pad-streams`).  A high-priority lane lives on queues of its own and measured
+        8.77 - 8.79 ms in all four alignments of a fresh process -- but 13.0 ms inside the full bench process (after the
+        bf16x3 legs), and 23.5 ms for the bf16x3 step in one alignment: priority also reorders dispatch.  Default 0."""
         self.main = self.side = None
         self.keep = []                  # main-stream tensors the side stream reads: alive until the join
         if device.type == "cuda" and enabled:

@@ -200,8 +200,7 @@ def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: Pac
     all-reduce per layer) and the per-stage f32 gradient buckets summed over the ranks, as backward.backward_train does."""
     from .backward import OVERLAP_FILTER_GRADIENTS, _FilterGradLane, _GradBuckets, _wgrad as _wgrad_f32
     lib = eng.lib
-    lane = _FilterGradLane(ge.device, OVERLAP_FILTER_GRADIENTS if overlap_filter_gradients is None else overlap_filter_gradients,
-                           priority=-1)         # queues of its own: never serialised behind the caller's stream
+    lane = _FilterGradLane(ge.device, OVERLAP_FILTER_GRADIENTS if overlap_filter_gradients is None else overlap_filter_gradients)
     inv = 1.0 / float(loss_scale)
     grads: Dict[str, torch.Tensor] = {}
     n_stages = len(pw.stages)
