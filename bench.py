@@ -45,10 +45,12 @@ ARITH = {"f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations",
                  "from the reference (OUTSIDE the 1e-3 contract)",
          "f16": "fp16 MFMA operands (v_mfma_f32_32x32x16_f16, one MFMA per product, f32 accumulate), fp16 activations "
                 "in HBM, f32 conv1 input / pooling / projection / loss; embeddings 3.7e-4 from the reference (contract "
-                "1e-3, tests/test_gpu_bench_size.py); triplets within 1.25e-3 of the filter's decision boundary are "
-                "re-embedded through the split-operand bf16 path inside the timed step (slots sized from the near-tie "
-                "counts of earlier steps; more near ties than slots => the selection re-embeds the whole batch at "
-                "f32-class precision when it is read), so the selection is the reference's; see `refine`"}
+                "1e-3, tests/test_gpu_bench_size.py); triplets within the MEASURED band (>= 1.25e-3) of the filter's decision "
+                "boundary are re-embedded through the split-operand bf16 path inside the timed region (the near ties of "
+                "`refine.window_steps` consecutive steps share one f32-class forward, the open window is flushed before the "
+                "region ends; slots sized from the near-tie counts of earlier steps; more near ties than slots, or an "
+                "observed fp16 error above half the band => the selection re-embeds the whole batch at f32-class precision "
+                "when it is read), so the selection is the reference's; see `refine`"}
 
 
 def cpu_baseline(sd_np, budget_s=9.0):
