@@ -114,3 +114,28 @@ def test_launch_bound_events_read_the_kernel_and_leave_results_alone():
     with pytest.raises(Exception):              # ... and reading it is an error, not a hang (bench.py falls back to pairs)
         a.elapsed_time(b)
     assert time.perf_counter() - t0 < 5.0
+
+
+def test_batches_in_flight_yield_the_sequential_embeddings_in_order():
+    """pipeline.BatchesInFlight: consecutive batches alternating over two streams -- the tensors model(x) returns, bit for
+    bit and in order; different batch sizes in one sequence; a consumer that reads each result at once."""
+    from deepspeaker_pytorch_amd.pipeline import BatchesInFlight
+    sd = O.make_state_dict(seed=11, num_classes=16)
+    m = build(sd)
+    sizes = [96, 96, 48, 96, 192, 48, 96]
+    xs = [torch.from_numpy(O.make_input(seed=950 + i, batch=b, frames=160)).cuda() for i, b in enumerate(sizes)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    for n in (1, 2, 3):
+        got = [e.clone() for e in BatchesInFlight(m, in_flight=n)(xs)]
+        torch.cuda.synchronize()
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    pipe = BatchesInFlight(m)
+    sums = [float(e.sum()) for e in pipe(xs)]                  # the consumer synchronises on every result
+    assert sums == [float(w.sum()) for w in want]
+    m.train()
+    with pytest.raises(RuntimeError):
+        list(pipe(xs[:1]))

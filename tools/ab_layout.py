@@ -108,6 +108,23 @@ def main():
     normal = torch.cuda.Stream(device=dev)
     print(f"forwards only (no side stream work): {forwards(20):.4f} ms")
 
+    # ---- plain embedding extraction with batches in flight (pipeline.BatchesInFlight) ----
+    from deepspeaker_pytorch_amd.pipeline import BatchesInFlight
+    for n in (1, 2, 3):
+        pipe = BatchesInFlight(model, in_flight=n)
+        ts = []
+        for r in range(args.rounds):
+            for _ in pipe([data_all] * 6):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in pipe([data_all] * 40):
+                pass
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 40 * 1e3)
+        print(f"embedding extraction, {n} batch(es) of 768 in flight: {statistics.median(ts):.4f} ms per batch "
+              f"({768 / statistics.median(ts):.1f} k embeddings/s)")
+
     # ---- what each part of the step costs on top of the forward ----
     mining._side_streams[dev] = normal
 
