@@ -50,8 +50,12 @@ class FeatureStore:
         if (st < 0).any() or (utt < 0).any() or (utt >= len(self)).any():
             raise IndexError("crop outside the corpus")
         dev = self.features.device
-        row_start = torch.from_numpy(self.offsets[utt] + st).to(dev)
-        row_end = torch.from_numpy(self.offsets[utt + 1]).to(dev)
+        # one pinned staging buffer, copied without blocking the host: a pageable .to(device) waits for everything queued
+        # on the stream before it -- the caller could never run ahead of the GPU (embed_variable_length, batches in flight)
+        rows = torch.from_numpy(np.stack([self.offsets[utt] + st, self.offsets[utt + 1]]))
+        if dev.type == "cuda":
+            rows = rows.pin_memory().to(dev, non_blocking=True)
+        row_start, row_end = rows[0], rows[1]
         out = torch.empty((len(utt), 1, frames, self.n_feat), dtype=torch.float32, device=dev)
         eng.lib.call("ds_assemble_crops_f32", eng._p(self.features), eng._p(row_start), eng._p(row_end), eng._p(out),
                      len(utt), frames, self.n_feat, eng._stream(out))

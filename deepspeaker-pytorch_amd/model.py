@@ -682,7 +682,7 @@ class DeepSpeakerModel(nn.Module):
         return outs
 
     def embed_variable_length(self, utterances, max_batch: int = 2048, pad_to: int = 16, max_frames: int = 262144,
-                              batch_step: int = 32):
+                              batch_step: int = 32, in_flight: int = 2):
         """Eval-mode embeddings of utterances of DIFFERENT lengths (BASELINE configs[4]: 100-800 frames; the
         temporal mean pool of model.py:207 accepts any T).  `utterances`: a sequence of [T_i, 64]
         (or [1, T_i, 64]) float tensors on the device, or a `data.FeatureStore` (the resident corpus: batches are
@@ -691,7 +691,10 @@ class DeepSpeakerModel(nn.Module):
         `max_frames` padded frames (about two 768 x 160-frame forwards: short utterances travel in larger batches, the
         GPU sees the same amount of work per launch) and at most `max_batch`.  They run through the masked forward:
         each embedding is bit-identical to the utterance's own forward -- padding never leaks
-        (Engine.forward_eval_planned(lengths=...)).  Returns [N, embedding_size] in the order given."""
+        (Engine.forward_eval_planned(lengths=...)).  Consecutive batches alternate over `in_flight` HIP streams (one
+        batch's assembly, HBM-bound first layer and small tail launches beside the other's matrix kernels: see
+        pipeline.BatchesInFlight); the caller's stream is ordered after all of them before the result is returned.
+        Returns [N, embedding_size] in the order given."""
         if self.training:
             raise RuntimeError("embed_variable_length is an inference path: call model.eval() first")
         n = len(utterances)
@@ -716,7 +719,19 @@ class DeepSpeakerModel(nn.Module):
         pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
         eng = get_engine()
         sorted_lens = lens[order].tolist()
-        i = 0
+        order_dev = order.to(dev)                # once: a per-batch pageable copy would stall the host on the stream
+        on_gpu = dev.type == "cuda"              # (the host emulator runs CPU tensors in program order)
+        if not on_gpu:
+            in_flight = 1
+        caller = torch.cuda.current_stream(dev) if on_gpu else None
+        lanes = [caller]
+        if in_flight > 1:
+            lanes = self.__dict__.setdefault("_varlen_lanes", {}).get(dev)
+            if lanes is None or len(lanes) != in_flight:
+                lanes = self.__dict__["_varlen_lanes"][dev] = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+            for lane in lanes:
+                lane.wait_stream(caller)        # the utterances (and `out`) were produced on the caller's stream
+        i = k = 0
         while i < n:
             # the largest count whose padded frames fit the budget (lengths ascend: the last member is the longest)
             cnt = 1
@@ -729,14 +744,20 @@ class DeepSpeakerModel(nn.Module):
             i += cnt
             ln = lens[idx]
             t_pad = int(-(-int(ln.max()) // pad_to) * pad_to)
-            if store is not None:       # whole utterances from the resident corpus, zero-padded by the gather kernel
-                x = store.crops(idx.numpy(), [0] * len(idx), t_pad)
-            else:
-                x = torch.zeros((len(idx), 1, t_pad, 64), dtype=torch.float32, device=dev)
-                for r, j in enumerate(idx.tolist()):
-                    x[r, 0, :feats[j].shape[0]].copy_(feats[j])
-            e = eng.forward_eval_planned(x, pw, self._folded(), precision=self.precision, lengths=ln)
-            out[idx.to(dev)] = e
+            with torch.cuda.stream(lanes[k % len(lanes)]):      # (a no-op context for None)
+                if store is not None:   # whole utterances from the resident corpus, zero-padded by the gather kernel
+                    x = store.crops(idx.numpy(), [0] * len(idx), t_pad)
+                else:
+                    x = torch.zeros((len(idx), 1, t_pad, 64), dtype=torch.float32, device=dev)
+                    for r, j in enumerate(idx.tolist()):
+                        x[r, 0, :feats[j].shape[0]].copy_(feats[j])
+                e = eng.forward_eval_planned(x, pw, self._folded(), precision=self.precision, lengths=ln)
+                out.index_copy_(0, order_dev[i - cnt:i], e)
+            k += 1
+        if in_flight > 1:
+            for lane in lanes:
+                caller.wait_stream(lane)
+            out.record_stream(lanes[0])
         return out
 
     def embed_reference(self, x: torch.Tensor) -> torch.Tensor:
