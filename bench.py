@@ -591,16 +591,6 @@ def main():
     elapsed, prof, again, refine, isolated = measure(args.precision, args.steps, args.warmup, args.repeats)
     if "pipelined_fn" in extras:
         extras["pipelined"] = extras.pop("pipelined_fn")()
-        if os.environ.get("DS_BENCH_PAD_STREAMS", "1") == "1":
-            # HIP deals streams to its (4) hardware queues round-robin in creation order; the training legs below are
-            # sensitive to which of their streams share a queue (measured 18.5 -> 19.6 ms when the two streams above shift
-            # them by two).  Two more streams shift them by a whole cycle: the legs see the round-3 assignment again.
-            pads = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            for st_ in pads:
-                with torch.cuda.stream(st_):
-                    torch.zeros(1, device=dev)
-            extras["pad_streams"] = pads
-            fence()
 
     secondary = {}
     if world == 1 and not args.no_secondary:
@@ -615,8 +605,25 @@ def main():
         import varlen_bench
         varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=4096, dev=dev)
         kt = max(3, args.steps // 4)
-        et, _, _, _ = measure_train("bf16x3", kt, 2)
-        et16, _, _, _ = measure_train("f16", kt, 2)
+        # The training legs run in FRESH PROCESSES (`bench.py --train ...`): HIP deals streams to its 4 hardware queues
+        # round-robin in creation order and two streams on one queue serialise, so inside this process the legs' stream
+        # overlap depends on how many streams the eval part happened to create before them (measured, same box, same
+        # code: 18.1 / 8.9 ms or 19.4 / 9.7 ms).  A fresh process has one alignment -- the one `--train` is measured in.
+        def train_leg(tp):
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--train", "--train-precision", tp, "--steps", str(kt),
+                   "--warmup", "2", "--repeats", "0", "--no-cpu-baseline"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and lines:
+                    return float(json.loads(lines[-1])["ms_per_step"]) * 1e-3 * kt, "fresh process"
+                print(f"[bench] training leg {tp} in a fresh process failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+            except Exception as exc:            # (no subprocess: measure here after all)
+                print(f"[bench] training leg {tp} in a fresh process failed: {exc}", file=sys.stderr)
+            return measure_train(tp, kt, 2)[0], "this process"
+        et, leg_where = train_leg("bf16x3")
+        et16, _ = train_leg("f16")
     if rank == 0:
         value = emb_per_step * args.steps / elapsed
         out = {
@@ -661,6 +668,7 @@ def main():
                                  "ms_per_step": round(et / kt * 1e3, 3), "dtype": "bf16x3",
                                  "algorithmic_tflops": round(emb_per_step * kt / et * 3 * FWD_FLOPS_PER_EMB / 1e12, 1),
                                  "frac_of_bf16_peak": round(emb_per_step * kt / et * 3 * FWD_FLOPS_PER_EMB / 1e12 / 2500.0, 4),
+                                 "measured_in": leg_where,
                                  "what": "train-mode forward of a/p/n (three BatchNorm statistic sets) + triplet loss + "
                                          "backward + fused Adagrad (train_triplet.py:215-224); ~3x the forward FLOPs"}
             out["train_step_f16"] = {"value": round(emb_per_step * kt / et16, 1), "unit": "utterances/s", "steps": kt,
