@@ -42,8 +42,11 @@ def enrolment_scores(test_emb: torch.Tensor, enrol_emb: torch.Tensor, enrol_size
     if sizes.ndim != 1 or len(sizes) != test_emb.shape[0] or (sizes < 1).any() or int(sizes.sum()) != enrol_emb.shape[0]:
         raise ValueError("enrol_sizes must give one set size >= 1 per trial, summing to the rows of enrol_emb")
     dev = test_emb.device
-    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(dev)
-    owner = torch.from_numpy(np.repeat(np.arange(len(sizes)), sizes).astype(np.int64)).to(dev)
+    def to_dev(a):         # through pinned memory, without blocking the host (a pageable copy waits for the stream's queue)
+        t = torch.from_numpy(a)
+        return t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t.to(dev)
+    offsets = to_dev(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64))
+    owner = to_dev(np.repeat(np.arange(len(sizes)), sizes).astype(np.int64))
     n, d = enrol_emb.shape
     expanded = torch.empty((n, d), dtype=torch.float32, device=dev)
     eng.lib.call("ds_gather_rows_f32", eng._p(test_emb.contiguous()), eng._p(owner), eng._p(expanded), n, d,
