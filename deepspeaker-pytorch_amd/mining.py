@@ -246,8 +246,8 @@ class RefineWindow:
                              eng._p(count), eng._p(mean_diff), d_p.numel(), st)
                 en["sel"]._complete(idx, count, d_p, d_n, mean_diff, loss, rb)
             ready = side.record_event()
-        for en in ents:
-            en["sel"]._ready = ready if side != cur else None
+        for en in ents:             # (also when the forward ran on the flushing caller's own stream: a selection of the
+            en["sel"]._ready = ready    # window may be read from another stream than the one that closed it)
 
 
 class TripletSelection:
