@@ -682,7 +682,7 @@ class DeepSpeakerModel(nn.Module):
         return outs
 
     def embed_variable_length(self, utterances, max_batch: int = 2048, pad_to: int = 16, max_frames: int = 262144,
-                              batch_step: int = 32, in_flight: int = 2):
+                              batch_step: int = 32, in_flight: int = 1):
         """Eval-mode embeddings of utterances of DIFFERENT lengths (BASELINE configs[4]: 100-800 frames; the
         temporal mean pool of model.py:207 accepts any T).  `utterances`: a sequence of [T_i, 64]
         (or [1, T_i, 64]) float tensors on the device, or a `data.FeatureStore` (the resident corpus: batches are
@@ -691,9 +691,10 @@ class DeepSpeakerModel(nn.Module):
         `max_frames` padded frames (about two 768 x 160-frame forwards: short utterances travel in larger batches, the
         GPU sees the same amount of work per launch) and at most `max_batch`.  They run through the masked forward:
         each embedding is bit-identical to the utterance's own forward -- padding never leaks
-        (Engine.forward_eval_planned(lengths=...)).  Consecutive batches alternate over `in_flight` HIP streams (one
-        batch's assembly, HBM-bound first layer and small tail launches beside the other's matrix kernels: see
-        pipeline.BatchesInFlight); the caller's stream is ordered after all of them before the result is returned.
+        (Engine.forward_eval_planned(lengths=...)).  `in_flight` > 1: consecutive batches alternate over that many HIP
+        streams (one batch's assembly, HBM-bound first layer and small tail launches beside the other's matrix kernels:
+        see pipeline.BatchesInFlight; +2 % at 2); the caller's stream is ordered after all of them before the result is
+        returned.  Default 1: extra streams shift which hardware queue every stream created later lands on.
         Returns [N, embedding_size] in the order given."""
         if self.training:
             raise RuntimeError("embed_variable_length is an inference path: call model.eval() first")

@@ -55,7 +55,7 @@ def run(model, n_utt=4096, max_batch=2048, seed=0, dev=None, max_frames=262144, 
     return {"utterances": n_utt, "frames_min_max": [100, 800], "utterances_per_s": round(n_utt / dt, 1),
             "frames_per_s": round(frames / dt, 1), "equivalent_160_frame_embeddings_per_s": round(frames / 160 / dt, 1),
             "padded_frames_over_real": round(padded / frames, 4), "max_batch": max_batch, "max_frames": max_frames,
-            "batches": n_batches,
+            "batches": n_batches, "batches_in_flight": in_flight,
             "enrolment_trials_per_s": round(n_spk / dt_score, 1), "mean_score": round(float(scores.mean()), 4),
             "policy": "sorted by length, zero-padded batches of <= max_frames padded frames, masked forward: embeddings bit-identical to single-utterance "
                       "forwards; score = mean distance to the speaker's enrolment utterances"}
