@@ -164,6 +164,11 @@ def main():
     ap.add_argument("--refine-window", type=int, default=8,
                     help="steps whose near ties share one refinement forward (mining.RefineWindow; 1 = every step its own): "
                          "the timed region ends with the open window flushed, so all of the refinement is inside it")
+    ap.add_argument("--profile-every", type=int, default=3,
+                    help="the live roofline times the convolution launches of every N-th step of the timed region (a timed "
+                         "launch costs ~5 us of completion-signal handling: all of them, 2 %% of the step).  Keep it coprime with "
+                         "--refine-window: the steps a window's flush runs beside must be sampled at their true share "
+                         "(every 4th step with a window of 8 sampled them at 40 %% instead of 12 %%: frac 0.375 instead of 0.405)")
     ap.add_argument("--refine-slots", type=int, default=0,
                     help="smallest number of near-tie re-embedding slots of the fp16 path (0: the library default, "
                          "mining.REFINE_CAP_MIN); the policy grows them from observed counts either way")
@@ -311,12 +316,13 @@ def main():
         """untimed settle-in steps run BEFORE the W contract warm-ups (reported as `pre_steps` in the line)"""
         return max(0, 30 - warmup)
 
-    def timed(step, steps, warmup, repeats=0, profile=True, finish=None):
+    def timed(step, steps, warmup, repeats=0, profile=True, finish=None, profile_every=1):
         # profile: per-launch events around the convolutions of the timed region (the live roofline of the eval line); the
         # training steps are timed without them (a pair of events per launch is ~70 per fp16 training step -- measured
         # 12.7 ms per step with them, 9.6 without)
         def prof_on():
             eng.profile = [] if profile else None
+            eng._profile_calls = {}
         prof_on()                               # warm-up with the event instrumentation on: the first
         for _ in range(pre_steps(warmup)):      # timing events of a process cost ~40 ms to create; and a fresh
             step()                              # box needs ~0.2 s of work before clocks / caches settle (setup,
@@ -330,7 +336,9 @@ def main():
         if finish is not None:
             finish()                            # nothing of the warm-up is left for the timed region to do
         prof_on()
+        eng.profile_every = max(1, profile_every)
         elapsed, t_enq = region(step, steps, finish)
+        eng.profile_every = 1
         if rank == 0:
             print(f"[bench] host enqueue {t_enq / steps * 1e3:.3f} ms/step, device-complete {elapsed / steps * 1e3:.3f} ms/step",
                   file=sys.stderr)
@@ -402,7 +410,8 @@ def main():
                 del sels[:-steps]
             return loss, sel, mined
 
-        elapsed, prof, again = timed(step, steps, warmup, repeats, finish=refine_policy(model).flush)
+        elapsed, prof, again = timed(step, steps, warmup, repeats, finish=refine_policy(model).flush,
+                                     profile_every=args.profile_every if precision == args.precision else 1)
         # The same kernels with NOTHING else on the chip: forwards only, back to back (no loss / filter / refinement /
         # search, hence no side stream).  Inside the step the near-tie refinement and the semi-hard search of step k run
         # on a side stream next to the forward of step k + 1 and take CUs from it, so the per-launch durations measured
@@ -536,7 +545,7 @@ def main():
             pass
         r = {"bound": "mfma", "kernel": KERNEL_NAME[precision], "achieved": round(achieved, 2), "peak": peak,
              "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-             "launches": len(prof), "avg_launch_ms": round(ms / max(len(prof), 1), 4),
+             "launches": len(prof), "avg_launch_ms": round(ms / max(len(prof), 1), 4), "steps_timed": steps,
              "conv_ms_per_step": round(ms / steps, 3),
              "by_layer_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by.items() if v[1] > 0}}
         # the member of the family furthest below the roofline (what the next optimisation round goes after)
@@ -626,6 +635,9 @@ def main():
         et16, _ = train_leg("f16")
     if rank == 0:
         value = emb_per_step * args.steps / elapsed
+        # the launches of every --profile-every-th forward of the timed region carry timing events
+        fwd_calls = 3 if args.split_apn else 1
+        profiled_steps = -(-(args.steps * fwd_calls) // max(1, args.profile_every)) / fwd_calls
         out = {
             "metric": "embeddings/sec (64-fbank x 160-frame utterances)",
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
@@ -640,7 +652,7 @@ def main():
                        "frames": FRAMES, "parallelism": f"dp{world}",
                        "forward_calls_per_step": 3 if args.split_apn else 1, "steps_in_flight": max(1, args.streams),
                        "arith": ARITH[args.precision]},
-            "roofline": roofline_of(args.precision, prof, args.steps),
+            "roofline": roofline_of(args.precision, prof, profiled_steps),
             "whole_forward_tflops": round(value * FWD_FLOPS_PER_EMB / 1e12, 2),
         }
         # the whole step (conv1, tail, loss, filter, refinement, search and launch gaps included) against the same peak

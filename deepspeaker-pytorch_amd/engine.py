@@ -129,6 +129,9 @@ class Engine:
         # launch stream and (label, flops, start, end, arithmetic) is appended (bench.py's live roofline).
         self.profile: Optional[list] = None
         self.self_timed_launches = True     # profile entries of single-kernel calls from events bound to the launch
+        self.profile_every = 1              # planned forwards: time the launches of every N-th call only (a timed launch
+        self._profile_calls = {}            # costs ~5 us of completion-signal handling: 2 % of the eval step at N = 1);
+                                            # counted per precision (a refinement forward does not shift the main one's turn)
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -649,6 +652,11 @@ class Engine:
         plan["x"].value, plan["e"].value = x.data_ptr(), e.data_ptr()
         plan["st"].value = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else None
         prof = self.profile if (self.profile is not None and x.is_cuda) else None
+        if prof is not None and self.profile_every > 1:
+            turn = self._profile_calls.get(precision, 0)
+            self._profile_calls[precision] = turn + 1
+            if turn % self.profile_every:
+                prof = None
         for fn, args, label, flops in plan["calls"]:
             if prof is not None and label is not None:
                 if self.self_timed_launches and fn.__name__ in _SELF_TIMED:    # one MFMA kernel per call: the launch carries its own events
