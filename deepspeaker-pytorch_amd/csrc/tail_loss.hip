@@ -386,6 +386,9 @@ __global__ void __launch_bounds__(256) avgpool_time_bwd_kernel(const float *gpoo
 //      conflict-free padded columns out), so every candidate element is read from L2 once per 8 anchors
 //      and the anchor values are LDS broadcasts.  Per-tile winners go to a workspace; a second kernel
 //      folds the tiles in ascending order.  Fixed scan / reduction order => deterministic.
+//      (Round 4: a squarer tile -- 16 anchors x 64 candidates per workgroup, a sixth of the L2 traffic -- was built and
+//      measured: 40 vs 41 us at 768 candidates, 135 vs 93 us at 6144.  The kernel is bound by its per-slab barriers,
+//      not by L2: the wide candidate tile amortises them better.  Not kept.)
 constexpr int MINE_A_MAX = 8;      // anchors per workgroup: 8, or 4 / 2 when 8 would leave the chip under-filled
 constexpr int MINE_K = 32;         // dimensions per staged slab
 constexpr int MINE_C = 256;        // candidates per workgroup
@@ -599,8 +602,12 @@ extern "C" int ds_mine_semihard_f32(const float *anchor, const float *d_p, const
     // has CUs (256 anchors x 768 candidates: 96), 4 or 2 anchors per workgroup fill it instead (same sums, same order)
     int A = MINE_A_MAX;
     while (A > 2 && ds_ceil_div(N, A) * n_ctiles < ds_cu_count()) A /= 2;
-    const size_t tile_words = 256 * MINE_P > 4 * A * 256 ? 256 * MINE_P : 4 * A * 256;
-    const size_t lds = ((size_t)A * D + tile_words) * 4;
+    auto lds_of = [&](int a_) {
+        const size_t tile_words = 256 * MINE_P > 4 * a_ * 256 ? 256 * MINE_P : 4 * a_ * 256;
+        return ((size_t)a_ * D + tile_words) * 4;
+    };
+    while (A > 2 && lds_of(A) > 64 * 1024) A /= 2;         // long rows: fewer anchors per workgroup fit next to the tile
+    const size_t lds = lds_of(A);
     DS_REQUIRE(lds <= 64 * 1024, DS_ERR_BAD_SHAPE);
     const int n_agroups = ds_ceil_div(N, A);
     if (A == 8)

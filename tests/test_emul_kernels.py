@@ -406,6 +406,41 @@ def test_mine_semihard(N, M):
     np.testing.assert_allclose(dst, ref_s, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,M,D", [(37, 150, 512), (16, 64, 512), (21, 333, 96), (9, 130, 1024), (40, 70, 2048)])
+def test_mine_semihard_shapes_and_ties(N, M, D):
+    """ds_mine_semihard_f32 against the oracle: ragged N / M, short and long rows (the anchors per workgroup shrink until
+    their rows fit the LDS next to the candidate tile), duplicated candidates (exact distance ties: the lowest index wins),
+    an anchor without a semi-hard candidate, an anchor whose every candidate shares its label."""
+    lib = emul_lib()
+    rs = np.random.RandomState(N * 1000 + M + D)
+    a = to_aligned(rs.randn(N, D).astype(np.float32))
+    cand = to_aligned(rs.randn(M, D).astype(np.float32))
+    cand[M // 2] = cand[3]                                   # exact ties across tiles and inside one
+    cand[5] = cand[4]
+    la = rs.randint(0, 5, N).astype(np.int64)
+    lc = rs.randint(0, 5, M).astype(np.int64)
+    la[2] = 99                                               # nobody shares this label: every candidate is "other"
+    la[3] = 7
+    lc_all_same = lc.copy()
+    d_all = np.sqrt(((a[:, None, :] - cand[None]) ** 2).sum(-1))
+    # (between two candidates' distances, never ON one: "farther than d_p" must not hinge on the last bit of a sum)
+    srt = np.sort(d_all, axis=1)
+    d_p = ((srt[:, M // 2] + srt[:, M // 2 + 1]) / 2).astype(np.float32)
+    d_p[1] = 1e9                                             # no semi-hard candidate: the closest other-speaker one
+    out, outd = aligned(N, np.int64), aligned(N, fill=np.nan)
+    ws = aligned(lib.raw("ds_mine_workspace_floats")(N, M), fill=np.nan)
+    for labels in (lc, np.full(M, 7, np.int64)):             # second pass: anchor 3 finds no candidate at all (-1)
+        la_a, lc_a, dp_a = to_aligned(la, np.int64), to_aligned(labels, np.int64), to_aligned(d_p)
+        lib.call("ds_mine_semihard_f32", ptr(a), ptr(dp_a), ptr(la_a), ptr(cand), ptr(lc_a), ptr(ws), ptr(out), ptr(outd),
+                 N, M, D, None)
+        ref = O.mine_semihard(a, d_p, la, cand, labels)
+        np.testing.assert_array_equal(out, ref)
+        ok = ref >= 0
+        want_d = np.sqrt(((a[ok] - cand[ref[ok]]) ** 2).sum(-1) + 1e-4 / D)
+        assert rel_err(outd[ok], want_d.astype(np.float32)) < 2e-6
+    assert out[3] == -1
+
+
 @pytest.mark.parametrize("p", [1.0, 2.0, 3.0, 1.5])
 def test_pairwise_distance_any_norm(p):
     """reference model.py:13-18 with self.norm = p (its own call sites pass 2): forward against the oracle, the
