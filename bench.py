@@ -53,54 +53,102 @@ ARITH = {"f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations",
                 "when it is read), so the selection is the reference's; see `refine`"}
 
 
-def cpu_baseline(sd_np, budget_s=9.0):
-    """The reference's CPU forward (torch ATen/oneDNN; restated in oracle/torch_restatement.py because
-    /root/reference is absent on the GPU box), eval mode, fp32, on the host cores, at B = 32 and B = 256
-    (BASELINE.md section 4).  The thread count is the best of a short scan (oneDNN degrades badly when
-    over-subscribed); `cores` = the threads used for the reported value.  Bounded samples."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))        # the checker, used by this leg only
-    import torch_restatement as TR
+CONV_SOURCES = {      # the sources whose change invalidates a replayed PMC traffic figure (profiles/pmc_traffic.json)
+    "f16": ("conv_mfma_f16.hip", "conv_mfma_f16_kernel.h", "conv_mfma_f16_pkernel.h", "conv_block_f16.hip", "ds_device.h"),
+    "bf16x3": ("conv_mfma_bf16.hip", "conv_mfma_bf16_kernel.h", "ds_device.h"),
+    "f32": ("conv_mfma_f32.hip", "ds_device.h"),
+}
+
+
+def conv_sources_digest(precision):
+    """sha256 over the kernel sources of `precision`'s convolution family (the GPU box has no .git: a content hash, not
+    a commit).  profiles/pmc_traffic.json records the digest of the build its counters were collected on;
+    tools/pmc_traffic_update.py writes it."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in CONV_SOURCES.get(precision, ()):
+        with open(os.path.join(ROOT, "deepspeaker-pytorch_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(sd_np, budget_s=7.0):
+    """The reference's CPU forward, eval mode, fp32, on the host cores, at B = 32 and B = 256.
+
+    kind "reference": the UNMODIFIED /root/reference/model.py (`DeepSpeakerModel(512, 1211).eval()`, BASELINE.md 4
+    steps 2-3) when that tree exists on this host; kind "port": its torch-ATen restatement
+    (oracle/torch_restatement.py, pinned to the reference's recorded outputs by tests/test_oracle_golden.py) where it does
+    not -- the GPU box has no /root/reference.  Both run the same oneDNN convolutions.
+
+    Two figures: `all_cores` -- torch.set_num_threads(os.cpu_count()), the plan's protocol -- and `value`, the best of a
+    short thread-count scan that includes it (oneDNN degrades badly when over-subscribed; `cores` = the threads of the
+    reported value).  Bounded samples."""
     ncpu = os.cpu_count() or 1
     sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
+    kind, fwd = "port", None
+    ref_dir = "/root/reference"
+    if os.path.isfile(os.path.join(ref_dir, "model.py")):
+        try:
+            import importlib.util
+            import warnings
+            spec = importlib.util.spec_from_file_location("_reference_model", os.path.join(ref_dir, "model.py"))
+            ref_mod = importlib.util.module_from_spec(spec)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                spec.loader.exec_module(ref_mod)
+                torch.manual_seed(0)
+                ref_model = ref_mod.DeepSpeakerModel(512, 1211).eval()
+            ref_model.load_state_dict(sd)
+            kind, fwd = "reference", ref_model.forward
+        except Exception as exc:                    # (the port below is pinned to the same outputs)
+            print(f"[bench] the reference model did not import ({exc}); timing its restatement", file=sys.stderr)
+    if fwd is None:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))        # the checker, used by this leg only
+        import torch_restatement as TR
+        fwd = lambda x: TR.forward_eval(sd, x)      # noqa: E731
     x32 = torch.randn(32, 1, FRAMES, 64)
-    best = None
+    scan = {}
     with torch.no_grad():
-        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)} | {ncpu}):
             torch.set_num_threads(nt)
-            TR.forward_eval(sd, x32)                              # warm-up at this thread count
+            fwd(x32)                                              # warm-up at this thread count
             t0 = time.perf_counter()
-            TR.forward_eval(sd, x32)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[1]:
-                best = (nt, dt)
-        cores = best[0]
-        torch.set_num_threads(cores)
-        by_batch = {}
-        for B in (32, 256):
+            fwd(x32)
+            scan[nt] = time.perf_counter() - t0
+        cores = min(scan, key=scan.get)
+
+        def sample(B, nt, budget):
+            torch.set_num_threads(nt)
             x = torch.randn(B, 1, FRAMES, 64)
-            TR.forward_eval(sd, x)                                # 1 warm-up (BASELINE.md section 4)
+            fwd(x)                                                # 1 warm-up (BASELINE.md section 4)
             n, reps, t0 = 0, 0, time.perf_counter()
             while True:
-                TR.forward_eval(sd, x)
+                fwd(x)
                 n += B
                 reps += 1
                 dt = time.perf_counter() - t0
-                if (dt > budget_s and reps >= 3) or reps >= 64:
+                if (dt > budget and reps >= 3) or reps >= 64:
                     break
-            by_batch[B] = (n / dt, n, reps, dt)
-    v32, v256 = by_batch[32], by_batch[256]
+            return n / dt, n, reps, dt
+        v32, v256 = sample(32, cores, budget_s), sample(256, cores, budget_s)
+        all32 = v32 if cores == ncpu else sample(32, ncpu, budget_s / 2)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
     except OSError:
         pass
-    return {"value": round(v32[0], 1), "unit": "embeddings/s", "cores": cores, "host_cores": ncpu, "kind": "port",
+    return {"value": round(v32[0], 1), "unit": "embeddings/s", "cores": cores, "host_cores": ncpu, "kind": kind,
             "cpu_model": cpu_model,
             "value_b256": round(v256[0], 1),
+            "all_cores": {"value": round(all32[0], 1), "cores": ncpu, "forwards": all32[2],
+                          "what": "torch.set_num_threads(os.cpu_count()), B = 32 (BASELINE.md section 4 step 1)"},
+            "thread_scan_ms_b32": {str(k): round(v * 1e3, 1) for k, v in sorted(scan.items())},
             "sample": f"B=32: {v32[1]} utterances [1,{FRAMES},64] ({v32[2]} forwards, {v32[3]:.1f} s); B=256: {v256[1]} "
                       f"utterances ({v256[2]} forwards, {v256[3]:.1f} s); eval forward, fp32, torch {torch.__version__} CPU, "
-                      f"{cores} threads (best of a scan over 8..128; the host has {ncpu})"}
+                      f"{cores} threads (best of a scan over 8..{ncpu}; the host has {ncpu}); "
+                      + ("the unmodified /root/reference/model.py" if kind == "reference" else
+                         "oracle/torch_restatement.py (no /root/reference on this host)")}
 
 
 def _backend():
@@ -440,14 +488,14 @@ def main():
             pol = model._refine_policy
             errs = [s_.observed_error[0] for s_ in last if s_.observed_error[0] is not None]
             fallbacks = sum(int(s_.refine_overflow or s_.band_exceeded) for s_ in last)
-            refine = {"band": last[-1].band, "band_floor": REFINE_BAND, "band_observed_max": pol.err_max_window,
+            refine = {"overflow_steps": sum(int(s_.refine_overflow) for s_ in last),
+                      "band_violation_steps": sum(int(s_.band_exceeded) for s_ in last),
+                      "embedding_error_observed": pol.embedding_error_observed,
+                      "band": last[-1].band, "band_floor": REFINE_BAND, "band_observed_max": pol.err_max_window,
                       "band_observed_max_timed_steps": max(errs, default=None), "band_samples_total": pol.err_samples,
                       "band_violations_total": pol.band_violations,
-                      "embedding_error_observed": pol.embedding_error_observed,
                       "slots": [s_.amb_cap for s_ in last][-1], "window_steps": pol.window, "near_ties_mean": round(sum(ties) / len(ties), 2),
-                      "near_ties_max": max(ties), "overflow_steps": sum(int(s_.refine_overflow) for s_ in last),
-                      "band_violation_steps": sum(int(s_.band_exceeded) for s_ in last),
-                      "steps": len(last), "calls_total": pol.calls, "overflows_total": pol.overflows}
+                      "near_ties_max": max(ties), "steps": len(last), "calls_total": pol.calls, "overflows_total": pol.overflows}
             if fallbacks:
                 # a step whose near ties outnumbered its slots, or whose probes showed an error above half its band,
                 # re-embeds the whole batch when its selection is READ (after the timed region): say so in the line
@@ -539,8 +587,17 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 t = json.load(f).get(precision)
             if t and (not args.split_apn) == (t["launch_batch"] == 3 * BATCH_TRIPLETS):
-                traffic = t["traffic_bytes_per_launch"]
-                traffic_src = f"replayed from {t.get('source', 'profiles/pmc_traffic.json')} ({t.get('launches', '?')} launches)"
+                have, want = t.get("kernel_sources_sha256"), conv_sources_digest(precision)
+                if have is not None and have != want:
+                    # the kernels changed after the counters were collected: the figure is not this build's
+                    traffic_src = (f"STALE -- {t.get('source', 'profiles/pmc_traffic.json')} was collected on kernel sources "
+                                   f"{have}, this build is {want}: re-run tools/pmc_run.sh + tools/pmc_traffic_update.py")
+                    if rank == 0:
+                        print("[bench] roofline.traffic: " + traffic_src, file=sys.stderr)
+                else:
+                    traffic = t["traffic_bytes_per_launch"]
+                    traffic_src = (f"replayed from {t.get('source', 'profiles/pmc_traffic.json')} ({t.get('launches', '?')} launches"
+                                   + (f", kernel sources {have}" if have else ", sources digest not recorded") + ")")
         except (OSError, ValueError, KeyError):
             pass
         r = {"bound": "mfma", "kernel": KERNEL_NAME[precision], "achieved": round(achieved, 2), "peak": peak,
@@ -694,6 +751,12 @@ def main():
             out["varlen"] = varlen
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_np)
+        # key order of the printed line: the contract's keys, then what a reader must not lose if the line's tail is cut
+        # (what the refinement did in the timed steps -- overflows / band violations / the embedding error it observed --
+        # the roofline, the CPU baseline), then the secondaries
+        head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "pre_steps", "world_size", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "refine", "roofline", "cpu_baseline", "config")
+        out = {**{k: out[k] for k in head if k in out}, **{k: v for k, v in out.items() if k not in head}}
         print(json.dumps(out))
     if multi:
         dist.destroy_process_group()

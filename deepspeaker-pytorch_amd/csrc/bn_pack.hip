@@ -384,7 +384,7 @@ unsigned *ds_sched_slot(void *stream) {
     return it->second.first + (size_t)k * DS_SCHED_WORDS;
 }
 
-extern "C" int ds_version(void) { return 301; }   // 30x: round-3 ABI (300: split grouped BatchNorm backward for data parallelism, grouped f64 sums; 301: + ds_conv_dgrad_bnbwd_bf16, ds_bn_bwd_group_finish_f32)
+extern "C" int ds_version(void) { return 500; }   // 500: round 5; 400: round 4 (fp16 training step, refinement probes, launch-bound timing); 30x: round-3 ABI (300: split grouped BatchNorm backward for data parallelism, grouped f64 sums; 301: + ds_conv_dgrad_bnbwd_bf16, ds_bn_bwd_group_finish_f32)
 
 // ---- launch timing (see DS_LAUNCH_BIG_LDS in ds_device.h) ----
 extern "C" int ds_event_create(void **out_event) {

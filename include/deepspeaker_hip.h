@@ -9,10 +9,23 @@
  *
  * Conventions (all entry points):
  *   - plain device pointers and sizes, no torch types; `stream` is a hipStream_t
- *     passed as void* (the caller's current stream).  Work is only enqueued; the
- *     library never synchronises, allocates, frees or keeps mutable global state,
- *     so every call is re-entrant and hipGraph-capturable.
- *   - the caller owns all buffers (inputs, outputs, scratch).
+ *     passed as void* (the caller's current stream).  Work is only enqueued: no
+ *     entry point synchronises the device or a stream (ds_event_elapsed_ms, a
+ *     read-out helper, waits for its `stop` event), so calls are re-entrant and
+ *     hipGraph-capturable.
+ *   - the caller owns all tensor buffers (inputs, outputs, scratch).  State the
+ *     LIBRARY owns -- all of it, each item behind its own lock or thread-local:
+ *       (1) tile-scheduling slots of the persistent fp16 kernels: device memory in
+ *           64 KiB chunks, hipMalloc'ed on first use per device under a mutex and
+ *           never freed; a ring of 8 slots per (device, stream) for eager launches,
+ *           one slot for good per launch captured into a graph (csrc/bn_pack.hip
+ *           ds_sched_slot).  The first launch on a new device therefore allocates;
+ *       (2) the armed event pair of ds_launch_timing_arm: thread-local, consumed by
+ *           the calling thread's next MFMA launch (csrc/ds_device.h);
+ *       (3) one process-wide tuning toggle, ds_conv_f16_set_layout_padding (off by
+ *           default; an A/B hook that changes speed, never results);
+ *       (4) the cached compute-unit count per device (read once).
+ *     Nothing else is kept between calls.
  *   - return value: 0 = DS_OK, negative = argument error (below), positive = the
  *     hipError_t of a failed launch.  Nothing throws, aborts or prints.
  *   - activations are channels-last fp32:  [B, T', F', C]  (the reference's NCHW
@@ -61,7 +74,9 @@ extern "C" {
 #define DS_CONV_CK      8   /* input-channel chunk of the packed weight layout */
 
 int ds_version(void);            /* 100: round 1; 200: round 2 (fp16 path, grouped BatchNorm backward, ds_bn_bwd_partial_rows takes C);
-                                    300 / 301: round 3 (persistent fp16 kernels, split grouped BatchNorm backward; + ds_conv_dgrad_bnbwd_bf16) */
+                                    300 / 301: round 3 (persistent fp16 kernels, split grouped BatchNorm backward; + ds_conv_dgrad_bnbwd_bf16);
+                                    400: round 4 (fp16 training step: ds_*_f16 train entry points, ds_wgrad_f16, probes of the
+                                    near-tie refinement, launch-bound timing); 500: round 5 */
 /* launch timing without marker packets: the next MFMA convolution / filter-gradient launch of the calling thread
  * records its own execution into the armed pair (hipExtLaunchKernelGGL); ds_launch_timing_end() disarms and returns
  * how many such launches happened since arming (1 = the timed call was a single kernel) */

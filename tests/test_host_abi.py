@@ -29,7 +29,7 @@ def test_hip_library_exports_every_declared_symbol():
         import __graft_entry__
         __graft_entry__.build()
     lib = _native.NativeLib(path)            # resolves every symbol or raises AttributeError
-    assert lib.raw("ds_version")() >= 100
+    assert lib.raw("ds_version")() >= 500            # round 5 (include/deepspeaker_hip.h)
     assert lib.error_string(-1) == "bad shape"
     # argument validation happens before any launch, so it is testable without a GPU
     shp = _native.ConvShape(1, 8, 8, 7, 64, 3, 1)
@@ -176,3 +176,19 @@ def test_weight_init_statistics_match_the_reference_rule():
         elif ".bn" in name and name.endswith("bias"):
             assert bool((p == 0).all()), name
     assert checked == 12
+
+
+def test_replayed_pmc_traffic_belongs_to_this_build():
+    """bench.py replays roofline.traffic from profiles/pmc_traffic.json (HBM counters cannot be read from inside the
+    process).  The entry of the headline family records the digest of the kernel sources it was collected on; a kernel
+    change without a new PMC pass (tools/pmc_run.sh, tools/pmc_summary.py, tools/pmc_traffic_update.py) fails HERE, and
+    bench.py prints traffic = null with the reason instead of a stale figure."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_digest", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    entry = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["f16"]
+    assert entry["kernel_sources_sha256"] == bench.conv_sources_digest("f16"), \
+        "fp16 convolution sources changed since " + entry["source"] + ": collect the PMC passes again"
+    assert os.path.exists(os.path.join(ROOT, entry["source"]))
