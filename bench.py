@@ -524,6 +524,10 @@ def main():
                         "what": "the same K-step region with consecutive steps alternating over two HIP streams "
                                 "(every step complete inside the bracket); results are the same tensors"}
             extras["pipelined_fn"] = run_pipelined
+        if precision == args.precision and getattr(model, "f16_guard", None) is not None:
+            # the fp16 path's precision guard (precision_guard.py): what it measured on this workload and which kernels
+            # the timed forwards therefore ran (an escalation would make this line a bf16x3 line, and say so)
+            extras["precision_guard"] = model.f16_guard.report()
         return elapsed, prof, again, refine, isolated
 
     red_modes = [None, None]
@@ -690,6 +694,8 @@ def main():
             return measure_train(tp, kt, 2)[0], "this process"
         et, leg_where = train_leg("bf16x3")
         et16, _ = train_leg("f16")
+    # the arithmetic the timed forwards really ran in: the requested one, unless the fp16 guard escalated
+    eff_prec = extras.get("precision_guard", {}).get("verdict", args.precision)
     if rank == 0:
         value = emb_per_step * args.steps / elapsed
         # the launches of every --profile-every-th forward of the timed region carry timing events
@@ -700,7 +706,7 @@ def main():
             "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "pre_steps": pre_steps(args.warmup),
             "world_size": dist.get_world_size() if multi else 1, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": eff_prec,
             "data": "synthetic" + (" (ABLATED: " + ",".join(sorted(ablate)) + " -- not the contract workload)" if ablate else ""),
             "config": {"workload": "BASELINE configs[1]: full DeepSpeaker ResCNN (64/128/256/512) eval forward + "
                                    "triplet loss + filter (near ties refined) + semi-hard negative search over the "
@@ -708,12 +714,14 @@ def main():
                        "batch_triplets": BATCH_TRIPLETS, "utterances_per_step_per_gpu": 3 * BATCH_TRIPLETS,
                        "frames": FRAMES, "parallelism": f"dp{world}",
                        "forward_calls_per_step": 3 if args.split_apn else 1, "steps_in_flight": max(1, args.streams),
-                       "arith": ARITH[args.precision]},
-            "roofline": roofline_of(args.precision, prof, profiled_steps),
+                       "arith": ARITH[eff_prec]},
+            "roofline": roofline_of(eff_prec, prof, profiled_steps),
             "whole_forward_tflops": round(value * FWD_FLOPS_PER_EMB / 1e12, 2),
         }
         # the whole step (conv1, tail, loss, filter, refinement, search and launch gaps included) against the same peak
-        out["roofline"]["step_frac"] = round(value * FWD_FLOPS_PER_EMB / 1e12 / PEAK_TFLOPS[args.precision], 4)
+        out["roofline"]["step_frac"] = round(value * FWD_FLOPS_PER_EMB / 1e12 / PEAK_TFLOPS[eff_prec], 4)
+        if "precision_guard" in extras:
+            out["precision_guard"] = extras["precision_guard"]
         if again:       # the contract's region is `value`; these are the same region timed again (box spread, DVFS)
             out["repeats_ms_per_step"] = {"median": round(float(np.median(again)), 3), "min": round(min(again), 3),
                                           "max": round(max(again), 3), "n": len(again)}
@@ -723,7 +731,7 @@ def main():
             out["pipelined"] = extras["pipelined"]
         if isolated is not None:
             iso_ms, iso_prof = isolated
-            ir = roofline_of(args.precision, iso_prof, 10)
+            ir = roofline_of(eff_prec, iso_prof, 10)
             out["roofline"]["isolated"] = {
                 "what": "the same launches with nothing else on the chip (10 forwards back to back, no side stream)",
                 "forward_ms": round(iso_ms, 3), "achieved": ir["achieved"], "frac": ir["frac"],
@@ -755,7 +763,8 @@ def main():
         # (what the refinement did in the timed steps -- overflows / band violations / the embedding error it observed --
         # the roofline, the CPU baseline), then the secondaries
         head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "pre_steps", "world_size", "ms_per_step",
-                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "refine", "roofline", "cpu_baseline", "config")
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "precision_guard", "refine", "roofline", "cpu_baseline",
+                "config")
         out = {**{k: out[k] for k in head if k in out}, **{k: v for k, v in out.items() if k not in head}}
         print(json.dumps(out))
     if multi:

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "ds_cast_f16_to_f32": (c_int, [_P, _P, c_longlong, _P]),
     "ds_avgpool_time_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_l2norm_scale_f32": (c_int, [_P, _P, c_int, c_int, c_float, c_float, _P]),
+    "ds_max_abs_diff_f32": (c_int, [_P, _P, c_longlong, _P, _P]),
     "ds_fc_workspace_floats": (c_longlong, [c_int, c_int, c_int]),
     "ds_fc_l2norm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "ds_pairwise_distance_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
@@ -155,10 +156,11 @@ _SIGNATURES = {
     "ds_roc_sweep_f32": (c_int, [_P, _P, c_int, c_float, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
     "ds_assemble_crops_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_optim_chunk_elems": (c_int, []),
-    "ds_adagrad_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P]),
-    "ds_sgd_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_int, _P]),
+    "ds_adagrad_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P, _P]),
+    "ds_sgd_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_int, _P, _P]),
+    "ds_nonfinite_flag_f32": (c_int, [_P, c_longlong, _P, _P]),
     "ds_adam_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_float,
-                                 c_float, c_float, _P]),
+                                 c_float, c_float, _P, _P]),
     "ds_pairwise_distance_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_triplet_margin_bwd_f32": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P]),
     "ds_l2norm_scale_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),

@@ -21,10 +21,13 @@ struct OptTables {
     const long long *numel;
     const int *chunk_tensor;
     const int *chunk_index;  // chunk number inside its tensor
+    const int *skip;         // nullable: a device flag; non-zero = leave everything untouched (gradient overflow of a
+                             // loss-scaled step, ds_nonfinite_flag_f32) -- decided on the device, no host round trip
 };
 
 // torch.optim.Adagrad (single-tensor path): grad += wd*p; sum += grad*grad; p -= clr * grad / (sqrt(sum) + eps)
 __global__ void __launch_bounds__(256) adagrad_kernel(const OptTables t, float clr, float wd, float eps) {
+    if (t.skip != nullptr && *t.skip != 0) return;
     const int ti = t.chunk_tensor[blockIdx.x];
     const long long n = t.numel[ti];
     const long long i0 = (long long)t.chunk_index[blockIdx.x] * OPT_CHUNK;
@@ -46,6 +49,7 @@ __global__ void __launch_bounds__(256) adagrad_kernel(const OptTables t, float c
 // torch.optim.SGD: grad += wd*p; buf = first ? grad : momentum*buf + (1-dampening)*grad; p -= lr*buf
 __global__ void __launch_bounds__(256) sgd_kernel(const OptTables t, float lr, float momentum, float dampening, float wd,
                                                   int first) {
+    if (t.skip != nullptr && *t.skip != 0) return;
     const int ti = t.chunk_tensor[blockIdx.x];
     const long long n = t.numel[ti];
     const long long i0 = (long long)t.chunk_index[blockIdx.x] * OPT_CHUNK;
@@ -71,6 +75,7 @@ __global__ void __launch_bounds__(256) sgd_kernel(const OptTables t, float lr, f
 // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 __global__ void __launch_bounds__(256) adam_kernel(const OptTables t, float lr, float b1, float b2, float eps, float wd,
                                                    float bc1, float bc2_sqrt) {
+    if (t.skip != nullptr && *t.skip != 0) return;
     const int ti = t.chunk_tensor[blockIdx.x];
     const long long n = t.numel[ti];
     const long long i0 = (long long)t.chunk_index[blockIdx.x] * OPT_CHUNK;
@@ -93,7 +98,33 @@ __global__ void __launch_bounds__(256) adam_kernel(const OptTables t, float lr, 
     }
 }
 
+// flag = 1 if any of x[0..n) is inf or NaN (every finder stores the same value: no atomics, no ordering needed); the flag
+// is NOT cleared here -- several tensors of one step accumulate into it
+__global__ void __launch_bounds__(256) nonfinite_flag_kernel(const float *x, long long n, int *flag) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    bool bad = false;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const f32x4 v = *(const f32x4 *)(x + i);
+            // (v - v) is 0 for finite values and NaN for inf / NaN
+            bad |= !((v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]) == 0.0f);
+        } else {
+            for (long long j = i; j < n; ++j) bad |= !(x[j] - x[j] == 0.0f);
+        }
+    }
+    if (bad) *flag = 1;
+}
+
 }  // namespace
+
+extern "C" int ds_nonfinite_flag_f32(const float *x, long long n, int *flag, void *stream) {
+    DS_REQUIRE(x && flag, DS_ERR_NULL);
+    DS_REQUIRE(n > 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE(((size_t)x & 15) == 0, DS_ERR_ALIGNMENT);
+    const long long want = (n + 4095) / 4096;
+    DS_LAUNCH(nonfinite_flag_kernel, (int)(want < 1024 ? want : 1024), 256, 0, stream, x, n, flag);
+    return ds_last_launch_error();
+}
 
 extern "C" int ds_optim_chunk_elems(void) { return OPT_CHUNK; }
 
@@ -111,34 +142,39 @@ static inline int opt_tables(OptTables &t, DS_OPT_ARGS) {
     t.numel = numel;
     t.chunk_tensor = chunk_tensor;
     t.chunk_index = chunk_index;
+    t.skip = nullptr;
     return DS_OK;
 }
 
-extern "C" int ds_adagrad_step_f32(DS_OPT_ARGS, float clr, float weight_decay, float eps, void *stream) {
+extern "C" int ds_adagrad_step_f32(DS_OPT_ARGS, float clr, float weight_decay, float eps, const int *skip_flag,
+                                   void *stream) {
     OptTables t;
     int rc = opt_tables(t, params, grads, state1, state2, numel, chunk_tensor, chunk_index, n_chunks);
     if (rc) return rc;
     DS_REQUIRE(state1, DS_ERR_NULL);
+    t.skip = skip_flag;
     DS_LAUNCH(adagrad_kernel, n_chunks, 256, 0, stream, t, clr, weight_decay, eps);
     return ds_last_launch_error();
 }
 
 extern "C" int ds_sgd_step_f32(DS_OPT_ARGS, float lr, float momentum, float dampening, float weight_decay,
-                               int first_step, void *stream) {
+                               int first_step, const int *skip_flag, void *stream) {
     OptTables t;
     int rc = opt_tables(t, params, grads, state1, state2, numel, chunk_tensor, chunk_index, n_chunks);
     if (rc) return rc;
     DS_REQUIRE(momentum == 0.0f || state1, DS_ERR_NULL);
+    t.skip = skip_flag;
     DS_LAUNCH(sgd_kernel, n_chunks, 256, 0, stream, t, lr, momentum, dampening, weight_decay, first_step);
     return ds_last_launch_error();
 }
 
 extern "C" int ds_adam_step_f32(DS_OPT_ARGS, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                float bias_correction1, float bias_correction2_sqrt, void *stream) {
+                                float bias_correction1, float bias_correction2_sqrt, const int *skip_flag, void *stream) {
     OptTables t;
     int rc = opt_tables(t, params, grads, state1, state2, numel, chunk_tensor, chunk_index, n_chunks);
     if (rc) return rc;
     DS_REQUIRE(state1 && state2, DS_ERR_NULL);
+    t.skip = skip_flag;
     DS_LAUNCH(adam_kernel, n_chunks, 256, 0, stream, t, lr, beta1, beta2, eps, weight_decay, bias_correction1,
               bias_correction2_sqrt);
     return ds_last_launch_error();

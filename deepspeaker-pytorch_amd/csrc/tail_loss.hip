@@ -52,6 +52,36 @@ __global__ void __launch_bounds__(256) l2norm_scale_kernel(const float *f, float
     }
 }
 
+// ---- max |a - b| and max |b| over two equally shaped tensors (the precision guard's error measure) -----------
+// one workgroup, fixed fold order: out[0] = max |a[i] - b[i]|, out[1] = max |b[i]|
+__global__ void __launch_bounds__(1024) max_abs_diff_kernel(const float *a, const float *b, long long n, float *out) {
+    float (*part)[16] = (float (*)[16])ds_dynamic_lds();          // [2][16]
+    float md = 0.f, mb = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const float vb = b[i];
+        md = fmaxf(md, fabsf(a[i] - vb));
+        mb = fmaxf(mb, fabsf(vb));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        md = fmaxf(md, ds_shfl_xor(md, m));
+        mb = fmaxf(mb, ds_shfl_xor(mb, m));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = md;
+        part[1][threadIdx.x >> 6] = mb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            md = fmaxf(md, part[0][w]);
+            mb = fmaxf(mb, part[1][w]);
+        }
+        out[0] = md;
+        out[1] = mb;
+    }
+}
+
 // ---- pairwise distance rows ------------------------------------------------------------------------
 __device__ __forceinline__ float row_sqdist(const float *a, const float *b, int D, int lane) {
     float s = 0.f;
@@ -678,6 +708,13 @@ extern "C" int ds_l2norm_scale_f32(const float *f, float *e, int B, int D, float
     DS_REQUIRE(f && e, DS_ERR_NULL);
     DS_REQUIRE(B > 0 && D > 0, DS_ERR_BAD_SHAPE);
     DS_LAUNCH(l2norm_scale_kernel, ds_ceil_div(B, 4), 256, 0, stream, f, e, B, D, alpha, eps);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_max_abs_diff_f32(const float *a, const float *b, long long n, float *out2, void *stream) {
+    DS_REQUIRE(a && b && out2, DS_ERR_NULL);
+    DS_REQUIRE(n > 0, DS_ERR_BAD_SHAPE);
+    DS_LAUNCH(max_abs_diff_kernel, 1, 1024, 2 * 16 * sizeof(float), stream, a, b, n, out2);
     return ds_last_launch_error();
 }
 

@@ -329,7 +329,7 @@ static int plan_wgrad_h(WgradPlanH &pl, const ds_conv_shape *s) {
     k.n_co_tiles = s->Cout / WB_C;
     k.n_ci_tiles = s->Cin / WB_C;
     const int base_blocks = k.n_co_tiles * k.n_ci_tiles;
-    int S = ds_ceil_div(256, base_blocks);                // one workgroup per CU, every one with the same share of the tiles
+    int S = ds_ceil_div(ds_cu_count(), base_blocks);      // one workgroup per CU, every one with the same share of the tiles
     if (S > k.n_tiles) S = k.n_tiles;
     if (S < 1) S = 1;
     k.S = S;

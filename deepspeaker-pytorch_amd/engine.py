@@ -564,6 +564,11 @@ class Engine:
                 pw.fc_rows = torch.empty(pw.fc_src.numel(), dtype=torch.float32, device=dev)
                 self.lib.call("ds_pack_fc_weight_rows_f32", self._p(pw.fc_src), self._p(pw.fc_rows), n_out, pw.fc_cf[0],
                               pw.fc_cf[1], self._stream(x))
+                # packed lazily on the stream of the first plan that wants it, then shared: plans built later for OTHER
+                # streams (BatchesInFlight lanes, the refinement's side stream) order themselves after this event
+                pw.fc_rows_event = torch.cuda.current_stream(dev).record_event() if x.is_cuda else None
+            elif x.is_cuda and getattr(pw, "fc_rows_event", None) is not None:
+                torch.cuda.current_stream(dev).wait_event(pw.fc_rows_event)
             f = buf(B, n_out)
             calls.append((self.lib.raw("ds_tail_small_f32"),
                           (self._p(a), self._p(pw.fc_rows), self._p(pw.fc_bias.detach()), self._p(f), e_slot, B, h, k, n_out,

@@ -84,6 +84,7 @@ class RefinePolicy:
         self.max_seen = 0
         self._ring = self._ring_err = None
         self._next = 0
+        self.guard = None               # the model's precision_guard.F16Guard (refine_policy() sets it)
 
     def observe(self, count: int, err: float = None, n_samples: int = 0, emb_err: float = None):
         self.seen = (self.seen + [int(count)])[-self.HISTORY:]
@@ -95,6 +96,8 @@ class RefinePolicy:
             self.err_max_ever = max(self.err_max_ever, float(err))
         if emb_err is not None:
             self.emb_errs = (self.emb_errs + [float(emb_err)])[-BAND_WINDOW:]
+            if self.guard is not None:          # the model's fp16 precision guard takes the same sample in
+                self.guard.observe_probe(emb_err)
 
     @property
     def embedding_error_observed(self) -> float:
@@ -401,6 +404,7 @@ def refine_policy(model) -> RefinePolicy:
     pol = getattr(model, "_refine_policy", None)
     if pol is None:
         pol = RefinePolicy()
+        pol.guard = getattr(model, "f16_guard", None)
         object.__setattr__(model, "_refine_policy", pol)
     return pol
 

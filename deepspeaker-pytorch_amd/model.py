@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import _native
 from .engine import ALPHA, BNParams, Engine, L2_EPS, PRECISIONS, STAGE_CHANNELS
+from .precision_guard import F16_GUARD_THRESHOLD, F16Guard
 
 _engine: Optional[Engine] = None
 
@@ -356,7 +357,7 @@ class _ResCNNTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
         eng = get_engine()
-        prec = model._train_arith()
+        prec = model._train_arith(x)
         if prec == "f16":
             from .train_f16 import forward_train_group_f16
             pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
@@ -381,7 +382,8 @@ class _ResCNNTrainFn(torch.autograd.Function):
             from .train_f16 import backward_train_f16
             grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
                                        loss_scale=ctx.model.loss_scale, reducer=ctx.model._reducer,
-                                       reduce_gradients=ctx.model._reducer is not None)
+                                       reduce_gradients=ctx.model._reducer is not None,
+                                       overflow_flag=ctx.model.grad_overflow_flag(ge.device))
         else:
             grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge.contiguous().float(),
                                    reducer=ctx.model._reducer, precision=ctx.precision,
@@ -397,7 +399,7 @@ class _ResCNNTripletFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xa, xp, xn, model, *params):
         eng = get_engine()
-        prec = model._train_arith()
+        prec = model._train_arith(xa, members=3)
         if prec == "f16":
             from .train_f16 import forward_train_group_f16
             pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
@@ -422,7 +424,8 @@ class _ResCNNTripletFn(torch.autograd.Function):
         if ctx.precision == "f16":
             from .train_f16 import backward_train_f16
             grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, loss_scale=ctx.model.loss_scale,
-                                       reducer=ctx.model._reducer, reduce_gradients=ctx.model._reducer is not None)
+                                       reducer=ctx.model._reducer, reduce_gradients=ctx.model._reducer is not None,
+                                       overflow_flag=ctx.model.grad_overflow_flag(ge.device))
         else:
             grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, reducer=ctx.model._reducer,
                                    precision=ctx.precision, reduce_gradients=ctx.model._reducer is not None)
@@ -472,8 +475,12 @@ class DeepSpeakerModel(nn.Module):
     """
 
     def __init__(self, embedding_size, num_classes, feature_dim=64, n_stages: int = 4, precision: str = "f32",
-                 low_latency: bool = False, train_precision: Optional[str] = None, loss_scale: float = 1024.0):
+                 low_latency: bool = False, train_precision: Optional[str] = None, loss_scale: float = 1024.0,
+                 f16_guard: Optional[float] = F16_GUARD_THRESHOLD):
         super().__init__()
+        # precision "f16": the eval path measures its own distance to the f32-class path on sample rows and runs the
+        # f32-class kernels instead while that estimate is above `f16_guard` (precision_guard.py; None: never)
+        object.__setattr__(self, "f16_guard", F16Guard(f16_guard) if (f16_guard is not None and precision == "f16") else None)
         # arithmetic of TRAINING steps: None = the f32-class default ("bf16x3" when `precision` is a 16-bit one, else
         # "f32"); "f16" = the opt-in fp16 step (train_f16.py: fp16 activations and loss-scaled fp16 gradients in HBM, one
         # fp16 MFMA per product; embeddings / loss within 1e-3, gradients within 3e-3 of the masked oracle)
@@ -557,11 +564,58 @@ class DeepSpeakerModel(nn.Module):
         sd["model.fc.bias"] = self.model.fc.bias
         return sd
 
-    def _train_arith(self) -> str:
-        """arithmetic of the next training step (see `train_precision`)"""
+    # ---- the loss-scaled fp16 training step's overflow handling (train_precision="f16") ----
+    def grad_overflow_flag(self, device=None) -> torch.Tensor:
+        """int32 device tensor [1]: 1 after a backward pass of the fp16 training step whose scaled gradients left fp16's
+        range (inf / NaN in a filter gradient), 0 otherwise; rewritten by every such pass.  The fused optimizers of
+        `optim.create_optimizer(model, ...)` read it ON THE DEVICE and skip the update (no host synchronisation);
+        `loss_scale` itself is static unless the training loop calls `update_loss_scale()`."""
+        dev = device if device is not None else next(self.parameters()).device
+        flag = self.__dict__.get("_overflow_flag")
+        if flag is None or flag.device != torch.device(dev):
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            object.__setattr__(self, "_overflow_flag", flag)
+        return flag
+
+    @property
+    def grad_overflow(self) -> bool:
+        """Did the last fp16 backward pass overflow?  (Reads the flag: a host synchronisation.)"""
+        flag = self.__dict__.get("_overflow_flag")
+        return bool(flag.item()) if flag is not None else False
+
+    def update_loss_scale(self, backoff: float = 0.5, growth: float = 2.0, growth_interval: int = 2000,
+                          max_scale: float = 65536.0) -> bool:
+        """Dynamic loss scaling for loops that want it (torch.amp.GradScaler.update's rule): call after optimizer.step().
+        Overflow in the last pass -> loss_scale *= backoff (that step was skipped on the device); `growth_interval` clean
+        passes in a row -> loss_scale *= growth.  One host synchronisation per call; returns whether the step overflowed."""
+        bad = self.grad_overflow
+        if bad:
+            self.loss_scale = max(1.0, self.loss_scale * backoff)
+            self._clean_steps = 0
+        else:
+            self._clean_steps = self.__dict__.get("_clean_steps", 0) + 1
+            if self._clean_steps >= growth_interval:
+                self.loss_scale = min(max_scale, self.loss_scale * growth)
+                self._clean_steps = 0
+        return bad
+
+    def _train_arith(self, x: Optional[torch.Tensor] = None, members: int = 1) -> str:
+        """arithmetic of the next training step (see `train_precision`); `x`: one member's input batch"""
         tp = self.train_precision
         if tp is None:
             return "bf16x3" if self.precision in ("bf16x3", "f16") else "f32"
+        if tp == "f16" and x is not None:
+            # the fp16 BatchNorm backward addresses the parity-class layout of the stride-2 data gradient with 24-bit
+            # pixel indices (csrc/train_f16.hip bwd_reduce_f16): all members' stage-1 pixels must stay below 2^24 (the
+            # bench step has 1.97 M).  Larger steps run the f32-class arithmetic instead of failing inside the pass.
+            pixels = members * x.shape[0] * ((x.shape[2] - 1) // 2 + 1) * 32
+            if pixels >= (1 << 24):
+                if not self.__dict__.get("_warned_f16_step_size"):
+                    import warnings
+                    warnings.warn(f"fp16 training step: {pixels} stage-1 pixels in one step exceed the 2^24 of its BatchNorm "
+                                  "backward; this step (and every one this large) runs train_precision='bf16x3'")
+                    self.__dict__["_warned_f16_step_size"] = True
+                return "bf16x3"
         return tp
 
     def _packed(self, with_dgrad: bool = False, with_bf16: bool = False, with_f16: bool = False, f32_banks: bool = True,
@@ -650,10 +704,28 @@ class DeepSpeakerModel(nn.Module):
                 self._stat_updates += 1
                 self.features = e
         else:
-            pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
-            self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=self.precision,
+            prec = self.eval_precision(x)
+            pw = self._packed(with_bf16=prec in ("bf16x3", "bf16"), with_f16=prec == "f16")
+            self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=prec,
                                                               low_latency=self.low_latency)
         return self.features
+
+    def eval_precision(self, x: torch.Tensor, lengths=None) -> str:
+        """The arithmetic the next eval forward of `x` runs in: `self.precision`, except that a model of precision "f16"
+        whose guard has measured an fp16 error estimate above its threshold runs "bf16x3" (precision_guard.F16Guard;
+        the first call on new weights measures -- one host synchronisation)."""
+        if self.f16_guard is None or self.precision != "f16":
+            return self.precision
+        return self.f16_guard.precision_for(self, x, lengths)
+
+    def calibrate_precision(self, x: torch.Tensor) -> Optional[dict]:
+        """Run the fp16 guard's check on the first rows of `x` now (what the first eval forward on new weights does by
+        itself; needed explicitly only before capturing the forward into a graph).  Returns the guard's report."""
+        _require_cuda(x, "DeepSpeakerModel.calibrate_precision")
+        if self.f16_guard is None:
+            return None
+        self.f16_guard.calibrate(self, x.contiguous().float())
+        return self.f16_guard.report()
 
     def forward_triplet(self, data_a, data_p, data_n):
         """`out_a, out_p, out_n = model(data_a), model(data_p), model(data_n)` (train_triplet.py:215) as one call.
@@ -717,9 +789,26 @@ class DeepSpeakerModel(nn.Module):
             dev = store.features.device
         order = torch.argsort(lens, stable=True)
         out = torch.empty((n, self.embedding_size), dtype=torch.float32, device=dev)
-        pw = self._packed(with_bf16=self.precision in ("bf16x3", "bf16"), with_f16=self.precision == "f16")
         eng = get_engine()
         sorted_lens = lens[order].tolist()
+        # the arithmetic (precision "f16": the guard's verdict; on new weights it measures first, on a zero-padded batch
+        # of up to 32 utterances around the median length) and every derived tensor -- packed filters, folded BatchNorm --
+        # are settled HERE, on the caller's stream, before the lanes fork: built inside one lane, the other lanes' first
+        # batches would read them with no ordering after the kernels that write them
+        prec = self.precision
+        if self.f16_guard is not None and prec == "f16":
+            mid = order[max(0, n // 2 - 16):n // 2 + 16]
+            ln_s = lens[mid]
+            t_s = int(-(-int(ln_s.max()) // pad_to) * pad_to)
+            if store is not None:
+                x_s = store.crops(mid.numpy(), [0] * len(mid), t_s)
+            else:
+                x_s = torch.zeros((len(mid), 1, t_s, 64), dtype=torch.float32, device=dev)
+                for r, j in enumerate(mid.tolist()):
+                    x_s[r, 0, :feats[j].shape[0]].copy_(feats[j])
+            prec = self.f16_guard.precision_for(self, x_s, ln_s)
+        pw = self._packed(with_bf16=prec in ("bf16x3", "bf16"), with_f16=prec == "f16")
+        folded = self._folded()
         order_dev = order.to(dev)                # once: a per-batch pageable copy would stall the host on the stream
         on_gpu = dev.type == "cuda"              # (the host emulator runs CPU tensors in program order)
         if not on_gpu:
@@ -752,7 +841,7 @@ class DeepSpeakerModel(nn.Module):
                     x = torch.zeros((len(idx), 1, t_pad, 64), dtype=torch.float32, device=dev)
                     for r, j in enumerate(idx.tolist()):
                         x[r, 0, :feats[j].shape[0]].copy_(feats[j])
-                e = eng.forward_eval_planned(x, pw, self._folded(), precision=self.precision, lengths=ln)
+                e = eng.forward_eval_planned(x, pw, folded, precision=prec, lengths=ln)
                 out.index_copy_(0, order_dev[i - cnt:i], e)
             k += 1
         if in_flight > 1:

@@ -19,6 +19,14 @@ from .model import _require_cuda, get_engine
 
 class _FusedBase(torch.optim.Optimizer):
     _engine = None          # tests may inject an Engine bound to the host emulator
+    # Optional int32 device tensor [1]: while it is non-zero a step() leaves parameters and state untouched (decided on the
+    # device, no host round trip) -- the gradient-overflow flag of the loss-scaled fp16 training step
+    # (DeepSpeakerModel.grad_overflow; create_optimizer wires it).  The host-side step counters (Adagrad's decayed lr, Adam's
+    # bias correction) still advance on a skipped step.
+    skip_flag = None
+
+    def _skip(self, eng):
+        return eng._p(self.skip_flag) if self.skip_flag is not None else None
 
     def _eng(self):
         return self._engine if self._engine is not None else get_engine()
@@ -131,7 +139,7 @@ class FusedAdagrad(_FusedBase):
                 step = float(states[0]["step"])
                 clr = group["lr"] / (1 + (step - 1) * group["lr_decay"])
                 eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
-                             eng._stream(params[0]))
+                             self._skip(eng), eng._stream(params[0]))
                 self._bump_versions(params)
         return loss
 
@@ -151,7 +159,7 @@ class FusedSGD(_FusedBase):
                 params, states, c = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False,
                                                  with_step=False, params=part)
                 eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
-                             group["weight_decay"], int(fresh), eng._stream(params[0]))
+                             group["weight_decay"], int(fresh), self._skip(eng), eng._stream(params[0]))
                 self._bump_versions(params)
         return loss
 
@@ -174,17 +182,24 @@ class FusedAdam(_FusedBase):
                 step = float(states[0]["step"])
                 b1, b2 = group["betas"]
                 eng.lib.call("ds_adam_step_f32", *self._args(eng, c), group["lr"], b1, b2, group["eps"],
-                             group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), eng._stream(params[0]))
+                             group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), self._skip(eng),
+                             eng._stream(params[0]))
                 self._bump_versions(params)
         return loss
 
 
 def create_optimizer(model, new_lr, optimizer="adagrad", lr_decay=1e-4, wd=0.0):
-    """train_triplet.py:369-383 with the fused implementations (same hyper-parameters)."""
+    """train_triplet.py:369-383 with the fused implementations (same hyper-parameters).  A model whose training step is the
+    loss-scaled fp16 one (train_precision="f16") hands the optimizer its gradient-overflow flag: a step whose scaled
+    gradients left fp16's range updates nothing."""
     if optimizer == "sgd":
-        return FusedSGD(model.parameters(), lr=new_lr, momentum=0.9, dampening=0.9, weight_decay=wd)
-    if optimizer == "adam":
-        return FusedAdam(model.parameters(), lr=new_lr, weight_decay=wd)
-    if optimizer == "adagrad":
-        return FusedAdagrad(model.parameters(), lr=new_lr, lr_decay=lr_decay, weight_decay=wd)
-    raise ValueError(optimizer)
+        opt = FusedSGD(model.parameters(), lr=new_lr, momentum=0.9, dampening=0.9, weight_decay=wd)
+    elif optimizer == "adam":
+        opt = FusedAdam(model.parameters(), lr=new_lr, weight_decay=wd)
+    elif optimizer == "adagrad":
+        opt = FusedAdagrad(model.parameters(), lr=new_lr, lr_decay=lr_decay, weight_decay=wd)
+    else:
+        raise ValueError(optimizer)
+    if getattr(model, "train_precision", None) == "f16" and hasattr(model, "grad_overflow_flag"):
+        opt.skip_flag = model.grad_overflow_flag()
+    return opt

@@ -57,6 +57,13 @@ class BatchesInFlight:
                 consumer = torch.cuda.current_stream(x.device)
                 lanes = self._lanes(x.device)
             lane = lanes[i % self.in_flight]
+            # whatever the forward derives from the weights -- the arithmetic a precision-"f16" model's guard settles on
+            # (it measures on new weights), the packed filters, the folded BatchNorm -- is built HERE, on the consumer's
+            # stream, ahead of the lanes' wait: built inside one lane (first call, first eval after a training step or a
+            # weight load), the next lane's forward would read it with no ordering after the kernels that write it
+            prec = self.model.eval_precision(x.contiguous().float())
+            self.model._packed(with_bf16=prec in ("bf16x3", "bf16"), with_f16=prec == "f16")
+            self.model._folded()
             lane.wait_stream(consumer)      # the batch was produced on the consumer's stream
             with torch.cuda.stream(lane), torch.no_grad():
                 x.record_stream(lane)

@@ -26,7 +26,7 @@ BatchNorm layer and direction carrying all members' sums, f32 gradient buckets p
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -190,18 +190,23 @@ def _wgrad_c1(eng: Engine, shp: ConvShape, x32, gz16, out, inv_scale: float):
 
 def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: PackedWeights, saved: SavedForward,
                        ge: torch.Tensor, loss_scale: float = DEFAULT_LOSS_SCALE,
-                       overlap_filter_gradients=None, reducer=None, reduce_gradients: bool = False) -> Dict[str, torch.Tensor]:
+                       overlap_filter_gradients=None, reducer=None, reduce_gradients: bool = False,
+                       overflow_flag: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """Parameter gradients (reference key names and shapes, f32, un-scaled) given dL/d(embedding) `ge` [B,512] f32, from
     the fp16 tensors `forward_train_group_f16` saved.  Filter gradients run on the second stream like the f32-class
     pass's (backward._FilterGradLane); the main chain stays on ONE stream over the whole batch (measured: every member's
     BatchNorm-backward / data-gradient chain on a stream of its own, as the forward does, is bitwise the same and SLOWER --
     9.9 against 8.9 ms per step: three times the launches, and 256-utterance convolutions fill the persistent grids
     worse than one 768-utterance launch).  `reducer` / `reduce_gradients` (data parallelism): global BatchNorm sums (one
-    all-reduce per layer) and the per-stage f32 gradient buckets summed over the ranks, as backward.backward_train does."""
+    all-reduce per layer) and the per-stage f32 gradient buckets summed over the ranks, as backward.backward_train does.
+    `overflow_flag` (int32 device tensor [1]): cleared at the start of the pass, set to 1 at its end if any filter / fc
+    gradient is inf or NaN (the static loss scale was too large for this step); never read by the host here."""
     from .backward import OVERLAP_FILTER_GRADIENTS, _FilterGradLane, _GradBuckets, _wgrad as _wgrad_f32
     lib = eng.lib
     lane = _FilterGradLane(ge.device, OVERLAP_FILTER_GRADIENTS if overlap_filter_gradients is None else overlap_filter_gradients)
     inv = 1.0 / float(loss_scale)
+    if overflow_flag is not None:
+        overflow_flag.zero_()
     grads: Dict[str, torch.Tensor] = {}
     n_stages = len(pw.stages)
     G = saved.stats["model.bn1"].shape[1]
@@ -284,4 +289,13 @@ def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: Pac
         lane.run(lambda: buckets.done(s))       # this stage's three filter gradients are enqueued: reduce them now
     lane.join()
     buckets.finish()
+    if overflow_flag is not None:
+        # Loss scaling is STATIC (`loss_scale`), and ds_scale_cast_f32_to_f16 does not saturate: a scaled gradient beyond
+        # fp16's 65504 is an inf in the gradient tensors, then NaN in the BatchNorm-backward sums and in every filter
+        # gradient downstream.  Any such value reaches the filter gradients of its own layer (the sums feed dL/dz, which
+        # the filter gradient contracts), so one pass over the f32 gradient buckets (46 MB: ~10 us each at HBM rate) sees
+        # it; under data parallelism the buckets are already the global sums, so every rank raises the same flag.  The
+        # flag stays on the device: the fused optimizers read it there (optim._FusedBase.skip_flag).
+        for flat in buckets.flat.values():
+            lib.call("ds_nonfinite_flag_f32", eng._p(flat), flat.numel(), eng._p(overflow_flag), st)
     return grads

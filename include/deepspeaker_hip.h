@@ -244,6 +244,11 @@ int ds_avgpool_time_f32(const float *x, float *pooled, int B, int Hr, int Wc, in
 int ds_l2norm_scale_f32(const float *f, float *e, int B, int D, float alpha, float eps,
                         void *stream);
 
+/* out2[0] = max |a - b|, out2[1] = max |b| over n floats (one workgroup, fixed fold order): the embedding-error
+ * measure of the tests (max |d| / max |ref|) on the device -- what the fp16 precision guard of
+ * DeepSpeakerModel.forward (model.py:185-218 in eval mode) compares its fp16 and f32-class sample rows with */
+int ds_max_abs_diff_f32(const float *a, const float *b, long long n, float *out2, void *stream);
+
 /* fused projection + normalisation: f = pooled . W^T + b  (model.py:209), e = alpha f / |f|
  * (model.py:210-213).  Split-K MFMA GEMM + a deterministic reduce; `workspace` holds
  * ds_fc_workspace_floats(B,K,N) floats; `bias` and `e` may be NULL (plain GEMM, used by the backward
@@ -553,15 +558,21 @@ int ds_assemble_crops_f32(const float *features, const long long *row_start, con
 int ds_optim_chunk_elems(void);
 int ds_adagrad_step_f32(const void *params, const void *grads, const void *state1, const void *state2,
                         const long long *numel, const int *chunk_tensor, const int *chunk_index,
-                        int n_chunks, float clr, float weight_decay, float eps, void *stream);
+                        int n_chunks, float clr, float weight_decay, float eps, const int *skip_flag,
+                        void *stream);
 int ds_sgd_step_f32(const void *params, const void *grads, const void *state1, const void *state2,
                     const long long *numel, const int *chunk_tensor, const int *chunk_index, int n_chunks,
                     float lr, float momentum, float dampening, float weight_decay, int first_step,
-                    void *stream);
+                    const int *skip_flag, void *stream);
 int ds_adam_step_f32(const void *params, const void *grads, const void *state1, const void *state2,
                      const long long *numel, const int *chunk_tensor, const int *chunk_index, int n_chunks,
                      float lr, float beta1, float beta2, float eps, float weight_decay,
-                     float bias_correction1, float bias_correction2_sqrt, void *stream);
+                     float bias_correction1, float bias_correction2_sqrt, const int *skip_flag, void *stream);
+/* `skip_flag` (nullable, device): non-zero = the launch leaves parameters and state untouched -- the overflow flag of a
+ * loss-scaled fp16 training step, read on the device (no host round trip; torch.amp.GradScaler's found_inf).
+ * ds_nonfinite_flag_f32: *flag = 1 if any of x[0..n) is inf or NaN (never cleared here: the tensors of one step
+ * accumulate into one flag the caller zeroed). */
+int ds_nonfinite_flag_f32(const float *x, long long n, int *flag, void *stream);
 
 #ifdef __cplusplus
 }

@@ -302,3 +302,61 @@ def test_whole_step_fp16_vs_masked_oracle(G):
     worst = {k: rel_l2(grads[k].numpy(), ref["grads"][k].numpy()) for k in grads}
     print(sorted(worst.items(), key=lambda kv: -kv[1])[:4])
     assert max(worst.values()) < 6e-3, worst
+
+
+def test_overflowing_loss_scale_raises_the_flag_and_the_optimizer_skips_the_step():
+    """the fp16 step's loss scale is static and the scaled cast does not saturate.  A scale that pushes dL/dz
+    past fp16's 65504 must end the pass with the overflow flag set (inf / NaN in the filter gradients), the fused
+    optimizers given that flag must leave parameters AND state untouched, and a sane scale must leave the flag clear."""
+    from deepspeaker_pytorch_amd.engine import BNParams, Engine
+    from deepspeaker_pytorch_amd.optim import FusedAdagrad, FusedAdam, FusedSGD
+    from deepspeaker_pytorch_amd.train_f16 import backward_train_f16, forward_train_group_f16
+    lib = emul_lib()
+    eng = Engine(lib)
+    n_stages = 2
+    sd = O.make_state_dict(seed=72, num_classes=4, n_stages=n_stages)
+    xs = [torch.from_numpy(O.make_input(seed=90, batch=2, frames=16))]
+    names = []
+    for i in range(1, n_stages + 1):
+        names += [f"model.bn{i}", f"model.layer{i}.0.bn1", f"model.layer{i}.0.bn2"]
+    tsd = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    bns = {n: BNParams(tsd[n + ".weight"], tsd[n + ".bias"], tsd[n + ".running_mean"].clone(), tsd[n + ".running_var"].clone())
+           for n in names}
+    pw = eng.pack_weights(tsd, n_stages, with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
+    ge = torch.from_numpy(np.random.RandomState(6).randn(2, 512).astype(np.float32) * 1e-2)
+    flag = torch.full((1,), 7, dtype=torch.int32)                      # stale value: the pass must rewrite it
+    for scale, expect in ((1024.0, 0), (1e9, 1)):
+        embs, saved = forward_train_group_f16(eng, xs, pw, bns, save=True)
+        grads = backward_train_f16(eng, {n: b.weight for n, b in bns.items()}, pw, saved, ge, loss_scale=scale,
+                                   overflow_flag=flag)
+        assert int(flag) == expect, (scale, int(flag))
+        finite = all(bool(torch.isfinite(g).all()) for k, g in grads.items() if "conv" in k or "fc" in k)
+        assert finite == (expect == 0)
+    # the flag is still 1: every fused optimizer leaves parameter and state alone; cleared, they step
+    for cls, kw in ((FusedAdagrad, dict(lr=0.1)), (FusedSGD, dict(lr=0.1, momentum=0.9, dampening=0.9)), (FusedAdam, dict(lr=0.1))):
+        p = torch.nn.Parameter(torch.arange(40, dtype=torch.float32).reshape(5, 8).clone())
+        p.grad = torch.ones_like(p)
+        opt = cls([p], **kw)
+        opt._engine = eng
+        opt.skip_flag = flag
+        before = p.detach().clone()
+        opt.step()
+        assert torch.equal(p.detach(), before), cls.__name__
+        for v in opt.state[p].values():
+            if torch.is_tensor(v) and v.numel() > 1:
+                assert float(v.abs().sum()) == 0.0, cls.__name__
+        flag.zero_()
+        opt.step()
+        assert not torch.equal(p.detach(), before), cls.__name__
+        flag.fill_(1)
+    # the detector itself: tail elements, NaN and -inf
+    x = to_aligned(np.zeros(4099, np.float32))
+    f = aligned(1, np.int32, fill=0)
+    lib.call("ds_nonfinite_flag_f32", ptr(x), 4099, ptr(f), None)
+    assert int(f[0]) == 0
+    for pos, val in ((4098, np.nan), (5, -np.inf), (4096, np.inf)):
+        x[:] = 0
+        x[pos] = val
+        f[0] = 0
+        lib.call("ds_nonfinite_flag_f32", ptr(x), 4099, ptr(f), None)
+        assert int(f[0]) == 1, (pos, val)

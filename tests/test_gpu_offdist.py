@@ -24,7 +24,7 @@ from conftest import ROOT, rel_err
 pytestmark = pytest.mark.gpu
 
 CONTRACT = 1e-3
-EMB_BAR = {"f32": 2e-5, "bf16x3": 4e-5, "f16": CONTRACT}
+EMB_BAR = {"f32": 2e-5, "bf16x3": 4e-5, "f16": CONTRACT, "f16raw": CONTRACT}
 CASES = {"x15": (4321, 768, 160, 15.0), "T100": (4322, 768, 100, 1.0), "T800": (4323, 384, 800, 1.0),
          "x15_T800": (4324, 96, 800, 15.0)}          # == tests/golden/make_golden.py OFFDIST_CASES
 
@@ -35,8 +35,10 @@ def gold():
 
 
 def build(sd, precision, num_classes=1211):
+    """precision "f16raw": the fp16 path with its precision guard switched off (f16_guard=None)"""
     from deepspeaker_pytorch_amd.model import DeepSpeakerModel
-    m = DeepSpeakerModel(512, num_classes, precision=precision)
+    kw = {"f16_guard": None} if precision == "f16raw" else {}
+    m = DeepSpeakerModel(512, num_classes, precision="f16" if precision == "f16raw" else precision, **kw)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     return m.cuda().eval()
 
@@ -72,13 +74,17 @@ def run_case(m, x, precision, ref_emb, ref_dp, ref_dn, ref_loss, ref_sel, tag, e
           f"{float(ref_dn.mean()):.3f}")
     assert err < (emb_bar or EMB_BAR[precision]), err
     assert loss_rel < CONTRACT
-    if precision == "f16" and sel.embedding_error is not None:
+    guard = getattr(m, "f16_guard", None)
+    on_f16 = precision in ("f16", "f16raw") and (guard is None or guard.verdict == "f16")      # fp16 kernels produced `e`
+    if guard is not None:
+        print(f"    precision guard: {guard.report()}")
+    if on_f16 and sel.embedding_error is not None:
         # the path's own estimate of its embedding error (fp16 vs f32-class on the 3 x slots sampled rows) is of the size
         # of the true error over all rows: the same measure on a sample can only be smaller, and not by much
         print(f"    embedding error the call observed on its {3 * sel.amb_cap} sampled rows: {sel.embedding_error:.3e} (all rows: {err:.3e})")
         assert 0.3 * err < sel.embedding_error < 1.2 * err, (sel.embedding_error, err)
     np.testing.assert_array_equal(sel.indices.cpu().numpy(), ref_sel)         # identical selection
-    if precision == "f16":
+    if on_f16:
         # the band covers what fp16 does -- or the call's own probes noticed that it does not and it fell back
         assert gap_err < 0.75 * sel.band or (sel.band_exceeded and sel.refined_all), (gap_err, sel.band)
     return gap_err, sel
@@ -139,21 +145,31 @@ def trained(request):
     return tsd, x, ref, d_p.astype(np.float32), d_n.astype(np.float32), ref_loss, ref_sel, losses
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16"])
-def test_trained_weights_realistic_inputs_vs_oracle(trained, precision):
-    """(b): the weights are whatever 24 Adagrad steps on the GPU made of them; the checker is the CPU oracle on those same
-    weights.  BatchNorm running statistics now match inputs of std 12, the clip is hit from above, distances are no
-    longer the sub-unit ones of a random-init network."""
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16", "f16raw"])
+def test_trained_weights_realistic_inputs_vs_oracle(trained, precision, request):
+    """(b): the weights are whatever 24 Adagrad / 40 SGD steps on the GPU made of them; the checker is the CPU oracle on
+    those same weights.  BatchNorm running statistics now match inputs of std 12, the clip is hit from above, distances are
+    no longer the sub-unit ones of a random-init network.
+
+    The SGD-trained network spreads the embeddings (mean d_n 6.0 against 1.3 at random init) and RAW fp16 then sits AT the
+    1e-3 contract (measured 0.86e-3 - 1.005e-3; every layer contributes, tools/f16_error_budget.py) with an error of
+    d_n - d_p (2.2e-3) past the band's floor.  precision="f16" (the default, guarded) must be INSIDE the contract on both
+    networks with no widened bar: its guard measures the first rows of the first forward against the f32-class path and
+    runs the f32-class kernels on the SGD network.  "f16raw" (f16_guard=None) is the unguarded arithmetic, kept to 1.5e-3
+    and to the band machinery that protects its selection."""
     tsd, x, ref, d_p, d_n, ref_loss, ref_sel, losses = trained
     print("\ntraining losses:", " ".join(f"{v:.3f}" for v in losses))
     m = build({k: v.numpy() for k, v in tsd.items()}, precision, num_classes=tsd["model.classifier.bias"].numel())
-    # The SGD-trained network spreads the embeddings (mean d_n 6.0 against 1.3 at random init): the fp16 path then sits AT
-    # the 1e-3 contract on the embeddings (measured 1.005e-3; bf16x3 1.4e-5) and the error of d_n - d_p (2.2e-3) is past
-    # the band's floor -- the case the measured band exists for.  Bars: 1.5e-3 here for fp16 (reported, and documented in
-    # DESIGN.md: with trained weights the 1e-3 bound holds with margin only on the f32-class paths).
-    gap_err, sel = run_case(m, x.cuda(), precision, ref, d_p, d_n, ref_loss, ref_sel, "trained",
-                            emb_bar=1.5e-3 if precision == "f16" else 5e-5)
+    bar = {"f16": CONTRACT, "f16raw": 1.5e-3}.get(precision, 5e-5)
+    gap_err, sel = run_case(m, x.cuda(), precision, ref, d_p, d_n, ref_loss, ref_sel, "trained", emb_bar=bar)
     if precision == "f16":
+        g = m.f16_guard
+        sgd = "sgd" in request.node.callspec.id
+        assert g.checks == 1 and g.sample_error is not None
+        # what the guard measured on 32 rows is of the size of the raw path's true error over all rows (printed by the
+        # "f16raw" case); its estimate put the SGD network above the threshold and the Adagrad one far below
+        assert (g.verdict == "bf16x3" and g.estimate > g.threshold) if sgd else (g.verdict == "f16" and g.estimate < 0.2 * g.threshold)
+    if precision == "f16raw":
         from deepspeaker_pytorch_amd.mining import REFINE_BAND, refine_policy, select_triplets
         # several more calls: the policy's band settles at what this network's fp16 error needs, and stays sufficient
         xd = x.cuda()

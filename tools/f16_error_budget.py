@@ -134,7 +134,7 @@ def main():
     torch.set_num_threads(os.cpu_count() or 8)
     cache = args.cache.format(opt=args.opt)
     if os.path.exists(cache):
-        sd, corpus = torch.load(cache)
+        sd, corpus = torch.load(cache, weights_only=False)
     else:
         sd, corpus = train(args.opt, args.steps, args.lr)
         torch.save((sd, corpus), cache)
