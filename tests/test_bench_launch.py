@@ -39,3 +39,39 @@ def test_launcher_world_size_mismatch_names_both():
     out = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--launch-selftest"], capture_output=True, text=True,
                          env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and "--gpus 4" in out.stderr
+
+
+def _run_emulated(*flags, nproc=2, timeout=900):
+    """`torch.distributed.run --nproc-per-node N tests/emul_bench.py ...`: bench.py's main() as the driver launches it,
+    kernels on the host emulator, gloo (tests/emul_bench.py)."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "emul_bench.py"), "--gpus", str(nproc), *flags]
+    from emul_util import emul_lib
+    emul_lib()                                            # build the emulated library once, before the ranks race for it
+    out = subprocess.run(cmd, capture_output=True, text=True, env=_env(DS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1"),
+                         timeout=timeout)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]            # rank 0 only
+    return json.loads(lines[0])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("tprec", ["bf16x3"])      # (the fp16 step under data parallelism: tests/test_distributed_gloo.py)
+def test_train_bench_two_ranks_end_to_end_on_the_emulator(tprec):
+    """`bench.py --train --gpus 2` end to end -- rendezvous, DeepSpeakerModel.enable_data_parallel, the
+    grouped training step with its 30 exchanges per step (12 BatchNorm layers x 2 directions + 5 gradient buckets + the
+    logged loss), barrier + max over ranks, the one line -- with two real ranks (gloo; the eval line's self-launch test
+    above only reaches the rendezvous)."""
+    d = _run_emulated("--train", "--train-precision", tprec, "--steps", "1", "--warmup", "0", "--repeats", "0")
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "utterances/s" and d["dtype"] == tprec and d["value"] > 0
+    assert d["all_reduce_per_step"] == 2 * 12 + 5 + 1
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["grad_comm"] == "shared"
+    assert d["config"]["grad_reduce"] == "allreduce"

@@ -151,16 +151,19 @@ def test_forced_data_parallel_sequence_with_one_rank(tmp_path, mine):
     _check_against_single_process(tmp_path, 1, mine, 2)
 
 
-@pytest.mark.parametrize("grad_comm,grad_reduce", [("separate", "allreduce"), ("shared", "rs_ag"), ("separate", "rs_ag")])
-def test_gradient_exchange_variants_are_the_same_step(tmp_path, grad_comm, grad_reduce):
+@pytest.mark.parametrize("grad_comm,grad_reduce,mine", [("separate", "allreduce", False), ("shared", "rs_ag", False),
+                                                        ("separate", "rs_ag", False), ("separate", "rs_ag", True)])
+def test_gradient_exchange_variants_are_the_same_step(tmp_path, grad_comm, grad_reduce, mine):
     """Reducer(grad_comm=..., grad_reduce=...): the buckets on their own communicator (reduced from inside the backward
     pass) or on the shared one (after it), as one all-reduce or as reduce-scatter + all-gather (bucket sizes here are
     not multiples of the world size: the padded staging path) -- every combination is the single-process step, with
     the same number of exchanges."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), False, str(tmp_path), 2, False, grad_comm, grad_reduce), nprocs=world,
+    # (mine=True: the overlapped bucket exchange on its own communicator next to the embedding all-gather and its
+    # reduce-scatter adjoint on the default one -- the combination that has never run on more than one real GPU)
+    mp.spawn(_worker, args=(world, _free_port(), mine, str(tmp_path), 2, False, grad_comm, grad_reduce), nprocs=world,
              join=True)
-    _check_against_single_process(tmp_path, world, False, 2)
+    _check_against_single_process(tmp_path, world, mine, 2)
 
 
 def test_reducer_rejects_unknown_modes_and_defaults_to_the_safe_ones(tmp_path):
