@@ -16,6 +16,8 @@ DS_EPI_OUT_PLANES16, DS_CONV_IN_PLANES16 = 256, 512
 DS_CONV_HINT_SINGLE_BUFFER = 64
 DS_CONV_HINT_CHUNK16 = 128
 DS_CONV_HINT_NO_PERSIST = 1024
+DS_CONV_HINT_NO_WIDE = 2048
+DS_CONV_HINT_ONE_QUEUE = 4096
 DS_CONV_CK = 8
 DS_TAIL_SMALL_MAX_B = 4
 

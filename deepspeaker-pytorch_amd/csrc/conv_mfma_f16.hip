@@ -307,6 +307,28 @@ static bool plan_persistent(PlanH &pl, const ds_conv_shape *s) {
     return true;
 }
 
+// cfg 7 exists in the persistent kernel only: the 128x128 two-wave plan (cfg 4) of a 3x3 layer with 32-channel chunks
+// and Cout % 256 == 0 widened to 128 x 256 -- each wave a 128 x 128 register tile (NSUB = 4), so that every pixel
+// fragment read from LDS feeds four MFMAs instead of two (tools/mfma_lds_ratio.hip: the MFMA + LDS ceiling of that ratio
+// is 1.58 - 1.65 PFLOP/s against 1.35 - 1.49).  Same M tiling, same staging, same per-pixel accumulation order: results
+// are bit-identical to cfg 4.  `k.tiles` / `pl.grid` are recomputed for the halved number of N tiles.
+constexpr int kCfgWide = 7;
+static bool widen_persistent(PlanH &pl, const ds_conv_shape *s) {
+    if (pl.cfg != 4 || s->KS != 3 || pl.ck != 32 || s->Cout % 256 != 0 || !pl.db) return false;
+    const size_t tile_bytes = (size_t)pl.k.NI * pl.k.seg_bytes;
+    const size_t epi = (size_t)2 * 2 * 32 * (2 * 32 + 4) * 4;           // two waves, two 32 x 68-float buffers each
+    const size_t lds = std::max(tile_bytes * 2, epi) + (size_t)128 * 4 + (size_t)pl.k.NI * 8 + 16;
+    if (lds > kLdsTotal / 2 - 64) return false;
+    pl.cfg = kCfgWide;
+    pl.k.n_ntiles = s->Cout / 256;
+    pl.lds_bytes = lds;
+    pl.grid = pl.n_mtiles * pl.k.n_ntiles;
+    const int resident = 2 * ds_cu_count();
+    pl.k.tiles = pl.grid;
+    if (pl.grid > resident) pl.grid = resident;
+    return true;
+}
+
 }  // namespace
 
 static int pack_f16(const float *w_oihw, void *w_f16, int Cout, int Cin, int KS, int mode, void *stream) {
@@ -400,6 +422,7 @@ extern "C" int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flag
     out8[0] = cf.MT; out8[1] = cf.NTILE; out8[2] = pl.k.RT; out8[3] = pl.k.NI;
     const int tiles = pl.grid;                                   // out8[4]: tiles (= workgroups of the one-tile kernel)
     const bool pers = !(flags & DS_CONV_HINT_NO_PERSIST) && plan_persistent(pl, s);
+    if (pers && !(flags & DS_CONV_HINT_NO_WIDE) && widen_persistent(pl, s)) out8[1] = 256;   // cfg 7: 128 x 256, NSUB = 4
     out8[4] = tiles; out8[5] = (int)pl.lds_bytes; out8[6] = cf.NTHR;
     // out8[7]: 10000 if the persistent kernel takes this plan (large launches; small ones may still be split-K)
     //          + 1000 if double-buffered + 100 for 16-channel chunks + staging items per thread
@@ -505,8 +528,11 @@ static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w
 #endif
     const bool persistent = k.n_splits == 1 && !(flags & DS_CONV_HINT_NO_PERSIST) && plan_persistent(pl, s);
     if (persistent) {
+        if (!(flags & DS_CONV_HINT_NO_WIDE)) widen_persistent(pl, s);
         k.sched = ds_sched_slot(stream);
         DS_REQUIRE(k.sched != nullptr, DS_ERR_UNSUPPORTED);
+        // one tile queue per XCD where the tiles of a queue (t = 8 j + q) then all belong to one n tile
+        k.sched_queues = (pl.grid % 8 == 0 && 8 % k.n_ntiles == 0 && !(flags & DS_CONV_HINT_ONE_QUEUE)) ? 8 : 1;
         k.sched_lds = (int)pl.lds_bytes - 16;       // the plan's LDS size ends with tables the persistent kernel does not use
         if (s->KS == 3) ds_f16_launch_pk3(pl, stream);
         else if (pl.ck == 16) ds_f16_launch_pk5c16(pl, stream);

@@ -60,6 +60,7 @@ struct ConvKH {
     float *partial;
     unsigned partial_elems;
     unsigned *sched;                // persistent kernel: tile-scheduling slot (ds_device.h)
+    int sched_queues;               // ... 8: one tile queue per XCD (workgroup b draws tiles 8 j + b % 8); 1: one queue
     int sched_lds;                  // ... and the byte offset of the LDS word tile indices are passed through
 #ifdef DS_F16_PROBE                 // tools/f16_phase_probe.py builds: s_memtime stamps of the phases of each workgroup
     long long *probe;

@@ -36,17 +36,31 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     constexpr int PSH = ds_f16_record_bytes(CKH);
     constexpr int PPR = PSH / 16;                   // 16-byte pieces per record
     constexpr int NU = KPT * NT;                    // (k-step, tap) units per chunk
-    constexpr int RU = (KS == 3) ? (KPT == 2 ? DS_F16_RING_K3 : 9) : (KPT == 2 ? DS_F16_RING_K5 : 5);
+    // filter ring, in units.  NSUB = 4 (a 128-channel-wide register tile: every pixel fragment read from LDS feeds FOUR
+    // MFMAs instead of two, tools/mfma_lds_ratio.hip) has 16 MFMAs = 512 clocks per unit and four fragments per ring
+    // slot: 3 units ahead cover the L2 latency at half the registers of the 6-deep ring of the 64-wide tiles
+    constexpr int RU = NSUB == 4 ? (KS == 3 ? 3 : 5)
+                                 : (KS == 3) ? (KPT == 2 ? DS_F16_RING_K3 : 9) : (KPT == 2 ? DS_F16_RING_K5 : 5);
     constexpr int NMF = MSUB * NSUB;                // MFMAs per unit
     constexpr int SPU = (NMF + 1) / 2 - NSUB;       // staging slots per unit
     constexpr int UL = (NIT + SPU - 1) / SPU;       // units that issue loads / that issue LDS writes
-    constexpr int TP = NSUB * 32 + 4, LPP = NSUB * 4, PPI = 64 / LPP, NRI = 32 / PPI;
-    // residual rows: those of the first RPRE sub-tiles are requested in the last units of the tile's last chunk, the
-    // others two sub-tiles ahead inside the epilogue (all MSUB * NRI of them held through the stream's tail would cost
+    // The epilogue works on 64 channels at a time whatever NSUB is (ENS = 2 sub-tiles of 32 channels: the turn-around
+    // buffers, the lane -> (pixel, 8 channels) assignment and the register use of a step are those of the 64-wide tiles):
+    // a wave's tile is MSUB x NH steps, step e = (ms, nh) = (e / NH, e % NH), channels n_base + 64 nh ...
+    constexpr int ENS = 2, NH = NSUB / ENS, NE = MSUB * NH;
+    constexpr int TP = ENS * 32 + 4, LPP = ENS * 4, PPI = 64 / LPP, NRI = 32 / PPI;
+    // residual rows: those of the first RPRE steps are requested in the last units of the tile's last chunk, the
+    // others two steps ahead inside the epilogue (all NE * NRI of them held through the stream's tail would cost
     // up to 80 registers)
     constexpr int RPRE = 2;
     constexpr int NRES = RPRE * NRI, ULR = (NRES + SPU - 1) / SPU;
+    // The 64-wide tiles run the filter ring through from a tile's last chunk into the next tile's first (RU - 1 units
+    // of fragments stay live across the epilogue).  With 128-wide tiles those are 32 registers the epilogue does not
+    // have (the compiler spilled them to scratch right behind their loads: an s_waitcnt vmcnt(0) per fragment inside
+    // the stream); the ring is refilled at the top of each tile instead -- a tile of that shape is 2304 MFMAs long.
+    constexpr bool RING_THROUGH = NSUB < 4;
     static_assert(NU % RU == 0, "ring slots must be chunk-invariant");
+    static_assert(NSUB % ENS == 0, "the epilogue walks the tile 64 channels at a time");
     static_assert(SPU >= 1 && NSUB >= 2 && NIT <= 16, "tile too small for the interleaved schedule");
     static_assert(2 * UL <= NU && ULR + 2 <= NU, "not enough units for the staging traffic");
     constexpr unsigned OOB = 0x80000000u;           // stays out of any buffer's range here
@@ -180,14 +194,25 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         ta.lin_valid = rowblock ? (p.Ho - sblk * p.RT < p.RT ? p.Ho - sblk * p.RT : p.RT) * p.Wo : live * pix_per_seg;
     };
 
-    // the first tile of a workgroup is its index; every further one is drawn from the slot's counter, one tile ahead of
-    // its use (t_next is known at the top of tile t_cur: the filter ring runs on into its fragments)
-    int t_cur = (int)blockIdx.x;
-    const int t_static = (int)gridDim.x, t_end = p.tiles;
+    // the first tile of a workgroup is its index; every further one is drawn from a counter, one tile ahead of its use
+    // (t_next is known at the top of tile t_cur: the filter ring runs on into its fragments).
+    // XCD-AWARE QUEUES (p.sched_queues == 8; grids that are a multiple of 8 whose n-tile count divides 8): workgroup b is
+    // dispatched to XCD b % 8 (observed placement; it only decides which L2 the filters are found in) and draws from
+    // queue b % 8, whose tiles are t = 8 j + (b % 8) -- all of ONE n tile (t % n_ntiles is the same for every tile of
+    // the queue), so an XCD's L2 keeps holding the filters of the n tiles its statically assigned first tiles had.  With
+    // ONE queue over all tiles a drawn tile is any n tile: on the 512-output-channel layers (filter banks of 4.7 and
+    // 6.5 MB against a 4 MB L2 per XCD) every XCD then walks the whole bank and the ring's loads miss the L2 --
+    // measured 178 us against 139 us for the one-tile-per-workgroup kernel on the 512-channel 3x3 layer, and a bimodal
+    // 185 / 235 us on the 256 -> 512 5x5 one (tools/f16_layer_ab.py).
+    const int nq = p.sched_queues, q = (int)blockIdx.x % nq;
+    int j_cur = (int)blockIdx.x / nq;
+    const int j_static = (int)gridDim.x / nq, t_end = p.tiles;
+    unsigned *const q_next = p.sched + q;
     int *const sched_word = (int *)(lds + p.sched_lds);
-    if (tid == 0) *sched_word = t_static + (int)ds_atomic_inc(p.sched);
+    if (tid == 0) *sched_word = j_static + (int)ds_atomic_inc(q_next);
     __syncthreads();
-    int t_next = ds_uniform(*sched_word);
+    int t_cur = j_cur * nq + q;
+    int t_next = ds_uniform(*sched_word) * nq + q;
     TileAt ta = {0, 0, 0, 0};
     const char *xb_base = (const char *)p.x;
     unsigned xb_bytes = 0, x_lo = 0;
@@ -204,17 +229,19 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         return p.w + lw + (size_t)(KPT * chunk + (u / NT)) * w_kc_stride + (size_t)(u % NT) * w_tap_stride;
     };
     f16x8 bq[RU][NSUB];
+    if constexpr (RING_THROUGH) {
 #pragma unroll
-    for (int d = 0; d < RU; ++d)
+        for (int d = 0; d < RU; ++d)
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(lane_w, 0, d) + (size_t)ns * 32 * 16);
+            for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(lane_w, 0, d) + (size_t)ns * 32 * 16);
+    }
 
     f32x16 acc[MSUB][NSUB];         // never cleared: the first unit of a tile accumulates into a literal zero
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     while (t_cur < t_end) {
         int t_drawn = 0;                        // the tile after next, drawn now, published before the epilogue's barrier
-        if (tid == 0) t_drawn = t_static + (int)ds_atomic_inc(p.sched);
+        if (tid == 0) t_drawn = (j_static + (int)ds_atomic_inc(q_next)) * nq + q;
         // every filter-fragment address below is tile-invariant; hoisted out of this loop they would be dozens of live
         // 64-bit values (spilled, and reloaded from scratch between the MFMAs): keep them derived where they are used
         DS_OPAQUE_VGPR(lane_w);
@@ -233,6 +260,12 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         size_t lane_wn = ((size_t)(tn.tile_n * NTILE + wn * NSUB * 32 + l31) * 16 + 8 * lhi);
         DS_OPAQUE_VGPR(lane_wn);
 
+        if constexpr (!RING_THROUGH) {          // the ring's first RU units, per tile
+#pragma unroll
+            for (int d = 0; d < RU; ++d)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) bq[d][ns] = *(const f16x8 *)(w_unit(lane_w, 0, d) + (size_t)ns * 32 * 16);
+        }
         // ---- (1) halo of both buffers, the first chunk's pixels -> buffer 0 ----
         ds_lds_barrier();                       // the previous tile's epilogue has finished with the LDS
         for (int i = tid; i < h_pieces; i += NTHR) {
@@ -262,10 +295,11 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         //   even slots: the filter-ring refills (L2 -> registers, RU-1 units ahead), then the staging traffic: loads of
         //               the next chunk's pixels in the first units, their LDS writes in the last ones; in the LAST
         //               chunk the residual rows of the epilogue instead
-        f32x4 resv[MSUB][NRI];
-        auto res_load = [&](int rms, int rk, int col_) {
-            const int m = (wm * MSUB + rms) * 32 + rk * PPI + my_p;
-            return ds_buffer_load_f32x4(rbuf, m < ta.lin_valid ? (unsigned)((ta.lin_base + m) * p.Cout + col_) * 2u : DS_BUFFER_OOB);
+        f32x4 resv[NE][NRI];
+        auto res_load = [&](int re, int rk, int col_) {     // step re = (sub-tile re / NH, channel half re % NH)
+            const int m = (wm * MSUB + re / NH) * 32 + rk * PPI + my_p;
+            return ds_buffer_load_f32x4(rbuf, m < ta.lin_valid ? (unsigned)((ta.lin_base + m) * p.Cout + col_ + 64 * (re % NH)) * 2u
+                                                               : DS_BUFFER_OOB);
         };
         auto run_chunk = [&](auto first_tag, auto last_tag, int chunk, const char *buf, char *obuf) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
@@ -298,7 +332,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                     } else {
                         const int e = q >> 1;
                         if (e < NSUB) {
-                            bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
+                            if (RING_THROUGH || !(LAST && ur >= NU)) bq[rslot][e] = *(const f16x8 *)(rw + (size_t)e * 32 * 16);
                         } else if constexpr (!LAST) {
                             const int s = e - NSUB;
                             if (u < UL) {                           // next chunk's pixels -> registers
@@ -346,50 +380,58 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             for (int it = 0; it < NIT; ++it) st[it] = ds_buffer_load_f32x4(xb, g_rel(it) - n_lo);
         };
         if constexpr (EARLY_PREFETCH) prefetch_next();
-        f32x4 sc[2] = {{1.0f, 1.0f, 1.0f, 1.0f}, {1.0f, 1.0f, 1.0f, 1.0f}};
-        f32x4 sh[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-        if (flags & DS_EPI_AFFINE) {
-            sc[0] = *(const f32x4 *)(p.scale + col);
-            sc[1] = *(const f32x4 *)(p.scale + col + 4);
-            sh[0] = *(const f32x4 *)(p.shift + col);
-            sh[1] = *(const f32x4 *)(p.shift + col + 4);
-        }
-        auto put_tile = [&](int ms) {               // accumulators of sub-tile ms -> this wave's buffer ms & 1
-            float *dst = tb + (ms & 1) * (32 * TP);
+        f32x4 sc[NH][2], sh[NH][2];
 #pragma unroll
-            for (int ns = 0; ns < NSUB; ++ns)
+        for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                sc[nh][hq] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+                sh[nh][hq] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (flags & DS_EPI_AFFINE) {
+                    sc[nh][hq] = *(const f32x4 *)(p.scale + col + 64 * nh + 4 * hq);
+                    sh[nh][hq] = *(const f32x4 *)(p.shift + col + 64 * nh + 4 * hq);
+                }
+            }
+        auto put_tile = [&](int e) {                // accumulators of step e -> this wave's buffer e & 1
+            float *dst = tb + (e & 1) * (32 * TP);
+            const int ms = e / NH, nh = e % NH;
+#pragma unroll
+            for (int ns = 0; ns < ENS; ++ns)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[ms][ns][4 * g + j];
+                    for (int j = 0; j < 4; ++j) v[j] = acc[ms][ENS * nh + ns][4 * g + j];
                     *(f32x4 *)(dst + lpix * TP + ns * 32 + 8 * g + 4 * lhi) = v;
                 }
         };
         // element offset of (pixel, first channel) = pixel * y_mul + y_add: channels-last, or 16-channel planes
         const unsigned y_mul = p.y_plane_stride ? 16u : (unsigned)p.Cout;
-        const unsigned y_add = p.y_plane_stride ? (unsigned)(col >> 4) * p.y_plane_stride + (unsigned)(col & 15) : (unsigned)col;
         auto write_out = [&](auto f32_tag) __attribute__((always_inline)) {
             constexpr bool OUT32 = decltype(f32_tag)::value;
             put_tile(0);
 #pragma unroll
-            for (int ms = 0; ms < MSUB; ++ms) {
-                const int cb = ms & 1;
-                ds_wave_sync();                     // sub-tile ms is in its buffer (LDS runs a wave's operations in order)
+            for (int e = 0; e < NE; ++e) {
+                const int ms = e / NH, nh = e % NH;
+                const int cb = e & 1;
+                const int ecol = col + 64 * nh;
+                const unsigned y_add = p.y_plane_stride ? (unsigned)(ecol >> 4) * p.y_plane_stride + (unsigned)(ecol & 15)
+                                                        : (unsigned)ecol;
+                ds_wave_sync();                     // step e is in its buffer (LDS runs a wave's operations in order)
                 const float *src = tb + cb * (32 * TP);
                 f32x4 tv[NRI][2];
 #pragma unroll
                 for (int k = 0; k < NRI; ++k)
 #pragma unroll
                     for (int hq = 0; hq < 2; ++hq) tv[k][hq] = *(const f32x4 *)(src + (k * PPI + my_p) * TP + my_c + 4 * hq);
-                if (ms + 1 < MSUB) put_tile(ms + 1);    // the next sub-tile's turn-around travels while this one is finished
-                if (ms + RPRE < MSUB) {
+                if (e + 1 < NE) put_tile(e + 1);    // the next step's turn-around travels while this one is finished
+                if (e + RPRE < NE) {
 #pragma unroll
-                    for (int k = 0; k < NRI; ++k) resv[ms + RPRE][k] = res_load(ms + RPRE, k, col);
+                    for (int k = 0; k < NRI; ++k) resv[e + RPRE][k] = res_load(e + RPRE, k, col);
                 }
 #pragma unroll
                 for (int k = 0; k < NRI; ++k) {
-                    const f16x8 r8 = __builtin_bit_cast(f16x8, resv[ms][k]);
+                    const f16x8 r8 = __builtin_bit_cast(f16x8, resv[e][k]);
                     const int m = (wm * MSUB + ms) * 32 + k * PPI + my_p;
                     f32x4 o[2];
 #pragma unroll
@@ -398,7 +440,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                         for (int j2 = 0; j2 < 2; ++j2) {
                             // two channels per packed instruction: fma (BatchNorm affine), add (residual); clip per channel
                             const ds_f32x2 v = {tv[k][hq][2 * j2], tv[k][hq][2 * j2 + 1]};
-                            const ds_f32x2 s2 = {sc[hq][2 * j2], sc[hq][2 * j2 + 1]}, h2 = {sh[hq][2 * j2], sh[hq][2 * j2 + 1]};
+                            const ds_f32x2 s2 = {sc[nh][hq][2 * j2], sc[nh][hq][2 * j2 + 1]},
+                                           h2 = {sh[nh][hq][2 * j2], sh[nh][hq][2 * j2 + 1]};
                             const ds_f16x2 rh = {r8[4 * hq + 2 * j2], r8[4 * hq + 2 * j2 + 1]};
                             ds_f32x2 t = v * s2 + h2;
                             t = t + __builtin_convertvector(rh, ds_f32x2);
@@ -436,8 +479,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     }
     // the last workgroup to leave hands the slot back zeroed (no counter is touched after a workgroup's own `done`)
     if (tid == 0 && ds_atomic_inc(p.sched + DS_SCHED_DONE) == gridDim.x - 1) {
-        p.sched[0] = 0u;
-        p.sched[DS_SCHED_DONE] = 0u;
+        for (int i = 0; i <= DS_SCHED_DONE; ++i) p.sched[i] = 0u;
     }
 }
 
@@ -460,7 +502,13 @@ static void launch_p(const PlanH &pl, void *stream) {
     else if (pl.cfg == 3) launch_nit_p<KS, 5, 2, 2, 1, CK>(pl, stream);     // 320x64, two waves
     else if (pl.cfg == 4) launch_nit_p<KS, 4, 2, 1, 2, CK>(pl, stream);     // 128x128, two waves
     else if (pl.cfg == 5) launch_nit_p<KS, 4, 2, 1, 4, CK>(pl, stream);     // 128x256
-    else launch_nit_p<KS, 5, 2, 4, 1, CK>(pl, stream);                      // 640x64, four waves
+    else if (pl.cfg == 6) launch_nit_p<KS, 5, 2, 4, 1, CK>(pl, stream);     // 640x64, four waves
+    else {
+        // cfg 7 (persistent kernel only; the planner upgrades a cfg-4 plan of a layer with Cout % 256 == 0): 128x256,
+        // two waves, each a 128 x 128 register tile (NSUB = 4: 256 accumulator registers, every LDS fragment read feeds
+        // four MFMAs) -- the 512-channel 3x3 layers on 10x4 maps
+        if constexpr (KS == 3 && CK == 32) launch_nit_p<KS, 4, 4, 1, 2, CK>(pl, stream);
+    }
 }
 
 }  // namespace

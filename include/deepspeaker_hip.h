@@ -68,6 +68,10 @@ extern "C" {
                                     record is one line, of which a chunk would use a quarter)                       */
 #define DS_CONV_HINT_SINGLE_BUFFER 64  /* fp16 convolution: plan with one LDS pixel tile (tuning / test hint)  */
 #define DS_CONV_HINT_CHUNK16      128  /* fp16 5x5 convolution: plan with 16-channel chunks (tuning / test hint)  */
+#define DS_CONV_HINT_NO_WIDE     2048  /* fp16 convolution: keep 64-channel-wide register tiles where the persistent kernel
+                                        * would take 128-wide ones (tuning / test hint: bit-identical)                */
+#define DS_CONV_HINT_ONE_QUEUE   4096  /* fp16 convolution, persistent kernel: one tile queue for the whole grid instead
+                                        * of one per XCD (tuning / test hint: bit-identical)                         */
 #define DS_CONV_HINT_NO_PERSIST  1024  /* fp16 convolution: one tile per workgroup even where the persistent kernel
                                         * applies (tuning / test hint: the two kernels are bit-identical)          */
 

@@ -78,6 +78,8 @@ PERSIST_CASES = [
     (3, 64, 128, 43, 16, 5, 2),              # 5x5 stride 2 row blocks, odd height
     (7, 32, 256, 9, 8, 5, 2),                # 5x5 stride 2, multi-image tiles, two n tiles
     (2, 32, 128, 100, 4, 3, 1),              # a tall narrow map: 32-row blocks
+    (7, 64, 256, 10, 4, 3, 1),               # Cout % 256 == 0 on 10x4 maps: the 128 x 256 plan (cfg 7, NSUB = 4), ragged tile
+    (8, 32, 512, 10, 4, 3, 1),               # ... two n tiles of 256, one chunk
 ]
 
 
@@ -96,6 +98,8 @@ def test_conv_f16_persistent_equals_one_tile_kernel(case, hint):
     lib.call("ds_conv_f16_plan_describe_hinted", ctypes.byref(ConvShape(b, h, w, ci, co, k, s)), hf, out8)
     taken = out8[7] >= 10000
     assert taken, list(out8)
+    wide = co % 256 == 0 and k == 3 and (out8[0], out8[6]) == (128, 128)
+    assert (out8[1] == 256) == wide, list(out8)       # the 128-channel-wide register tile where it applies, only there
     rs = np.random.RandomState(17 + sum(case))
     x = (np.abs(rs.randn(b, ci, h, w)) * 2).astype(np.float16).astype(np.float32)
     wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
@@ -108,6 +112,9 @@ def test_conv_f16_persistent_equals_one_tile_kernel(case, hint):
         ya = run_conv_f16(lib, x, wt, s, flags | hf, *args)
         yb = run_conv_f16(lib, x, wt, s, flags | hf | DS_CONV_HINT_NO_PERSIST, *args)
         assert np.isfinite(ya).all() and np.array_equal(ya, yb), (flags, list(out8))
+        if wide:                                      # ... and the persistent kernel's own 64-wide form
+            from deepspeaker_pytorch_amd._native import DS_CONV_HINT_NO_WIDE
+            assert np.array_equal(ya, run_conv_f16(lib, x, wt, s, flags | hf | DS_CONV_HINT_NO_WIDE, *args))
     ref = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
     assert rel_err(run_conv_f16(lib, x, wt, s, DS_EPI_OUT_F32 | hf), ref) < 2e-6
 
@@ -279,6 +286,29 @@ def test_conv_block_xcd_dealt_tile_order(monkeypatch):
     monkeypatch.setenv("DS_EMUL_CUS", "4")
     test_conv_block_fused_equals_two_convolutions((9, 20, 16, 128), "f16")
     test_conv_block_fused_equals_two_convolutions((17, 9, 32, 64), "planes")
+
+
+@pytest.mark.parametrize("case", [(21, 64, 128, 10, 4, 3, 1), (19, 32, 512, 10, 4, 3, 1), (20, 32, 256, 20, 8, 3, 1),
+                                  (13, 32, 256, 9, 8, 5, 2)])
+def test_conv_f16_persistent_xcd_queues(case, monkeypatch):
+    """One tile queue per XCD (grids that are a multiple of 8 whose n-tile count divides 8: workgroup b walks the tiles
+    8 j + b % 8, all of one n tile): every tile exactly once whatever the draw order -- bitwise the one-queue walk and the
+    one-tile-per-workgroup kernel.  4 emulated CUs = 8 resident two-wave (4 four-wave) workgroups, ragged tile counts."""
+    from deepspeaker_pytorch_amd._native import DS_CONV_HINT_NO_PERSIST, DS_CONV_HINT_ONE_QUEUE
+    monkeypatch.setenv("DS_EMUL_CUS", "4")
+    lib = emul_lib()
+    b, ci, co, h, w, k, s = case
+    rs = np.random.RandomState(23 + sum(case))
+    x = (np.abs(rs.randn(b, ci, h, w)) * 2).astype(np.float16).astype(np.float32)
+    wt = (rs.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float16).astype(np.float32)
+    scale, shift = rs.uniform(0.5, 1.5, co).astype(np.float32), rs.randn(co).astype(np.float32)
+    flags = DS_EPI_AFFINE | DS_EPI_CLIP
+    ya = run_conv_f16(lib, x, wt, s, flags, scale, shift)
+    assert np.isfinite(ya).all()
+    assert np.array_equal(ya, run_conv_f16(lib, x, wt, s, flags | DS_CONV_HINT_ONE_QUEUE, scale, shift))
+    assert np.array_equal(ya, run_conv_f16(lib, x, wt, s, flags | DS_CONV_HINT_NO_PERSIST, scale, shift))
+    ref = O.conv2d(x.astype(np.float64), wt.astype(np.float64), s, k // 2)
+    assert rel_err(run_conv_f16(lib, x, wt, s, DS_EPI_OUT_F32), ref) < 2e-6
 
 
 def test_conv_block_unsupported_geometries():

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_CHUNK16, DS_CONV_HINT_NO_PERSIST, DS_CONV_IN_PLANES16,
+from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_CHUNK16, DS_CONV_HINT_NO_PERSIST, DS_CONV_HINT_NO_WIDE, DS_CONV_HINT_ONE_QUEUE, DS_CONV_IN_PLANES16,
                                              DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_RESIDUAL)
 from deepspeaker_pytorch_amd.model import get_engine
 
@@ -23,7 +23,9 @@ B = 768
 # (H, W, Cin, Cout, KS, stride, residual, plane-major input)
 LAYERS = [(80, 32, 64, 128, 5, 2, False, True), (40, 16, 128, 256, 5, 2, False, False), (20, 8, 256, 256, 3, 1, True, False),
           (20, 8, 256, 512, 5, 2, False, False), (10, 4, 512, 512, 3, 1, True, False)]
-VARIANTS = [("persistent", 0), ("one tile / wg", DS_CONV_HINT_NO_PERSIST), ("persistent, 16-ch chunks", DS_CONV_HINT_CHUNK16),
+VARIANTS = [("persistent", 0), ("persistent, one tile queue", DS_CONV_HINT_ONE_QUEUE),
+            ("persistent, 64-wide register tiles", DS_CONV_HINT_NO_WIDE),
+            ("persistent, 64-wide, one tile queue", DS_CONV_HINT_NO_WIDE | DS_CONV_HINT_ONE_QUEUE), ("one tile / wg", DS_CONV_HINT_NO_PERSIST), ("persistent, 16-ch chunks", DS_CONV_HINT_CHUNK16),
             ("one tile / wg, 16-ch chunks", DS_CONV_HINT_CHUNK16 | DS_CONV_HINT_NO_PERSIST)]
 st = eng._stream(torch.zeros(1, device=dev))
 for (h, w, ci, co, k, s_, res, planes) in LAYERS:
@@ -39,8 +41,14 @@ for (h, w, ci, co, k, s_, res, planes) in LAYERS:
     shp = ConvShape(B, h, w, ci, co, k, s_)
     base = DS_EPI_AFFINE | DS_EPI_CLIP | (DS_EPI_RESIDUAL if res else 0) | (DS_CONV_IN_PLANES16 if planes else 0)
     variants = [v for v in VARIANTS if k == 5 or not (v[1] & DS_CONV_HINT_CHUNK16)]
+    if not (k == 3 and co % 256 == 0):
+        variants = [v for v in variants if not (v[1] & DS_CONV_HINT_NO_WIDE)]       # (the hint changes nothing there)
+    if "--only" in sys.argv and f"{ci}x{co}x{k}" not in sys.argv[sys.argv.index("--only") + 1].split(","):
+        continue
     if planes:
         variants = [v for v in variants if v[1] & DS_CONV_HINT_CHUNK16]        # plane-major input implies 16-channel chunks
+    if k == 5:
+        variants += [(n + ", one tile queue", hnt | DS_CONV_HINT_ONE_QUEUE) for n, hnt in variants if not (hnt & DS_CONV_HINT_NO_PERSIST)]
     outs, times, descs = [], [[] for _ in variants], []
     for name, hint in variants:
         out8 = (ctypes.c_int * 8)()
@@ -67,6 +75,6 @@ for (h, w, ci, co, k, s_, res, planes) in LAYERS:
         t = np.array(times[vi])
         same = torch.equal(outs[vi], outs[0])
         d = descs[vi]
-        print(f"   {name:30s} {np.median(t):8.1f} us [{t.min():7.1f}]  {fl / np.median(t) / 1e6:6.0f} TF   tile {d[0]}x{d[1]} RT {d[2]} NI {d[3]} "
+        print(f"   {name:42s} {np.median(t):8.1f} us [{t.min():7.1f}]  {fl / np.median(t) / 1e6:6.0f} TF   tile {d[0]}x{d[1]} RT {d[2]} NI {d[3]} "
               f"tiles {d[4]} plan {d[7]}   {'bitwise equal' if same else 'DIFFERS'}")
         assert same
