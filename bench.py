@@ -545,6 +545,27 @@ def main():
                         "what": "the same K-step region with consecutive steps alternating over two HIP streams "
                                 "(every step complete inside the bracket); results are the same tensors"}
             extras["pipelined_fn"] = run_pipelined
+
+            def run_window1():
+                # `value` amortises the refinement forward over --refine-window steps, which a caller that READS
+                # every selection (train_triplet.py:262) never gets -- a read closes the window.  The same region with the
+                # library's default window of 1 (every step its own refinement forward), reported next to `value`.
+                pol = refine_policy(model)
+                pol.flush()
+                keep = pol.window
+                pol.window = 1
+                for _ in range(4):
+                    step()
+                runs = [region(step, steps, pol.flush)[0] / steps * 1e3 for _ in range(3)]
+                pol.flush()
+                pol.window = keep
+                return {"window_steps": 1, "ms_per_step": round(float(np.median(runs)), 3),
+                        "value": round(emb_per_step / float(np.median(runs)) * 1e3, 1), "unit": "embeddings/s",
+                        "runs_ms_per_step": [round(v, 3) for v in runs],
+                        "what": "the same K-step region with mining.RefinePolicy.window = 1, the library default: what a loop "
+                                "that reads every step's selection pays"}
+            if precision == "f16" and "refine" not in ablate and max(1, args.refine_window) > 1:
+                extras["window1_fn"] = run_window1
         if precision == args.precision and getattr(model, "f16_guard", None) is not None:
             # the fp16 path's precision guard (precision_guard.py): what it measured on this workload and which kernels
             # the timed forwards therefore ran (an escalation would make this line a bf16x3 line, and say so)
@@ -674,12 +695,16 @@ def main():
             if again:
                 line["repeats_ms_per_step"] = {"median": round(float(np.median(again)), 3), "min": round(min(again), 3),
                                                "max": round(max(again), 3), "n": len(again)}
+            # every K-step region of this run (the contract's first, then the repeats)
+            line["regions_ms_per_step"] = [round(elapsed / args.steps * 1e3, 3)] + [round(v, 3) for v in again]
             print(json.dumps(line))
         if multi:
             dist.destroy_process_group()
         return
 
     elapsed, prof, again, refine, isolated = measure(args.precision, args.steps, args.warmup, args.repeats)
+    if "window1_fn" in extras:
+        extras["refine_window_1"] = extras.pop("window1_fn")()
     if "pipelined_fn" in extras:
         extras["pipelined"] = extras.pop("pipelined_fn")()
 
@@ -695,7 +720,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import varlen_bench
         varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=4096, dev=dev)
-        kt = max(3, args.steps // 4)
+        # the training legs: >= 20 steps per region after >= 10 warm-ups, the median of 3 regions (5 steps after 2
+        # warm-ups could not tell a 20 % regression from box spread)
+        kt, wt_, regions_t = max(20, args.steps), 10, 3
         # The training legs run in FRESH PROCESSES (`bench.py --train ...`): HIP deals streams to its 4 hardware queues
         # round-robin in creation order and two streams on one queue serialise, so inside this process the legs' stream
         # overlap depends on how many streams the eval part happened to create before them (measured, same box, same
@@ -703,18 +730,21 @@ def main():
         def train_leg(tp):
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--train", "--train-precision", tp, "--steps", str(kt),
-                   "--warmup", "2", "--repeats", "0", "--no-cpu-baseline"]
+                   "--warmup", str(wt_), "--repeats", str(regions_t - 1), "--no-cpu-baseline"]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 if r.returncode == 0 and lines:
-                    return float(json.loads(lines[-1])["ms_per_step"]) * 1e-3 * kt, "fresh process"
+                    regs = json.loads(lines[-1])["regions_ms_per_step"]
+                    return float(np.median(regs)) * 1e-3 * kt, "fresh process", regs
                 print(f"[bench] training leg {tp} in a fresh process failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
             except Exception as exc:            # (no subprocess: measure here after all)
                 print(f"[bench] training leg {tp} in a fresh process failed: {exc}", file=sys.stderr)
-            return measure_train(tp, kt, 2)[0], "this process"
-        et, leg_where = train_leg("bf16x3")
-        et16, _ = train_leg("f16")
+            e_, _, again_, _ = measure_train(tp, kt, wt_, regions_t - 1)
+            regs = [e_ / kt * 1e3] + list(again_)
+            return float(np.median(regs)) * 1e-3 * kt, "this process", [round(v, 3) for v in regs]
+        et, leg_where, regs_t = train_leg("bf16x3")
+        et16, _, regs_t16 = train_leg("f16")
     # the arithmetic the timed forwards really ran in: the requested one, unless the fp16 guard escalated
     eff_prec = extras.get("precision_guard", {}).get("verdict", args.precision)
     if rank == 0:
@@ -748,6 +778,8 @@ def main():
                                           "max": round(max(again), 3), "n": len(again)}
         if refine is not None:
             out["refine"] = refine
+        if "refine_window_1" in extras:
+            out["refine_window_1"] = extras["refine_window_1"]
         if "pipelined" in extras:
             out["pipelined"] = extras["pipelined"]
         if isolated is not None:
@@ -766,11 +798,12 @@ def main():
                                  "ms_per_step": round(et / kt * 1e3, 3), "dtype": "bf16x3",
                                  "algorithmic_tflops": round(emb_per_step * kt / et * 3 * FWD_FLOPS_PER_EMB / 1e12, 1),
                                  "frac_of_bf16_peak": round(emb_per_step * kt / et * 3 * FWD_FLOPS_PER_EMB / 1e12 / 2500.0, 4),
-                                 "measured_in": leg_where,
+                                 "measured_in": leg_where, "warmup": wt_, "regions_ms_per_step": regs_t,
                                  "what": "train-mode forward of a/p/n (three BatchNorm statistic sets) + triplet loss + "
                                          "backward + fused Adagrad (train_triplet.py:215-224); ~3x the forward FLOPs"}
             out["train_step_f16"] = {"value": round(emb_per_step * kt / et16, 1), "unit": "utterances/s", "steps": kt,
                                      "ms_per_step": round(et16 / kt * 1e3, 3), "dtype": "f16",
+                                     "warmup": wt_, "regions_ms_per_step": regs_t16,
                                      "algorithmic_tflops": round(emb_per_step * kt / et16 * 3 * FWD_FLOPS_PER_EMB / 1e12, 1),
                                      "frac_of_f16_peak": round(emb_per_step * kt / et16 * 3 * FWD_FLOPS_PER_EMB / 1e12 / 2500.0, 4),
                                      "what": "the same step in the OPT-IN fp16 mode (DeepSpeakerModel(train_precision='f16')): fp16 "

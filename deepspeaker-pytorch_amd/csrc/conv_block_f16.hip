@@ -489,8 +489,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
                     const unsigned vo = m < lin_valid ? (unsigned)(lin_base + m) * y_mul + y_add : DS_BUFFER_OOB;
                     if constexpr (OUT32) {
                         const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
-                        ds_buffer_store_f32x4(ybuf, bo, o[0]);
-                        ds_buffer_store_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
+                        ds_buffer_store_out_f32x4(ybuf, bo, o[0]);
+                        ds_buffer_store_out_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
                     } else {
                         ds_u32x4 hb;
 #pragma unroll
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
 #ifdef DS_ABL_NO_STORE
                         if (hb[0] == 0x12345678u)               // (keeps the values live)
 #endif
-                        ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, hb));
+                        ds_buffer_store_out_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, hb));
                     }
                 }
             }

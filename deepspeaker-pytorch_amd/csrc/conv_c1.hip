@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
                 const f16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {20, 20, 20, 20, 20, 20, 20, 20};
                 const f16x8 hc = __builtin_elementwise_min(__builtin_elementwise_max(h, lo), hi);
                 h = clip ? hc : h;
-                ds_buffer_store_f32x4(ybuf, live ? eoff * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+                ds_buffer_store_out_f32x4(ybuf, live ? eoff * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
                 continue;
             }
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
                 t = t * sc4[j] + sh4[j];
                 v[j] = clip ? fminf(fmaxf(t, 0.0f), 20.0f) : t;       // a select, not a branch (NaN passes when off)
             }
-            ds_buffer_store_f32x4(ybuf, voff, v);
+            ds_buffer_store_out_f32x4(ybuf, voff, v);
         }
         ds_wave_sync();
     }

@@ -494,8 +494,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
             const unsigned vo = voff[ms][k];
             if (out32) {
                 const unsigned b = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
-                ds_buffer_store_f32x4(ybuf, b, o[0]);
-                ds_buffer_store_f32x4(ybuf, b != DS_BUFFER_OOB ? b + 16u : DS_BUFFER_OOB, o[1]);
+                ds_buffer_store_out_f32x4(ybuf, b, o[0]);
+                ds_buffer_store_out_f32x4(ybuf, b != DS_BUFFER_OOB ? b + 16u : DS_BUFFER_OOB, o[1]);
             } else {
                 f16x8 h;
 #pragma unroll
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                     h[j] = (_Float16)o[0][j];
                     h[4 + j] = (_Float16)o[1][j];
                 }
-                ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+                ds_buffer_store_out_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
             }
         }
     }

@@ -451,8 +451,8 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                     const unsigned vo = m < ta.lin_valid ? (unsigned)(ta.lin_base + m) * y_mul + y_add : DS_BUFFER_OOB;
                     if constexpr (OUT32) {
                         const unsigned bo = vo != DS_BUFFER_OOB ? vo * 4u : DS_BUFFER_OOB;
-                        ds_buffer_store_f32x4(ybuf, bo, o[0]);
-                        ds_buffer_store_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
+                        ds_buffer_store_out_f32x4(ybuf, bo, o[0]);
+                        ds_buffer_store_out_f32x4(ybuf, bo != DS_BUFFER_OOB ? bo + 16u : DS_BUFFER_OOB, o[1]);
                     } else {
                         ds_u32x4 hb;
 #pragma unroll
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                             for (int j2 = 0; j2 < 2; ++j2)
                                 hb[2 * hq + j2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
                                                                                    ds_f32x2{o[hq][2 * j2], o[hq][2 * j2 + 1]}, ds_f16x2));
-                        ds_buffer_store_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, hb));
+                        ds_buffer_store_out_f32x4(ybuf, vo != DS_BUFFER_OOB ? vo * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, hb));
                     }
                 }
             }

@@ -103,6 +103,17 @@ __device__ __forceinline__ f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte
 __device__ __forceinline__ void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ds_u32x4, v), b, (int)byte_off, 0, 0);
 }
+// The ACTIVATION stores of the convolution epilogues (a layer's output: written once, read by the next launch).  The
+// cache-policy operand of the store is a build-time knob (tools/f16_ab.py variants: 0 = default write-back, 2 = nt,
+// 17 = sc0 sc1 write-through).  Measured (round 5, same process, profiles/r05_run7_store_policy_ab.txt): no difference --
+// ten forwards back to back take 1753 / 1747 / 1753 us each, which is also the sum of their launches: the ~10 us
+// "gaps" rocprofv3 shows between consecutive convolution launches are the profiler's serialisation, not the stream.
+#ifndef DS_EPI_STORE_AUX
+#define DS_EPI_STORE_AUX 0
+#endif
+__device__ __forceinline__ void ds_buffer_store_out_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ds_u32x4, v), b, (int)byte_off, 0, DS_EPI_STORE_AUX);
+}
 typedef unsigned int ds_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ds_buffer_store_b64(ds_buffer b, unsigned byte_off, ds_u32x2 v) {
     __builtin_amdgcn_raw_buffer_store_b64(v, b, (int)byte_off, 0, 0);

@@ -137,6 +137,7 @@ static inline f32x4 ds_buffer_load_f32x4(ds_buffer b, unsigned byte_off) {
 static inline void ds_buffer_store_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) {
     if ((unsigned long long)byte_off + 16 <= b.bytes) memcpy(b.base + byte_off, &v, 16);
 }
+static inline void ds_buffer_store_out_f32x4(ds_buffer b, unsigned byte_off, f32x4 v) { ds_buffer_store_f32x4(b, byte_off, v); }
 typedef unsigned int ds_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int ds_u32x2 __attribute__((ext_vector_type(2)));
 static inline void ds_buffer_store_b64(ds_buffer b, unsigned byte_off, ds_u32x2 v) {

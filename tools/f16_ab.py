@@ -112,6 +112,17 @@ def main():
                     per[vi].setdefault(label, []).append((e0.elapsed_time(e1) * 1e3, fl))
                 eng.profile = None
                 tot[vi].append(t0.elapsed_time(t1) * 1e3)
+        # whole forwards back to back WITHOUT per-launch events (launch gaps as they are in a real step)
+        b2b = [[] for _ in specs]
+        for r in range(max(4, rounds // 2)):
+            for vi, (eng, pw, fo) in enumerate(zip(engines, packs, folds)):
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                for _ in range(10):
+                    eng.forward_eval_planned(x, pw, fo, precision="f16")
+                t1.record()
+                torch.cuda.synchronize()
+                b2b[vi].append(t0.elapsed_time(t1) * 100.0)
     labels = list(per[0].keys())
     print(f"\nmedian us per launch over {rounds} interleaved rounds (min in brackets), TFLOP/s of the median")
     print("layer".ljust(30) + "".join(n.rjust(30) for n, _, _ in specs))
@@ -127,6 +138,10 @@ def main():
     row = "whole forward (with events)".ljust(30)
     for vi in range(len(specs)):
         row += f"{np.median(tot[vi]):9.1f} [{min(tot[vi]):7.1f}]".rjust(30)
+    print(row)
+    row = "forward, 10 back to back, no events".ljust(30)
+    for vi in range(len(specs)):
+        row += f"{np.median(b2b[vi]):9.1f} [{min(b2b[vi]):7.1f}]".rjust(30)
     print(row)
 
 

@@ -10,8 +10,8 @@ cd $R
 for w in $WHAT; do
   case $w in
     tests) timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest.log ;;
-    newtests) timeout 900 python -m pytest tests/test_gpu_bench_size.py tests/test_gpu_parity.py tests/test_gpu_bench_cli.py -m gpu -x -q -s > $OUT/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -5 $OUT/pytest_new.log ;;
-    r4tests) timeout 1500 python -m pytest tests/test_gpu_offdist.py tests/test_gpu_trajectory.py tests/test_gpu_streams.py tests/test_gpu_bench_size.py tests/test_gpu_bench_cli.py -m gpu -q -s > $OUT/pytest_r4.log 2>&1; echo "pytest(r4) rc=$?"; grep -E "^\[|passed|failed|FAILED|Error|policy after" $OUT/pytest_r4.log | tail -60 ;;
+    newtests) timeout 900 python -m pytest tests/test_gpu_bench_size.py tests/test_gpu_parity.py tests/test_gpu_zz_bench_cli.py -m gpu -x -q -s > $OUT/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -5 $OUT/pytest_new.log ;;
+    r4tests) timeout 1500 python -m pytest tests/test_gpu_offdist.py tests/test_gpu_trajectory.py tests/test_gpu_streams.py tests/test_gpu_bench_size.py tests/test_gpu_zz_bench_cli.py -m gpu -q -s > $OUT/pytest_r4.log 2>&1; echo "pytest(r4) rc=$?"; grep -E "^\[|passed|failed|FAILED|Error|policy after" $OUT/pytest_r4.log | tail -60 ;;
     f16train) timeout 1500 python -m pytest tests/test_gpu_train_f16.py tests/test_gpu_trajectory.py -m gpu -q -s > $OUT/pytest_f16train.log 2>&1; echo "pytest(f16train) rc=$?"; grep -E "^\[|passed|failed|FAILED|Error|loss scale|unmasked|bf16x3:|f16:" $OUT/pytest_f16train.log | tail -40
            for tp in bf16x3 f16; do timeout 600 python bench.py --train --train-precision $tp --no-cpu-baseline > $OUT/train_$tp.json 2> $OUT/train_$tp.err; echo "train $tp rc=$?"; cat $OUT/train_$tp.json; done ;;
     offdist) timeout 900 python -m pytest tests/test_gpu_offdist.py -m gpu -q -s -k "trained or planted" > $OUT/pytest_offdist.log 2>&1; echo "pytest(offdist) rc=$?"; grep -E "^\[trained|passed|failed|FAILED|policy after|training losses|^E " $OUT/pytest_offdist.log | tail -30 ;;
@@ -37,7 +37,7 @@ for w in $WHAT; do
     extras) timeout 300 python tools/mine_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/mine_probe.txt
             timeout 300 python tools/latency_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.txt ;;
     trainab) for i in 1 2; do for f in "" "--no-fuse-bn"; do echo "train_bench --grouped $f"; timeout 300 python tools/train_bench.py --grouped --steps 20 --warmup 5 $f 2>&1 | grep -v amdgpu.ids | tail -1; done; done | tee $OUT/train_ab.txt ;;
-    traintests) timeout 1200 python -m pytest tests/test_gpu_train_parity.py tests/test_gpu_parity.py tests/test_gpu_bench_cli.py -m gpu -x -q -s > $OUT/pytest_train.log 2>&1; echo "pytest(train) rc=$?"; tail -15 $OUT/pytest_train.log ;;
+    traintests) timeout 1200 python -m pytest tests/test_gpu_train_parity.py tests/test_gpu_parity.py tests/test_gpu_zz_bench_cli.py -m gpu -x -q -s > $OUT/pytest_train.log 2>&1; echo "pytest(train) rc=$?"; tail -15 $OUT/pytest_train.log ;;
     fwdstreams) timeout 300 python tools/train_fwd_streams.py 2>&1 | grep -v amdgpu.ids | tee $OUT/train_fwd_streams.txt ;;
     pmc16) timeout 1500 tools/pmc_run.sh $TAG/pmc16 --train --train-precision f16 --repeats 0; python tools/pmc_train_summary.py $OUT/pmc16 > $OUT/pmc_train16_summary.md 2> $OUT/pmc_train16_summary.err; head -70 $OUT/pmc_train16_summary.md ;;
     pmc) timeout 1200 tools/pmc_run.sh $TAG/pmc --no-secondary --repeats 0; python tools/pmc_summary.py $OUT/pmc kernel 52 > $OUT/pmc_summary.md 2> $OUT/pmc_summary.err; head -60 $OUT/pmc_summary.md ;;
