@@ -206,3 +206,40 @@ def test_planted_too_narrow_band_is_detected(gold):
         nxt = select_triplets(e[:256], e[256:512], e[512:], 0.1, model=m, inputs=(x[:256], x[256:512], x[512:]))
     assert nxt.band >= 2.0 * sel.observed_error[0] and not nxt.band_exceeded
     np.testing.assert_array_equal(nxt.indices.cpu().numpy(), g1["cfg1_selected"])
+
+
+def test_guard_rechecks_without_a_host_synchronisation_and_follows_the_weights(gold):
+    """precision_guard.F16Guard on the GPU: (a) the periodic re-check runs on the side stream and is taken in by a later
+    forward (no synchronisation: `rechecks` counts, `checks` does not), embeddings unchanged bit for bit; (b) weights that
+    make fp16 inadequate (every filter scaled so that activations sit at the top of fp16's coarse range is not needed: a
+    threshold below the measured error does it) escalate, and the forward then returns the f32-class path's embeddings;
+    (c) a capture sees the standing verdict and measures nothing."""
+    from deepspeaker_pytorch_amd.model import DeepSpeakerModel
+    sd = O.make_state_dict(seed=0, num_classes=16)
+    x = case_inputs("x15", gold)[:96]
+    m = build(sd, "f16", num_classes=16)
+    g = m.f16_guard
+    g.recheck = 3
+    with torch.no_grad():
+        e0 = m(x).clone()
+        assert g.checks == 1 and g.verdict == "f16" and g.rechecks == 0
+        for _ in range(8):
+            assert torch.equal(m(x), e0)
+        torch.cuda.synchronize()
+        m(x)
+    assert g.checks == 1 and g.rechecks >= 2 and g.source in ("check", "recheck") and g.verdict == "f16"
+    assert abs(g.sample_error - 4.2e-4) < 1.5e-4            # the re-check read the same thing the first check did
+    # (b) a guard that cannot be met: the same weights, threshold below the measured error
+    m2 = DeepSpeakerModel(512, 16, precision="f16", f16_guard=1e-4)
+    m2.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m2 = m2.cuda().eval()
+    m3 = build(sd, "bf16x3", num_classes=16)
+    with torch.no_grad():
+        e2, e3 = m2(x).clone(), m3(x).clone()
+    assert m2.f16_guard.verdict == "bf16x3" and m2.f16_guard.escalations == 1 and torch.equal(e2, e3)
+    # (c) inside a capture nothing is measured
+    m4 = build(sd, "f16", num_classes=16)
+    gr = m4.graphed(x)                                    # warm-up forwards (outside the capture) run the check
+    assert m4.f16_guard.checks == 1
+    n_calls = m4.f16_guard.calls
+    assert torch.equal(gr(x), e0) and m4.f16_guard.calls == n_calls and m4.f16_guard.checks == 1

@@ -578,3 +578,46 @@ def test_training_step_bf16x3(dev, golden):
         # held tight: measured 1e-5 .. 1.4e-3 over all tensors, against the exact-f32 path's 7e-6 .. 9e-4.
         assert abs(dg[0] - ref[0]) <= 5e-3 * abs(ref[0]), name
         assert np.abs(dg - ref).max() <= 1.5e-1 * np.abs(ref).max(), name
+
+
+@pytest.mark.parametrize("case", [(768, 512, 512, 10, 4, 3, 1), (768, 256, 512, 20, 8, 5, 2), (96, 512, 1024, 10, 4, 3, 1)])
+def test_xcd_tile_queues_and_wide_register_tile_are_bitwise_the_one_tile_kernel(case):
+    """Round 5 at the bench size on the real chip: the persistent fp16 convolution with one tile queue per
+    XCD and, for the 512-channel 3x3 layers, the 128-channel-wide register tile (NSUB = 4) -- bit-identical to its own
+    one-queue / 64-wide forms and to the one-tile-per-workgroup kernel, and within 1e-5 of a float64 convolution of the
+    same fp16 operands on a sample of images.  (The third case is the 5x5 stride-2 data gradient of the fp16 training
+    step run as a 3x3 convolution with 4 Cin output channels.)"""
+    import ctypes
+    from deepspeaker_pytorch_amd._native import (ConvShape, DS_CONV_HINT_NO_PERSIST, DS_CONV_HINT_NO_WIDE, DS_CONV_HINT_ONE_QUEUE,
+                                                 DS_EPI_AFFINE, DS_EPI_CLIP)
+    from deepspeaker_pytorch_amd.model import get_engine
+    eng = get_engine()
+    b, ci, co, h, w, k, s_ = case
+    ho, wo = (h - 1) // s_ + 1, (w - 1) // s_ + 1
+    g = torch.Generator(device="cpu").manual_seed(sum(case))
+    x = torch.randn(b, h, w, ci, generator=g).abs().half().cuda()
+    wt = (torch.randn(co, ci, k, k, generator=g) * (1.0 / (ci * k * k) ** 0.5)).cuda()
+    wp = eng._pack_f16(wt, k)
+    sc, sh = (torch.rand(co, generator=g) + 0.5).cuda(), torch.randn(co, generator=g).cuda()
+    shp = ConvShape(b, h, w, ci, co, k, s_)
+    st = eng._stream(x)
+    outs = {}
+    for name, hint in (("default", 0), ("one queue", DS_CONV_HINT_ONE_QUEUE), ("64-wide", DS_CONV_HINT_NO_WIDE),
+                       ("one tile per workgroup", DS_CONV_HINT_NO_PERSIST)):
+        y = torch.full((b, ho, wo, co), float("nan"), dtype=torch.float16, device="cuda")
+        eng.lib.call("ds_conv_fwd_f16", ctypes.byref(shp), eng._p(x), eng._p(wp), eng._p(sc), eng._p(sh), None, eng._p(y),
+                     DS_EPI_AFFINE | DS_EPI_CLIP | hint, st)
+        outs[name] = y
+    torch.cuda.synchronize()
+    for name, y in outs.items():
+        assert bool(torch.isfinite(y.float()).all()), name
+        assert torch.equal(y, outs["default"]), name
+    out8 = (ctypes.c_int * 8)()
+    eng.lib.call("ds_conv_f16_plan_describe", ctypes.byref(shp), out8)
+    # (a two-wave workgroup on a 256-channel n tile is the NSUB = 4 plan; the 5x5 layer's 128 x 256 plan has four waves)
+    assert out8[7] >= 10000 and ((out8[1], out8[6]) == (256, 128)) == (k == 3 and co % 256 == 0), list(out8)
+    nb = 4
+    ref = torch.nn.functional.conv2d(x[:nb].permute(0, 3, 1, 2).double().cpu(), wt.half().double().cpu(), None, s_, k // 2)
+    ref = (ref * sc.double().cpu()[None, :, None, None] + sh.double().cpu()[None, :, None, None]).clamp(0, 20)
+    got = outs["default"][:nb].permute(0, 3, 1, 2).double().cpu()
+    assert float((got - ref).abs().max()) <= 20 * 2.0 ** -11 + 1e-5

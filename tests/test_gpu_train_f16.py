@@ -163,3 +163,31 @@ def test_fp16_training_converges_like_the_f32_class_step():
     d = np.abs(curves["f16"] - curves["bf16x3"]) / np.maximum(curves["bf16x3"], 5e-3)
     assert d[:5].max() < 0.05 and np.median(d) < 0.15          # chaotic beyond the first steps: hinge set changes
     assert curves["f16"][10:].mean() < curves["f16"][:10].mean()
+
+
+def test_overflowing_loss_scale_is_flagged_on_the_device_and_the_step_skipped():
+    """a loss scale that pushes dL/dz past fp16's 65504 (1e9 here) ends the backward pass with the overflow flag
+    set; the optimizer `create_optimizer` built reads that flag ON THE DEVICE and leaves every parameter bit-for-bit alone;
+    `update_loss_scale()` halves the scale.  The default scale leaves the flag clear and the step updates."""
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss
+    from deepspeaker_pytorch_amd.optim import create_optimizer
+    sd = O.make_state_dict(seed=33, num_classes=16)
+    xs = [torch.from_numpy(O.make_input(seed=36 + i, batch=8, frames=160)).cuda() for i in range(3)]
+    for scale, overflow in ((1024.0, False), (1e9, True)):
+        m = build(sd, 16, loss_scale=scale)
+        opt = create_optimizer(m, 0.01, "sgd")
+        assert opt.skip_flag is m.grad_overflow_flag()
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        loss = TripletMarginLoss(0.1).forward(*m.forward_triplet(*xs))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        assert m.grad_overflow == overflow
+        changed = [n for n, p in m.named_parameters() if p.grad is not None and not torch.equal(p.detach(), before[n])]
+        if overflow:
+            assert not changed, changed[:3]
+            assert m.update_loss_scale() and m.loss_scale == 5e8
+        else:
+            assert len(changed) >= 38
+            assert not m.update_loss_scale() and m.loss_scale == 1024.0
