@@ -288,8 +288,7 @@ def test_conv_block_xcd_dealt_tile_order(monkeypatch):
     test_conv_block_fused_equals_two_convolutions((17, 9, 32, 64), "planes")
 
 
-@pytest.mark.parametrize("case", [(21, 64, 128, 10, 4, 3, 1), (19, 32, 512, 10, 4, 3, 1), (20, 32, 256, 20, 8, 3, 1),
-                                  (13, 32, 256, 9, 8, 5, 2)])
+@pytest.mark.parametrize("case", [(19, 32, 512, 10, 4, 3, 1), (13, 32, 256, 9, 8, 5, 2)])
 def test_conv_f16_persistent_xcd_queues(case, monkeypatch):
     """One tile queue per XCD (grids that are a multiple of 8 whose n-tile count divides 8: workgroup b walks the tiles
     8 j + b % 8, all of one n tile): every tile exactly once whatever the draw order -- bitwise the one-queue walk and the
