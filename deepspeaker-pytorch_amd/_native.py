@@ -84,6 +84,7 @@ _SIGNATURES = {
     "ds_conv_f16_plan_describe": (c_int, [POINTER(ConvShape), POINTER(c_int)]),
     "ds_conv_f16_plan_describe_hinted": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
     "ds_conv_f16_set_layout_padding": (None, [c_int]),
+    "ds_conv_f16_set_forced_cfg": (None, [c_int]),
     "ds_conv_f16_plan_lds_layout": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
     "ds_cast_f32_to_f16": (c_int, [_P, _P, c_longlong, _P]),
     "ds_cast_f16_to_f32": (c_int, [_P, _P, c_longlong, _P]),

@@ -156,6 +156,7 @@ static double frag_read_cost(int MT, int NI, int RT, int Wc, int IS, int row_byt
 // than its run-to-run spread (20x8: 126.9 vs 127.2 us; 10x4: 163.9 vs 161.6) -- the fragment reads of those layers are not
 // what their MFMA streams wait for.  Off by default; kept as a tuning hook.
 static bool g_layout_padding = false;
+static int g_forced_cfg = -1;               // tuning hook (tools/f16_cfg_ab.py): plan with this tile configuration only
 static void choose_strides(ConvKH &k, int MT, int PSH) {
     const int row_cap = (k.cols_in + 4) * PSH;
     const int pad_units = g_layout_padding ? 16 : 1;
@@ -220,6 +221,7 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
     for (int c = 0; c < kNumCfgH; ++c) {
         const TileCfgH &cf = kCfgH[c];
         if (s->Cout % cf.NTILE) continue;
+        if (g_forced_cfg >= 0 && c != g_forced_cfg) continue;
         const int wg_per_cu = 256 / cf.NTHR;
         const size_t lds_cap = kLdsTotal / wg_per_cu - 64;
         // (two tiles of 32 channels) > (two tiles of 16 channels: 5x5 stride-2 layers, whose input tile is 4x the
@@ -251,7 +253,10 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
                 else eff *= (double)blocks / (double)(ds_ceil_div_ll(blocks, slots) * slots);
                 if (mode == 1) eff *= 0.97;
                 if (mode == 2) eff *= (s->KS == 3 ? 0.90 : 0.85);
-                static const int pref[kNumCfgH] = {6, 4, 3, 5, 2, 1, 0};
+                // ties: the four-wave 160 x 256 tile ahead of the two-wave 160 x 128 one (round 5, tools/f16_cfg_ab.py, every
+                // configuration forced in turn at the bench size: 135 against 142 us on the 256-channel 3x3 layers; the
+                // other layers' choices were already the fastest)
+                static const int pref[kNumCfgH] = {4, 6, 3, 5, 2, 1, 0};
                 eff += 1e-9 * rt + 1e-6 * pref[c];
                 if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; bdb = db; bck = ck; }
             }
@@ -432,6 +437,9 @@ extern "C" int ds_conv_f16_plan_describe_hinted(const ds_conv_shape *s, int flag
 
 // tuning hook (tools/ab_layout.py): 0 = tile rows / segments of whole records only; 1 (default) = padded strides
 extern "C" void ds_conv_f16_set_layout_padding(int on) { g_layout_padding = on != 0; }
+// tuning hook (tools/f16_cfg_ab.py): cfg in [0, 7) = plan every fp16 convolution with that tile configuration (layers it
+// does not fit return DS_ERR_UNSUPPORTED); anything else = the planner's own choice.  Results do not depend on it.
+extern "C" void ds_conv_f16_set_forced_cfg(int cfg) { g_forced_cfg = (cfg >= 0 && cfg < kNumCfgH) ? cfg : -1; }
 
 // the LDS layout of the pixel tile in that plan: out4 = { records per tile row, bytes per tile row, bytes per segment,
 // 1000 x LDS cycles of a fragment read (1000 = conflict-free) }

@@ -22,8 +22,9 @@
  *           ds_sched_slot).  The first launch on a new device therefore allocates;
  *       (2) the armed event pair of ds_launch_timing_arm: thread-local, consumed by
  *           the calling thread's next MFMA launch (csrc/ds_device.h);
- *       (3) one process-wide tuning toggle, ds_conv_f16_set_layout_padding (off by
- *           default; an A/B hook that changes speed, never results);
+ *       (3) two process-wide tuning hooks, ds_conv_f16_set_layout_padding and
+ *           ds_conv_f16_set_forced_cfg (off by default; A/B hooks that change speed,
+ *           never results);
  *       (4) the cached compute-unit count per device (read once).
  *     Nothing else is kept between calls.
  *   - return value: 0 = DS_OK, negative = argument error (below), positive = the
@@ -223,6 +224,7 @@ int ds_conv_f16_plan_lds_layout(const ds_conv_shape *s, int flags, int *out4);
 /* tuning hook: 1 = pad tile rows / segments by 16-byte units until a fragment read is free of bank conflicts in the
  * planner's model; default 0 (whole records only: measured equal, tools/ab_layout.py) */
 void ds_conv_f16_set_layout_padding(int on);
+void ds_conv_f16_set_forced_cfg(int cfg);   /* tuning hook: plan with tile configuration `cfg` only (-1: the planner's choice) */
 /* One whole BasicBlock in eval mode as ONE kernel (reference model.py:66-82):
  *     y = clip(bn2(conv3x3(clip(bn1(conv3x3(x))))) + x)
  * for the shallow stages (W = 32 with 64 channels, W = 16 with 128: ds_conv_block_f16_supported), where a workgroup
