@@ -256,8 +256,12 @@ static int plan_f16(PlanH &pl, const ds_conv_shape *s, bool allow_db = true, boo
                 // ties: the four-wave 160 x 256 tile ahead of the two-wave 160 x 128 one (round 5, tools/f16_cfg_ab.py, every
                 // configuration forced in turn at the bench size: 135 against 142 us on the 256-channel 3x3 layers; the
                 // other layers' choices were already the fastest)
-                static const int pref[kNumCfgH] = {4, 6, 3, 5, 2, 1, 0};
-                eff += 1e-9 * rt + 1e-6 * pref[c];
+                // (same sweep: on the 128-channel 3x3 layers of the training step the four-wave 320 x 128 tile takes 146 us per
+                // layer, the two-wave 320 x 64 one 157: the wider n tile first, whatever the M tile)
+                // 128-pixel tiles: the two-wave plan first for a 3x3 (widen_persistent turns it into the NSUB = 4 tile where
+                // Cout allows: 137.4 against 138.5 us), the four-wave one for a 5x5 (190 against 270 us)
+                static const int pref3[kNumCfgH] = {3, 6, 5, 1, 4, 2, 0}, pref5[kNumCfgH] = {3, 6, 5, 1, 2, 4, 0};
+                eff += 1e-9 * rt + 1e-6 * (s->KS == 3 ? pref3 : pref5)[c];
                 if (eff > best) { best = eff; bc = c; brt = rt; bni = ni; bdb = db; bck = ck; }
             }
         }

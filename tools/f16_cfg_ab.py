@@ -23,6 +23,10 @@ NAMES = ["160x128 2w", "160x256 4w", "320x128 4w", "320x64 2w", "128x128 2w", "1
 # (H, W, Cin, Cout, KS, stride, residual, plane-major input)
 LAYERS = [(80, 32, 64, 128, 5, 2, False, True), (40, 16, 128, 256, 5, 2, False, False), (20, 8, 256, 256, 3, 1, True, False),
           (20, 8, 256, 512, 5, 2, False, False), (10, 4, 512, 512, 3, 1, True, False)]
+if "--train-shapes" in sys.argv:      # the single-layer launches only the fp16 TRAINING step has: the 3x3 layers of stages 1-2 (their
+    # eval forward is the fused block) and the 5x5 stride-2 data gradients run as 3x3 convolutions with 4 Cin output channels
+    LAYERS = [(80, 32, 64, 64, 3, 1, False, False), (40, 16, 128, 128, 3, 1, False, False), (40, 16, 128, 256, 3, 1, False, False),
+              (20, 8, 256, 512, 3, 1, False, False), (10, 4, 512, 1024, 3, 1, False, False)]
 st = eng._stream(torch.zeros(1, device=dev))
 setcfg = eng.lib.raw("ds_conv_f16_set_forced_cfg")
 for (h, w, ci, co, k, s_, res, planes) in LAYERS:
