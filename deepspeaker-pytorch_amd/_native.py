@@ -71,6 +71,7 @@ _SIGNATURES = {
     "ds_conv_dgrad_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P]),
     "ds_conv_bf16_stats_rows": (c_int, [POINTER(ConvShape), c_int]),
     "ds_conv_bf16_plan_describe": (c_int, [POINTER(ConvShape), c_int, POINTER(c_int)]),
+    "ds_conv_bf16_set_forced_cfg": (None, [c_int]),
     "ds_conv_fwd_bf16": (c_int, [POINTER(ConvShape), _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "ds_pack_conv_weight_f16": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_pack_conv_weights_f16_batch": (c_int, [POINTER(PackJob), c_int, _P]),

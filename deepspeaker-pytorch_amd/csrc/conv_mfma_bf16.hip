@@ -120,6 +120,8 @@ static size_t epi_bytes(const TileCfgB &cf) {
 }
 
 
+static int g_forced_cfg_b = -1;      // tuning hook (tools/bf16_cfg_ab.py): plan with this tile configuration only
+
 // `s` describes the tile grid: input [B,H,W,Cin], KS x KS taps, stride s->stride, output grid Ho x Wo computed
 // with `pad`.  The forward convolution writes that grid densely; the stride-2 data gradient runs four such
 // grids (parity classes) whose outputs interleave in y (out_* arguments).
@@ -146,6 +148,7 @@ static int plan_bf16(PlanB &pl, const ds_conv_shape *s, bool x3, int out_stride 
         const TileCfgB &cf = kCfgB[c];
         if (s->Cout % cf.NTILE) continue;
         if (c >= 3 && !big_tile_ok) continue;
+        if (g_forced_cfg_b >= 0 && c != g_forced_cfg_b) continue;
         const size_t lds_cap = kLdsCapB[c];
         const long long item_cap = c >= 3 ? 32 * cf.NTHR : 16 * cf.NTHR;
         for (int rt = 1; rt <= Ho; ++rt) {
@@ -275,6 +278,9 @@ extern "C" int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3) {
     int rc = plan_bf16(pl, s, x3 != 0);
     return rc == DS_OK ? pl.n_mtiles : rc;
 }
+
+// tuning hook: cfg in [0, 9) = plan every bf16 convolution with that tile configuration; anything else = the planner's choice
+extern "C" void ds_conv_bf16_set_forced_cfg(int cfg) { g_forced_cfg_b = (cfg >= 0 && cfg < kNumCfgB) ? cfg : -1; }
 
 extern "C" int ds_conv_bf16_plan_describe(const ds_conv_shape *s, int x3, int *out8) {
     DS_REQUIRE(out8 != nullptr, DS_ERR_NULL);

@@ -22,8 +22,8 @@
  *           ds_sched_slot).  The first launch on a new device therefore allocates;
  *       (2) the armed event pair of ds_launch_timing_arm: thread-local, consumed by
  *           the calling thread's next MFMA launch (csrc/ds_device.h);
- *       (3) two process-wide tuning hooks, ds_conv_f16_set_layout_padding and
- *           ds_conv_f16_set_forced_cfg (off by default; A/B hooks that change speed,
+ *       (3) process-wide tuning hooks, ds_conv_f16_set_layout_padding and
+ *           ds_conv_{f16,bf16}_set_forced_cfg (off by default; A/B hooks that change speed,
  *           never results);
  *       (4) the cached compute-unit count per device (read once).
  *     Nothing else is kept between calls.
@@ -192,6 +192,7 @@ int ds_conv_bf16_stats_rows(const ds_conv_shape *s, int x3);
 /* tiling the bf16 planner picks: out8 = {M tile, N tile, rows per segment, segments per tile, workgroups,
  * LDS bytes, threads per workgroup, LDS row pitch in pixel records} */
 int ds_conv_bf16_plan_describe(const ds_conv_shape *s, int x3, int *out8);
+void ds_conv_bf16_set_forced_cfg(int cfg);  /* tuning hook, as ds_conv_f16_set_forced_cfg */
 int ds_conv_fwd_bf16(const ds_conv_shape *s, const float *x, const void *w_hi, const void *w_lo,
                      const float *scale, const float *shift, const float *residual, float *y,
                      float *stats_partial, int flags, void *stream);
