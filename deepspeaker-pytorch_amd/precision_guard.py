@@ -55,17 +55,23 @@ class F16Guard:
         self.source = None              # what the standing verdict came from: "check", "recheck", "probes"
         self.checks = self.rechecks = self.escalations = self.deescalations = 0
         self.pending = None             # an asynchronous re-check in flight
+        self._below = 0                 # consecutive measurements below the de-escalation bar while escalated
 
     # ---- decisions --------------------------------------------------------------------------------------------
     def _decide(self, err: float, source: str, factor: Optional[float] = None):
         self.sample_error = float(err)
         self.estimate = float(err) * (self.sample_factor if factor is None else factor)
         if self.verdict == "f16" and self.estimate > self.threshold:
-            self.verdict, self.source = ESCALATED, source
+            self.verdict, self.source, self._below = ESCALATED, source, 0
             self.escalations += 1
-        elif self.verdict == ESCALATED and self.estimate < 0.8 * self.threshold and source != "probes":
-            self.verdict, self.source = "f16", source
-            self.deescalations += 1
+        elif self.verdict == ESCALATED and source != "probes":
+            # back to fp16: at once when a check on NEW weights reads below 0.8 x the threshold; an asynchronous re-check
+            # (same weights: the verdict may have come from the refinement's probes, which see other rows) has to read
+            # below it twice in a row -- no flapping between the two arithmetics every `recheck` forwards
+            self._below = self._below + 1 if self.estimate < 0.8 * self.threshold else 0
+            if self._below >= (1 if source == "check" else 2):
+                self.verdict, self.source, self._below = "f16", source, 0
+                self.deescalations += 1
         elif self.source is None:
             self.source = source
 
