@@ -719,6 +719,13 @@ def main():
         # training steps: their working sets stay in the caching allocator)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import varlen_bench
+        # the models measured so far are done: their launch plans (each pins GBs of activation buffers) and the allocator's
+        # cached blocks go first -- with them in place the variable-length run's own plans (2 GB each, 16 of them) evict and
+        # re-allocate one another through the 12 GiB plan-cache bound, and the same code measured 27 k - 130 k utterances/s
+        # from run to run inside this process while it measures 124 k standalone
+        fence()
+        eng.drop_eval_plans()
+        torch.cuda.empty_cache()
         varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=4096, dev=dev)
         # the training legs: >= 20 steps per region after >= 10 warm-ups, the median of 3 regions (5 steps after 2
         # warm-ups could not tell a 20 % regression from box spread)

@@ -591,6 +591,16 @@ class Engine:
         keep += [pw, folded]
         return {"calls": calls, "keep": keep, "x": x_slot, "e": e_slot, "st": st_slot, "n_out": n_out, "lens": lens_dev}
 
+    def drop_eval_plans(self) -> int:
+        """Forget every cached eval launch plan (each pins its activation buffers, its packed filters and its folded
+        BatchNorm): for a process that is done with the models / shapes it has been running and is about to run others
+        -- the LRU bounds (PLAN_CACHE_ENTRIES / PLAN_CACHE_BYTES) would get there too, one eviction per new plan.
+        Returns the number of bytes of activation buffers released (to torch's caching allocator)."""
+        plans = self.__dict__.get("_eval_plans", {})
+        freed = sum(q.get("bytes", 0) for q in plans.values())
+        plans.clear()
+        return freed
+
     def forward_eval_planned(self, x: torch.Tensor, pw: PackedWeights, folded, precision: str = "f32",
                              lengths: Optional[torch.Tensor] = None, low_latency: bool = False) -> torch.Tensor:
         """forward_eval through a launch plan cached per (shape, weights version, precision, device).
