@@ -26,6 +26,12 @@ void ds_f16_launch_pk5c16(const PlanH &pl, void *stream);
 #ifdef DS_F16_PKERNEL_TU
 namespace {
 
+#ifdef DS_F16_PROBE     // tools/pkernel_phase_probe.py: stamp i of a workgroup's tile number tile_no (tiles 0..3 are recorded)
+#define DS_PK_STAMP(i) do { if (p.probe && threadIdx.x == 0 && tile_no < 4) p.probe[((size_t)blockIdx.x * 4 + tile_no) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DS_PK_STAMP(i) ((void)0)
+#endif
+
 template <int KS, int MSUB, int NSUB, int WM, int WN, int NIT, int CKH, bool LIN>
 __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f16_pkernel(const ConvKH p) {
     constexpr int NTHR = WM * WN * 64;
@@ -239,7 +245,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
     f32x16 acc[MSUB][NSUB];         // never cleared: the first unit of a tile accumulates into a literal zero
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    while (t_cur < t_end) {
+    int tile_no = 0;
+    (void)tile_no;
+    for (; t_cur < t_end; ++tile_no) {
+        DS_PK_STAMP(0);
         int t_drawn = 0;                        // the tile after next, drawn now, published before the epilogue's barrier
         if (tid == 0) t_drawn = (j_static + (int)ds_atomic_inc(q_next)) * nq + q;
         // every filter-fragment address below is tile-invariant; hoisted out of this loop they would be dozens of live
@@ -289,6 +298,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
 #pragma unroll
         for (int it = 0; it < NIT; ++it) *(f32x4 *)(lds + l_off(it)) = st[it];
         ds_lds_barrier();
+        DS_PK_STAMP(1);
 
         // ---- (2) the chunks: NU units of NMF MFMAs each, one side operation after each MFMA ----
         //   odd slots:  the NEXT unit's pixel fragments (LDS -> registers, double-buffered per unit)
@@ -368,8 +378,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
 
         // ---- (3) epilogue (see conv_mfma_f16_kernel.h: transposed accumulators turned around through wave-private LDS
         // buffers, whole pixel rows stored).  At its head the NEXT tile's first input chunk is requested. ----
+        DS_PK_STAMP(2);
         if (tid == 0) *sched_word = t_drawn;
         ds_lds_barrier();                       // every wave is done reading the pixel tile
+        DS_PK_STAMP(3);
         const int t_after = ds_uniform(*sched_word);
         // (16 items in flight through the epilogue do not fit the register file next to it: those kernels request the
         // next chunk at the epilogue's end instead -- it then has the tile-top barrier and the halo zeroing to arrive in)
@@ -469,6 +481,7 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
         if (out32) write_out(std::true_type{});
         else write_out(std::false_type{});
         if constexpr (!EARLY_PREFETCH) prefetch_next();
+        DS_PK_STAMP(4);
         ta = tn;
         xb_base = nb_base;
         xb_bytes = nb_bytes;
