@@ -394,6 +394,10 @@ def test_planned_eval_forward_equals_unplanned(precision):
         e2 = eng.forward_eval_planned(x, pw, folded, precision=precision)
         e3 = eng.forward_eval_planned(x, pw, folded, precision=precision)
         assert torch.equal(e1, e2) and torch.equal(e2, e3)
+    # drop_eval_plans: the cache is emptied (its activation buffers go back to the allocator) and the next call plans afresh
+    assert len(eng._eval_plans) == 2
+    assert eng.drop_eval_plans() > 0 and len(eng._eval_plans) == 0 and eng.drop_eval_plans() == 0
+    assert torch.equal(eng.forward_eval_planned(x, pw, folded, precision=precision), e1) and len(eng._eval_plans) == 1
 
 
 def test_training_step_bf16x3_matches_oracle():

@@ -4,7 +4,7 @@ Trains the fixture of tests/test_gpu_offdist.py (40 SGD steps, lr 0.02, momentum
 16-speaker corpus of std-12 features) with the torch restatement on the host, then evaluates the eval forward with the
 stage convolutions' operands rounded to fp16 -- everywhere, in one layer only, and everywhere but one layer; weights
 only / activations only -- and prints each variant's embedding error (max |d| / max |ref|, the tests' measure).
-Candidate fixes are evaluated the same way (--fix): see FIXES.
+Candidate fixes are evaluated the same way by tools/f16_error_fixes.py.
 
     python tools/f16_error_budget.py [--steps 40] [--opt sgd|adagrad|init] [--cache /tmp/f16_budget.pt]
 """
@@ -23,9 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import deepspeaker_oracle as O           # noqa: E402
 import torch_restatement as TR           # noqa: E402
 
-LAYERS = [f"model.conv{i}" for i in range(2, 5)]
-LAYERS = ["model.conv2", "model.conv3", "model.conv4"]
-ALL = []
+ALL = []          # the eleven stage convolutions, in forward order (conv1 runs split-operand bf16 in every mode)
 for i in range(1, 5):
     if i > 1:
         ALL.append(f"model.conv{i}")
