@@ -659,8 +659,14 @@ def main():
         # back-to-back MFMAs from registers with random operand bits; the nominal peak assumes 2.4 GHz sustained, the
         # chip's power management does not) -- context for `frac`, replayed, not measured in this run
         attainable = {"f16": 1680.0, "bf16x3": 1823.0, "bf16": 1823.0, "f32": 151.0}.get(precision)
-        if attainable:
+        live = mfma_rate.get("bf16" if precision in ("bf16x3", "bf16") else precision)
+        if live:                # measured in this process (measure_mfma_rate), on this box
+            r["mfma_register_only_tflops"] = live["tflops"]
+            r["mfma_register_only_source"] = live["what"]
+            r["frac_of_register_only"] = round((3 if precision == "bf16x3" else 1) * achieved / live["tflops"], 4)
+        elif attainable:        # (the f32 MFMA rate is not probed live: replayed from profiles/r02_mfma_peak.txt)
             r["mfma_register_only_tflops"] = attainable
+            r["mfma_register_only_source"] = "replayed from profiles/r02_mfma_peak.txt"
             r["frac_of_register_only"] = round((3 if precision == "bf16x3" else 1) * achieved / attainable, 4)
         if precision == "bf16x3":
             # "achieved" counts each product once (algorithmic FLOPs); the matrix cores issue three MFMAs per
@@ -668,6 +674,30 @@ def main():
             r["mfma_issue_tflops"] = round(3 * achieved, 1)
             r["mfma_issue_frac"] = round(3 * achieved / peak, 4)
         return r
+
+    mfma_rate = {}
+
+    def measure_mfma_rate(kind):
+        """What the matrix cores of THIS box deliver when they do nothing else (ds_mfma_rate_probe: independent 32x32x16
+        MFMAs back to back from registers on every SIMD, random operand bits): six launches of ~1.5 ms timed with events,
+        the median of the last three (the clock settles over the first).  The nominal peak assumes 2.4 GHz sustained; the
+        chip clocks to its power budget."""
+        import ctypes
+        sink = torch.zeros(1, device=dev)
+        flop = ctypes.c_double(0.0)
+        st_ = eng._stream(sink)
+        ts = []
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.lib.call("ds_mfma_rate_probe", 1 if kind == "bf16" else 0, 10000, eng._p(sink), ctypes.byref(flop), st_)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ts.append(e0.elapsed_time(e1))
+        ms = float(np.median(ts[3:]))
+        mfma_rate[kind] = {"tflops": round(flop.value / ms / 1e9, 1),
+                           "what": f"measured in this run: ds_mfma_rate_probe, {kind} 32x32x16 MFMAs back to back from registers on "
+                                   f"every SIMD, random operand bits, median of 3 launches of {ms:.2f} ms"}
 
     emb_per_step = 3 * BATCH_TRIPLETS * world
     if args.train:
@@ -754,6 +784,12 @@ def main():
         et16, _, regs_t16 = train_leg("f16")
     # the arithmetic the timed forwards really ran in: the requested one, unless the fp16 guard escalated
     eff_prec = extras.get("precision_guard", {}).get("verdict", args.precision)
+    if rank == 0 and dev.type == "cuda" and not args.no_secondary:
+        try:                # (after every timed region: the probe heats the chip)
+            for kind in ("f16", "bf16"):
+                measure_mfma_rate(kind)
+        except Exception as exc:
+            print(f"[bench] ds_mfma_rate_probe failed ({exc}); frac_of_register_only uses the replayed figure", file=sys.stderr)
     if rank == 0:
         value = emb_per_step * args.steps / elapsed
         # the launches of every --profile-every-th forward of the timed region carry timing events

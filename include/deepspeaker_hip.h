@@ -91,6 +91,11 @@ int ds_event_elapsed_ms(void *start, void *stop, float *ms);     /* waits for `s
 int ds_launch_timing_arm(void *start, void *stop);
 int ds_launch_timing_end(void);
 const char *ds_error_string(int code);
+/* measurement only: one launch of independent fp16 (bf16 != 0: bf16) 32x32x16 MFMAs issued back to back from registers on
+ * every SIMD, random operand bits -- the matrix cores' power- / clock-limited rate on THIS chip.  *flop_out receives the
+ * floating-point operations of the launch; the caller times it with its own events (bench.py:
+ * roofline.mfma_register_only_tflops).  Not on any product path. */
+int ds_mfma_rate_probe(int bf16, int iters, float *sink, double *flop_out, void *stream);
 
 /* ---- layout ---------------------------------------------------------------------------------- */
 int ds_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);

@@ -543,3 +543,17 @@ def test_bf16_planner_counts_waves_and_members():
     assert rows(ctypes.byref(ConvShape(768, 10, 4, 512, 512, 3, 1)), 1) > 0
     assert rows(ctypes.byref(ConvShape(768, 80, 32, 64, 64, 3, 1)), 5) < 0      # 768 utterances are not 5 members
     assert rows5(ctypes.byref(ConvShape(768, 80, 32, 64, 128, 3, 1)), 3) < 0    # not a 5x5 stride-2 layer
+
+
+def test_mfma_rate_probe_entry_point():
+    """ds_mfma_rate_probe (measurement only: bench.py's live register-only MFMA rate): runs, touches nothing but its sink,
+    and reports the floating-point operations of its launch."""
+    import ctypes
+    lib = emul_lib()
+    sink = aligned(4, np.float32, fill=7.0)
+    for bf16 in (0, 1):
+        flop = ctypes.c_double(0.0)
+        assert lib.raw("ds_mfma_rate_probe")(bf16, 1, ptr(sink), ctypes.byref(flop), None) == 0
+        assert flop.value > 0 and flop.value % (4 * 4 * 2.0 * 32 * 32 * 16) == 0        # whole workgroups of four waves
+    assert (sink == 7.0).all()
+    assert lib.raw("ds_mfma_rate_probe")(0, 0, ptr(sink), ctypes.byref(flop), None) == -1
