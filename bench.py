@@ -679,7 +679,7 @@ def main():
 
     def measure_mfma_rate(kind):
         """What the matrix cores of THIS box deliver when they do nothing else (ds_mfma_rate_probe: independent 32x32x16
-        MFMAs back to back from registers on every SIMD, random operand bits): six launches of ~1.5 ms timed with events,
+        MFMAs back to back from registers on every SIMD, random operand bits): six launches of ~6.5 ms timed with events,
         the median of the last three (the clock settles over the first).  The nominal peak assumes 2.4 GHz sustained; the
         chip clocks to its power budget."""
         import ctypes
@@ -687,10 +687,10 @@ def main():
         flop = ctypes.c_double(0.0)
         st_ = eng._stream(sink)
         ts = []
-        for _ in range(6):
+        for _ in range(6):      # (launches of ~6.5 ms: shorter ones are still ramping -- 1.3 -> 1.58 PFLOP/s over eight 1.7 ms launches)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            eng.lib.call("ds_mfma_rate_probe", 1 if kind == "bf16" else 0, 10000, eng._p(sink), ctypes.byref(flop), st_)
+            eng.lib.call("ds_mfma_rate_probe", 1 if kind == "bf16" else 0, 40000, eng._p(sink), ctypes.byref(flop), st_)
             e1.record()
             torch.cuda.synchronize(dev)
             ts.append(e0.elapsed_time(e1))
