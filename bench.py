@@ -230,6 +230,9 @@ def main():
                          "launch costs ~5 us of completion-signal handling: all of them, 2 %% of the step).  Keep it coprime with "
                          "--refine-window: the steps a window's flush runs beside must be sampled at their true share "
                          "(every 4th step with a window of 8 sampled them at 40 %% instead of 12 %%: frac 0.375 instead of 0.405)")
+    ap.add_argument("--refine-stream", default="side", choices=["side", "main"],
+                    help="the near-tie refinement's f32-class forward on the side stream (beside the next forward) or on the "
+                         "step's own stream (serialised)")
     ap.add_argument("--refine-slots", type=int, default=0,
                     help="smallest number of near-tie re-embedding slots of the fp16 path (0: the library default, "
                          "mining.REFINE_CAP_MIN); the policy grows them from observed counts either way")
@@ -462,7 +465,8 @@ def main():
                     h_lab = dist.all_gather_into_tensor(lab_glob, labels_loc, async_op=True)
                 # filter (train_triplet.py:251-262) with the near ties of the fp16 forward re-embedded at f32-class
                 # precision; the loss call below re-uses the same distance pass
-                sel = select_triplets(*embs, margin=0.1, model=None if "refine" in ablate else model, inputs=data)
+                sel = select_triplets(*embs, margin=0.1, model=None if "refine" in ablate else model, inputs=data,
+                                      side_stream=args.refine_stream == "side")
                 loss = loss_fn.forward(*embs)
                 if "mine" in ablate:
                     mined = None
