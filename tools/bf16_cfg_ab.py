@@ -21,7 +21,7 @@ dev = torch.device("cuda:0")
 setcfg = eng.lib.raw("ds_conv_bf16_set_forced_cfg")
 NAMES = ["128x64 4w", "160x128 4w", "256x64 4w", "160x128 2w", "160x256 4w", "320x128 4w", "320x64 2w", "128x128 2w", "128x256 4w"]
 rounds = 6
-for B in (256, 768):
+for B in ([int(a) for a in sys.argv[1:]] or [256, 768]):
     for name, H, W, Cin, Cout, KS, s in LAYERS:
         x = torch.randn(B, H, W, Cin, device=dev)
         w = torch.randn(Cout, Cin, KS, KS, device=dev) * 0.05

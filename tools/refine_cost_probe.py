@@ -35,5 +35,9 @@ for rows in (12, 24, 48, 96, 192, 384, 768):
         torch.cuda.synchronize()
         prof, eng.profile = eng.profile, None
         conv = sum(p[2].elapsed_time(p[3]) for p in prof)
+    if rows in (12, 96, 768):
+        for label, fl, a, b, _ in prof:
+            t = a.elapsed_time(b) * 1e3
+            print(f"        {label:34s} {t:8.1f} us  {fl / t / 1e6:6.0f} TF (x3 on the matrix cores)")
     print(f"{rows:4d} rows: {ms * 1e3:8.1f} us per forward = {ms * 1e3 / rows:6.2f} us per row ({len(prof)} convolution launches, {conv * 1e3:.0f} us "
           f"inside them with event pairs); as a share of a 768-row fp16 forward of 1750 us: {ms * 1e3 / 1750:.1%}")
