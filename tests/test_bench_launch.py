@@ -53,7 +53,8 @@ def _run_emulated(*flags, nproc=2, timeout=900):
     from emul_util import emul_lib
     emul_lib()                                            # build the emulated library once, before the ranks race for it
     out = subprocess.run(cmd, capture_output=True, text=True,
-                         env=_env(DS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", DS_EMUL_BENCH_TRIPLETS="1"), timeout=timeout)
+                         env=_env(DS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", DS_EMUL_BENCH_TRIPLETS="1", DS_EMUL_CUS="1"),
+                         timeout=timeout)
     assert out.returncode == 0, out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]            # rank 0 only
