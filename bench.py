@@ -222,9 +222,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--refine-window", type=int, default=8,
-                    help="steps whose near ties share one refinement forward (mining.RefineWindow; 1 = every step its own): "
-                         "the timed region ends with the open window flushed, so all of the refinement is inside it")
+    ap.add_argument("--refine-window", type=int, default=1,
+                    help="steps whose near ties share one refinement forward (mining.RefineWindow).  Default 1, the library's "
+                         "default and what the reference loop gets: it reads every step's selection (train_triplet.py:262-264) "
+                         "and a read closes the window.  Larger windows are reported as the `refine_window_8` secondary")
+    ap.add_argument("--batches", type=int, default=4,
+                    help="resident input batches the steps rotate through (each 768 utterances + labels, seeded): near-tie "
+                         "counts, refinement slot sizing and the precision guard's samples then vary from step to step as "
+                         "they do in a real loop")
     ap.add_argument("--profile-every", type=int, default=3,
                     help="the live roofline times the convolution launches of every N-th step of the timed region (a timed "
                          "launch costs ~5 us of completion-signal handling: all of them, 2 %% of the step).  Keep it coprime with "
@@ -321,16 +326,21 @@ def main():
 
     sd_np = synthetic_state_dict(seed=0, num_classes=1211)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    # anchors | positives | negatives, resident in HBM as one [768,1,160,64] buffer
-    data_all = torch.randn(3 * BATCH_TRIPLETS, 1, FRAMES, 64, generator=g).to(dev)
-    data = list(data_all.split(BATCH_TRIPLETS))
     loss_fn = TripletMarginLoss(0.1)
     eng = get_engine()
-    # synthetic speaker ids (c1 = anchor/positive speaker, c2 = negative speaker), 64 speakers
-    c1 = torch.randint(0, 64, (BATCH_TRIPLETS,), generator=g)
-    c2 = (c1 + 1 + torch.randint(0, 63, (BATCH_TRIPLETS,), generator=g)) % 64
-    c1, c2 = c1.to(dev), c2.to(dev)
-    labels_loc = torch.cat([c1, c1, c2])
+    # --batches resident batches, each anchors | positives | negatives as one [768,1,160,64] buffer in HBM with its
+    # synthetic speaker ids (c1 = anchor/positive speaker, c2 = negative speaker, 64 speakers); step k takes batch
+    # k % --batches.  Batch 0 is the batch of every earlier round's line (same generator, same draw order).
+    n_batches = max(1, args.batches)
+    batches = []
+    for _ in range(n_batches):
+        d_all = torch.randn(3 * BATCH_TRIPLETS, 1, FRAMES, 64, generator=g).to(dev)
+        c1_ = torch.randint(0, 64, (BATCH_TRIPLETS,), generator=g)
+        c2_ = (c1_ + 1 + torch.randint(0, 63, (BATCH_TRIPLETS,), generator=g)) % 64
+        c1_, c2_ = c1_.to(dev), c2_.to(dev)
+        batches.append({"all": d_all, "apn": list(d_all.split(BATCH_TRIPLETS)), "c1": c1_, "c2": c2_,
+                        "labels": torch.cat([c1_, c1_, c2_])})
+    data_all, data = batches[0]["all"], batches[0]["apn"]
     n_slots = max(2, args.streams)              # steps in flight, each with its own gather buffers (2: the `pipelined` secondary)
     # two sets of gather buffers per slot, used alternately: the search over one set (side stream, overlapped with the
     # next forward) is long done when that set is gathered into again two steps later
@@ -440,10 +450,14 @@ def main():
         last_mined = [[None, None] for _ in range(n_slots)]
         parity = [0] * n_slots
         sels = []
+        step_no = [0]
 
         def step(slot=0):
             par = parity[slot]
             parity[slot] ^= 1
+            bt = batches[step_no[0] % n_batches]            # the resident batches in rotation
+            step_no[0] += 1
+            data_all, data, c1, labels_loc = bt["all"], bt["apn"], bt["c1"], bt["labels"]
             emb_glob, lab_glob = emb_globs[slot][par], lab_globs[slot][par]
             if multi and last_mined[slot][par] is not None:
                 last_mined[slot][par].wait()            # the search that read this buffer set two steps ago (done long since)
@@ -550,26 +564,32 @@ def main():
                                 "(every step complete inside the bracket); results are the same tensors"}
             extras["pipelined_fn"] = run_pipelined
 
-            def run_window1():
-                # `value` amortises the refinement forward over --refine-window steps, which a caller that READS
-                # every selection (train_triplet.py:262) never gets -- a read closes the window.  The same region with the
-                # library's default window of 1 (every step its own refinement forward), reported next to `value`.
+            def run_window(win):
+                # `value` is measured at the library's default window of 1: a caller that READS every selection
+                # (train_triplet.py:262-264) closes the window every step and pays one refinement forward per step.  A loop
+                # that defers its reads can share one refinement forward between `win` steps; the same region with that
+                # window, reported next to `value` (never as `value`).
                 pol = refine_policy(model)
                 pol.flush()
                 keep = pol.window
-                pol.window = 1
-                for _ in range(4):
+                pol.window = win
+                for _ in range(2 * win):
                     step()
+                pol.flush()
                 runs = [region(step, steps, pol.flush)[0] / steps * 1e3 for _ in range(3)]
                 pol.flush()
                 pol.window = keep
-                return {"window_steps": 1, "ms_per_step": round(float(np.median(runs)), 3),
+                return {"window_steps": win, "ms_per_step": round(float(np.median(runs)), 3),
                         "value": round(emb_per_step / float(np.median(runs)) * 1e3, 1), "unit": "embeddings/s",
                         "runs_ms_per_step": [round(v, 3) for v in runs],
-                        "what": "the same K-step region with mining.RefinePolicy.window = 1, the library default: what a loop "
+                        "what": f"the same K-step region with mining.RefinePolicy.window = {win}: the near ties of {win} "
+                                "consecutive steps share one f32-class refinement forward (the open window is flushed inside "
+                                "the region)" if win > 1 else
+                                "the same K-step region with mining.RefinePolicy.window = 1, the library default: what a loop "
                                 "that reads every step's selection pays"}
-            if precision == "f16" and "refine" not in ablate and max(1, args.refine_window) > 1:
-                extras["window1_fn"] = run_window1
+            if precision == "f16" and "refine" not in ablate:
+                other = 8 if max(1, args.refine_window) == 1 else 1
+                extras["window_fn"] = (other, run_window)
         if precision == args.precision and getattr(model, "f16_guard", None) is not None:
             # the fp16 path's precision guard (precision_guard.py): what it measured on this workload and which kernels
             # the timed forwards therefore ran (an escalation would make this line a bf16x3 line, and say so)
@@ -589,12 +609,15 @@ def main():
         red = model.enable_data_parallel(force=args.force_collectives, grad_comm=args.grad_comm,
                                          grad_reduce=args.grad_reduce) if multi else None
         opt = create_optimizer(model, 0.1, "adagrad", lr_decay=1e-4)
+        tstep_no = [0]
 
         def step(slot=0):
             # the three forwards of train_triplet.py:215 in lock-step over one batch (same values, three BatchNorm
             # statistic sets); under data parallelism: one statistics all-reduce per BatchNorm layer and direction,
             # gradient buckets all-reduced from inside the backward pass
-            out_a, out_p, out_n = model.forward_triplet(data[0], data[1], data[2])
+            d_ = batches[tstep_no[0] % n_batches]["apn"]
+            tstep_no[0] += 1
+            out_a, out_p, out_n = model.forward_triplet(d_[0], d_[1], d_[2])
             loss = loss_fn.forward(out_a, out_p, out_n)
             if multi:
                 loss = loss / world
@@ -668,6 +691,11 @@ def main():
             r["mfma_register_only_tflops"] = live["tflops"]
             r["mfma_register_only_source"] = live["what"]
             r["frac_of_register_only"] = round((3 if precision == "bf16x3" else 1) * achieved / live["tflops"], 4)
+            real = mfma_rate.get("f16_real") if precision == "f16" else None
+            if real:            # the same loop on the operand values this forward's kernels see
+                r["mfma_register_only_real_operands_tflops"] = real["tflops"]
+                r["mfma_register_only_real_operands_source"] = real["what"]
+                r["frac_of_register_only_real_operands"] = round(achieved / real["tflops"], 4)
         elif attainable:        # (the f32 MFMA rate is not probed live: replayed from profiles/r02_mfma_peak.txt)
             r["mfma_register_only_tflops"] = attainable
             r["mfma_register_only_source"] = "replayed from profiles/r02_mfma_peak.txt"
@@ -703,6 +731,36 @@ def main():
                            "what": f"measured in this run: ds_mfma_rate_probe, {kind} 32x32x16 MFMAs back to back from registers on "
                                    f"every SIMD, random operand bits, median of 3 launches of {ms:.2f} ms"}
 
+    def measure_mfma_rate_real(model):
+        """The same probe with operands taken from THIS forward's tensors: A fragments from the packed fp16 filter bank of the
+        256-channel 3x3 layer, B fragments from the fp16 activation that layer reads (post clipped-ReLU).  Random operand
+        bits are the worst case for the multiplier array's switching power; this is the rate on the values the kernels see."""
+        import ctypes
+        with torch.no_grad():
+            taps = {}
+            pw_, folded_ = model._packed(with_f16=True), model._folded()
+            eng.forward_eval(batches[0]["all"][:64].contiguous(), pw_, folded_, taps=taps, precision="f16")
+        act, bank = taps["stage3.b"], pw_.stages[2].l_conv2_f16
+        zeros = float((act == 0).float().mean())
+        sink = torch.zeros(1, device=dev)
+        flop = ctypes.c_double(0.0)
+        st_ = eng._stream(sink)
+        ts = []
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.lib.call("ds_mfma_rate_probe_data", eng._p(bank), bank.numel(), eng._p(act), act.numel(), 40000, eng._p(sink),
+                         ctypes.byref(flop), st_)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ts.append(e0.elapsed_time(e1))
+        ms = float(np.median(ts[3:]))
+        mfma_rate["f16_real"] = {"tflops": round(flop.value / ms / 1e9, 1),
+                                 "what": "measured in this run: ds_mfma_rate_probe_data, the same back-to-back f16 32x32x16 MFMA "
+                                         "loop with A fragments read from the packed fp16 filter bank of the 256-channel 3x3 layer "
+                                         f"and B fragments from the fp16 activation it reads ({zeros:.0%} zeros), median of 3 "
+                                         f"launches of {ms:.2f} ms"}
+
     emb_per_step = 3 * BATCH_TRIPLETS * world
     if args.train:
         tprec = args.train_precision
@@ -737,8 +795,9 @@ def main():
         return
 
     elapsed, prof, again, refine, isolated = measure(args.precision, args.steps, args.warmup, args.repeats)
-    if "window1_fn" in extras:
-        extras["refine_window_1"] = extras.pop("window1_fn")()
+    if "window_fn" in extras:
+        win_, fn_ = extras.pop("window_fn")
+        extras[f"refine_window_{win_}"] = fn_(win_)
     if "pipelined_fn" in extras:
         extras["pipelined"] = extras.pop("pipelined_fn")()
 
@@ -792,6 +851,8 @@ def main():
         try:                # (after every timed region: the probe heats the chip)
             for kind in ("f16", "bf16"):
                 measure_mfma_rate(kind)
+            if eff_prec == "f16":
+                measure_mfma_rate_real(load_model("f16").eval())
         except Exception as exc:
             print(f"[bench] ds_mfma_rate_probe failed ({exc}); frac_of_register_only uses the replayed figure", file=sys.stderr)
     if rank == 0:
@@ -812,6 +873,8 @@ def main():
                        "batch_triplets": BATCH_TRIPLETS, "utterances_per_step_per_gpu": 3 * BATCH_TRIPLETS,
                        "frames": FRAMES, "parallelism": f"dp{world}",
                        "forward_calls_per_step": 3 if args.split_apn else 1, "steps_in_flight": max(1, args.streams),
+                       "refine_window_steps": max(1, args.refine_window),
+                       "resident_batches": f"{n_batches} seeded batches (inputs + speaker ids) in rotation, step k takes batch k % {n_batches}",
                        "arith": ARITH[eff_prec]},
             "roofline": roofline_of(eff_prec, prof, profiled_steps),
             "whole_forward_tflops": round(value * FWD_FLOPS_PER_EMB / 1e12, 2),
@@ -825,8 +888,9 @@ def main():
                                           "max": round(max(again), 3), "n": len(again)}
         if refine is not None:
             out["refine"] = refine
-        if "refine_window_1" in extras:
-            out["refine_window_1"] = extras["refine_window_1"]
+        for k_ in ("refine_window_1", "refine_window_8"):
+            if k_ in extras:
+                out[k_] = extras[k_]
         if "pipelined" in extras:
             out["pipelined"] = extras["pipelined"]
         if isolated is not None:

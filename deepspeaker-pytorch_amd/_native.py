@@ -43,6 +43,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "ds_version": (c_int, []),
     "ds_mfma_rate_probe": (c_int, [c_int, c_int, _P, _P, _P]),
+    "ds_mfma_rate_probe_data": (c_int, [_P, c_longlong, _P, c_longlong, c_int, _P, _P, _P]),
     "ds_event_create": (c_int, [POINTER(c_void_p)]),
     "ds_event_destroy": (c_int, [_P]),
     "ds_event_elapsed_ms": (c_int, [_P, _P, POINTER(c_float)]),

@@ -59,7 +59,10 @@ __global__ void __launch_bounds__(1024) max_abs_diff_kernel(const float *a, cons
     float md = 0.f, mb = 0.f;
     for (long long i = threadIdx.x; i < n; i += 1024) {
         const float vb = b[i];
-        md = fmaxf(md, fabsf(a[i] - vb));
+        // a non-finite difference (a NaN / inf row of either path) must not vanish in the fold: fmaxf drops NaN, so it is
+        // turned into +inf here -- the guard then reads an infinite error and escalates
+        const float d = fabsf(a[i] - vb);
+        md = (d != d) ? __builtin_inff() : fmaxf(md, d);
         mb = fmaxf(mb, fabsf(vb));
     }
 #pragma unroll

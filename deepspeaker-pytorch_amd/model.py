@@ -566,22 +566,37 @@ class DeepSpeakerModel(nn.Module):
 
     # ---- the loss-scaled fp16 training step's overflow handling (train_precision="f16") ----
     def grad_overflow_flag(self, device=None) -> torch.Tensor:
-        """int32 device tensor [1]: 1 after a backward pass of the fp16 training step whose scaled gradients left fp16's
-        range (inf / NaN in a filter gradient), 0 otherwise; rewritten by every such pass.  The fused optimizers of
-        `optim.create_optimizer(model, ...)` read it ON THE DEVICE and skip the update (no host synchronisation);
-        `loss_scale` itself is static unless the training loop calls `update_loss_scale()`."""
-        dev = device if device is not None else next(self.parameters()).device
-        flag = self.__dict__.get("_overflow_flag")
-        if flag is None or flag.device != torch.device(dev):
-            flag = torch.zeros(1, dtype=torch.int32, device=dev)
-            object.__setattr__(self, "_overflow_flag", flag)
-        return flag
+        """int32 device tensor [1]: raised (set to 1, never cleared) by every backward pass of the fp16 training step whose
+        scaled gradients left fp16's range (inf / NaN in a filter gradient).  Passes only OR into it -- the reference's
+        canonical step is three `model(x)` calls, i.e. three backward passes per `loss.backward()`, and so is gradient
+        accumulation -- and the fused optimizers of `optim.create_optimizer(model, ...)` CONSUME it: they read it on the
+        device, skip the update while it is set (no host synchronisation), then latch it into `grad_overflow` and clear
+        it (`_consume_overflow`).  `loss_scale` itself is static unless the training loop calls `update_loss_scale()`."""
+        dev = torch.device(device if device is not None else next(self.parameters()).device)
+        st = self.__dict__.get("_overflow_state")
+        if st is None or st.device != dev:
+            if dev.type == "cuda" and dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            if st is None or st.device != dev:
+                st = torch.zeros(2, dtype=torch.int32, device=dev)      # [pending, latched by the last optimizer step]
+                object.__setattr__(self, "_overflow_state", st)
+                object.__setattr__(self, "_overflow_flag", st[0:1])
+        return self.__dict__["_overflow_flag"]
+
+    def _consume_overflow(self):
+        """optim._FusedBase.step, after its last launch: latch the pending flag for `grad_overflow` / `update_loss_scale`
+        and clear it for the next step's passes (two 4-byte device operations on the caller's stream)."""
+        st = self.__dict__.get("_overflow_state")
+        if st is not None:
+            st[1:2].copy_(st[0:1])
+            st[0:1].zero_()
 
     @property
     def grad_overflow(self) -> bool:
-        """Did the last fp16 backward pass overflow?  (Reads the flag: a host synchronisation.)"""
-        flag = self.__dict__.get("_overflow_flag")
-        return bool(flag.item()) if flag is not None else False
+        """Did the backward passes of the last optimizer step (or the passes since it) overflow?  (Reads the flags: a
+        host synchronisation.)"""
+        st = self.__dict__.get("_overflow_state")
+        return bool(st.max().item()) if st is not None else False
 
     def update_loss_scale(self, backoff: float = 0.5, growth: float = 2.0, growth_interval: int = 2000,
                           max_scale: float = 65536.0) -> bool:
@@ -709,6 +724,22 @@ class DeepSpeakerModel(nn.Module):
             self.features = get_engine().forward_eval_planned(x, pw, self._folded(), precision=prec,
                                                               low_latency=self.low_latency)
         return self.features
+
+    # new weights / a model coming back from training re-arm the fp16 path's precision check (precision_guard.py)
+    def load_state_dict(self, *args, **kwargs):
+        result = super().load_state_dict(*args, **kwargs)
+        guard = self.__dict__.get("f16_guard")
+        if guard is not None:
+            guard.invalidate()
+        return result
+
+    def train(self, mode: bool = True):
+        was_training = self.training
+        super().train(mode)
+        guard = self.__dict__.get("f16_guard")
+        if guard is not None and was_training and not mode:
+            guard.invalidate()
+        return self
 
     def eval_precision(self, x: torch.Tensor, lengths=None) -> str:
         """The arithmetic the next eval forward of `x` runs in: `self.precision`, except that a model of precision "f16"

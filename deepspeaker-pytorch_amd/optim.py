@@ -19,14 +19,46 @@ from .model import _require_cuda, get_engine
 
 class _FusedBase(torch.optim.Optimizer):
     _engine = None          # tests may inject an Engine bound to the host emulator
-    # Optional int32 device tensor [1]: while it is non-zero a step() leaves parameters and state untouched (decided on the
-    # device, no host round trip) -- the gradient-overflow flag of the loss-scaled fp16 training step
-    # (DeepSpeakerModel.grad_overflow; create_optimizer wires it).  The host-side step counters (Adagrad's decayed lr, Adam's
-    # bias correction) still advance on a skipped step.
-    skip_flag = None
+    # Gradient-overflow flag of the loss-scaled fp16 training step: an int32 device tensor [1]; while it is non-zero a
+    # step() leaves parameters and state untouched (decided on the device, no host round trip), and step() CONSUMES it --
+    # the backward passes only ever raise it (a step may be several passes), the optimizer clears it after its last launch.
+    # Either a tensor assigned to `skip_flag` directly, or -- what create_optimizer wires -- the model itself
+    # (`skip_source`, a weak reference): the flag is then resolved at every step() on the device the parameters are on
+    # NOW (a model moved with .cuda() after the optimizer was built gets a flag there, never a stale or host pointer), and
+    # the model latches the consumed value for `grad_overflow` / `update_loss_scale()`.
+    # The host-side step counters (Adagrad's decayed lr, Adam's bias correction) still advance on a skipped step -- unlike
+    # torch.amp.GradScaler, which does not call optimizer.step() at all: undoing them would need the flag on the host.
+    _skip_tensor = None
+    skip_source = None
 
-    def _skip(self, eng):
-        return eng._p(self.skip_flag) if self.skip_flag is not None else None
+    @property
+    def skip_flag(self):
+        model = self.skip_source() if self.skip_source is not None else None
+        if model is not None:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    return model.grad_overflow_flag(p.device)
+        return self._skip_tensor
+
+    @skip_flag.setter
+    def skip_flag(self, flag):
+        self._skip_tensor, self.skip_source = flag, None
+
+    def _skip(self, eng, params):
+        flag = self.skip_flag
+        if flag is None:
+            return None
+        if flag.device != params[0].device:
+            raise RuntimeError(f"optimizer skip_flag lives on {flag.device}, the parameters on {params[0].device}")
+        return eng._p(flag)
+
+    def _consume_skip(self):
+        """after the last launch of a step(): the flag has been read by every launch; latch + clear it"""
+        model = self.skip_source() if self.skip_source is not None else None
+        if model is not None:
+            model._consume_overflow()
+        elif self._skip_tensor is not None:
+            self._skip_tensor.zero_()
 
     def _eng(self):
         return self._engine if self._engine is not None else get_engine()
@@ -139,8 +171,9 @@ class FusedAdagrad(_FusedBase):
                 step = float(states[0]["step"])
                 clr = group["lr"] / (1 + (step - 1) * group["lr_decay"])
                 eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
-                             self._skip(eng), eng._stream(params[0]))
+                             self._skip(eng, params), eng._stream(params[0]))
                 self._bump_versions(params)
+        self._consume_skip()
         return loss
 
 
@@ -159,8 +192,9 @@ class FusedSGD(_FusedBase):
                 params, states, c = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False,
                                                  with_step=False, params=part)
                 eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
-                             group["weight_decay"], int(fresh), self._skip(eng), eng._stream(params[0]))
+                             group["weight_decay"], int(fresh), self._skip(eng, params), eng._stream(params[0]))
                 self._bump_versions(params)
+        self._consume_skip()
         return loss
 
 
@@ -182,9 +216,10 @@ class FusedAdam(_FusedBase):
                 step = float(states[0]["step"])
                 b1, b2 = group["betas"]
                 eng.lib.call("ds_adam_step_f32", *self._args(eng, c), group["lr"], b1, b2, group["eps"],
-                             group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), self._skip(eng),
+                             group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), self._skip(eng, params),
                              eng._stream(params[0]))
                 self._bump_versions(params)
+        self._consume_skip()
         return loss
 
 
@@ -201,5 +236,6 @@ def create_optimizer(model, new_lr, optimizer="adagrad", lr_decay=1e-4, wd=0.0):
     else:
         raise ValueError(optimizer)
     if getattr(model, "train_precision", None) == "f16" and hasattr(model, "grad_overflow_flag"):
-        opt.skip_flag = model.grad_overflow_flag()
+        import weakref
+        opt.skip_source = weakref.ref(model)
     return opt

@@ -8,10 +8,13 @@ filters and activations alike; exact residuals or error-diffused filter rounding
 can be fixed to buy the margin back: the error is what 11 bits give on that network.  So the path measures itself and
 escalates:
 
-  * the first eval forward on a new generation of weights runs its first `rows` utterances through BOTH the fp16 path
-    and the f32-class path (split-operand bf16, 1e-5 from the reference), reduces max |e16 - e32| / max |e32| on the
-    device (`ds_max_abs_diff_f32`) and reads it back -- one host synchronisation per weight generation (at most every
-    `min_gap` forwards when the weights change every call);
+  * the first eval forward on a new generation of weights runs `rows` utterances TAKEN ACROSS THE BATCH (every
+    B // rows-th row, starting at an offset that moves from check to check) through BOTH the fp16 path and the
+    f32-class path (split-operand bf16, 1e-5 from the reference), reduces max |e16 - e32| / max |e32| on the device
+    (`ds_max_abs_diff_f32`; a non-finite difference reads as an infinite error) and reads it back -- one host
+    synchronisation per weight generation.  The rate limit (`min_gap` forwards between synchronous checks) applies
+    only while the weights change on EVERY forward (an evaluation interleaved with optimizer steps);
+    `load_state_dict` and a train -> eval transition always re-arm the check;
   * estimate of the whole batch's error = `sample_factor` x the sample's (a maximum over 32 x 512 values against one
     over 768 x 512 of the same distribution: 4.4 against 5.1 standard deviations);
   * estimate > `threshold` (0.7e-3: the contract with 30 % to spare) => every eval forward of this model runs the
@@ -56,6 +59,27 @@ class F16Guard:
         self.checks = self.rechecks = self.escalations = self.deescalations = 0
         self.pending = None             # an asynchronous re-check in flight
         self._below = 0                 # consecutive measurements below the de-escalation bar while escalated
+        self._seen = None               # weight generation the previous forward saw
+        self._changed_last = False      # ... and whether THAT forward had seen a change too (weights changing every call)
+        self._samples = 0               # checks of either kind so far: moves the sample's first row
+
+    def invalidate(self):
+        """New weights were loaded (load_state_dict) or the model came back from training: the next eval forward measures,
+        whatever the rate limit says (a warm-up forward followed by a checkpoint load, or a sweep over
+        checkpoints with fewer than `min_gap` forwards each, was never measured)."""
+        self.last_check = -(1 << 30)
+        self._changed_last = False
+
+    def _sample(self, x: torch.Tensor, lengths=None):
+        """`rows` utterances spread over the whole batch (not its head: a batch is anchors | positives | negatives, or
+        sorted by length), the first of them moving with every check."""
+        n = min(self.rows, x.shape[0])
+        stride = max(1, x.shape[0] // n)
+        off = self._samples % stride
+        self._samples += 1
+        xs = x[off::stride][:n]
+        ls = None if lengths is None else lengths[off::stride][:n].contiguous()
+        return xs, ls
 
     # ---- decisions --------------------------------------------------------------------------------------------
     def _decide(self, err: float, source: str, factor: Optional[float] = None):
@@ -97,16 +121,23 @@ class F16Guard:
         error.  One host synchronisation."""
         from .model import get_engine
         eng = get_engine()
-        n = min(self.rows, x.shape[0])
-        xs = x[:n].contiguous().float()
+        xs, ls = self._sample(x, lengths)
+        xs = xs.contiguous().float()
         # the banks of both paths and the folded BatchNorm are built here, on the caller's stream
-        out = self._compare(model, eng, xs, None if lengths is None else lengths[:n], xs)
+        out = self._compare(model, eng, xs, ls, xs)
         d, m = out.tolist()                                   # the synchronisation
         self.key = (model._pack_key, model._fold_key)
         self.last_check = self.calls
         self.checks += 1
-        self._decide(d / m if m > 0 else 0.0, "check")
+        self._decide(self._ratio(d, m), "check")
         return self.sample_error
+
+    @staticmethod
+    def _ratio(d: float, m: float) -> float:
+        # a non-finite pair (NaN / inf rows in either path) is an infinite error: escalate
+        if d != d or m != m or d == float("inf") or m == float("inf"):
+            return float("inf")
+        return d / m if m > 0 else 0.0
 
     def _recheck_async(self, model, x: torch.Tensor):
         """The same comparison without a synchronisation: the sample rows are COPIED on the caller's stream (the caller
@@ -114,8 +145,7 @@ class F16Guard:
         from .mining import _side_stream
         from .model import get_engine
         eng = get_engine()
-        n = min(self.rows, x.shape[0])
-        xs = x[:n].contiguous().float().clone()
+        xs = self._sample(x)[0].float().clone(memory_format=torch.contiguous_format)
         model._packed(with_bf16=True)           # (packed on the caller's stream if they do not exist yet)
         model._packed(with_f16=True)
         model._folded()
@@ -136,7 +166,7 @@ class F16Guard:
         if p is not None and p["event"].query():
             d, m = p["host"].tolist()
             self.pending = None
-            self._decide(d / m if m > 0 else 0.0, "recheck")
+            self._decide(self._ratio(d, m), "recheck")
 
     # ---- the question DeepSpeakerModel.forward asks ----------------------------------------------------------------
     def precision_for(self, model, x: torch.Tensor, lengths=None) -> str:
@@ -147,7 +177,12 @@ class F16Guard:
         model._packed(with_f16=True)            # refreshes the generation keys (cached objects otherwise)
         model._folded()
         key = (model._pack_key, model._fold_key)
-        if self.key is None or (key != self.key and self.calls - self.last_check >= self.min_gap):
+        changed = self._seen is not None and key != self._seen
+        # rate-limited only while the weights change on every forward (this one and the one before it both saw new
+        # weights): a single change -- a checkpoint loaded after a warm-up forward -- is measured at once
+        every_call = changed and self._changed_last
+        self._seen, self._changed_last = key, changed
+        if self.key is None or (key != self.key and (not every_call or self.calls - self.last_check >= self.min_gap)):
             self.calibrate(model, x, lengths)
         elif self.pending is None and self.calls - self.last_check >= self.recheck and lengths is None:
             self._recheck_async(model, x)

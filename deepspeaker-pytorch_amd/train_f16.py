@@ -199,14 +199,14 @@ def backward_train_f16(eng: Engine, bn_weights: Dict[str, torch.Tensor], pw: Pac
     9.9 against 8.9 ms per step: three times the launches, and 256-utterance convolutions fill the persistent grids
     worse than one 768-utterance launch).  `reducer` / `reduce_gradients` (data parallelism): global BatchNorm sums (one
     all-reduce per layer) and the per-stage f32 gradient buckets summed over the ranks, as backward.backward_train does.
-    `overflow_flag` (int32 device tensor [1]): cleared at the start of the pass, set to 1 at its end if any filter / fc
-    gradient is inf or NaN (the static loss scale was too large for this step); never read by the host here."""
+    `overflow_flag` (int32 device tensor [1]): set to 1 at the end of the pass if any filter / fc gradient is inf or NaN
+    (the static loss scale was too large for this step); never cleared and never read by the host here -- a step may be
+    several passes (three `model(x)` calls, gradient accumulation), so the flag is cleared where it is CONSUMED: by the
+    fused optimizer after its update (optim._FusedBase._consume_skip)."""
     from .backward import OVERLAP_FILTER_GRADIENTS, _FilterGradLane, _GradBuckets, _wgrad as _wgrad_f32
     lib = eng.lib
     lane = _FilterGradLane(ge.device, OVERLAP_FILTER_GRADIENTS if overlap_filter_gradients is None else overlap_filter_gradients)
     inv = 1.0 / float(loss_scale)
-    if overflow_flag is not None:
-        overflow_flag.zero_()
     grads: Dict[str, torch.Tensor] = {}
     n_stages = len(pw.stages)
     G = saved.stats["model.bn1"].shape[1]

@@ -96,6 +96,12 @@ const char *ds_error_string(int code);
  * floating-point operations of the launch; the caller times it with its own events (bench.py:
  * roofline.mfma_register_only_tflops).  Not on any product path. */
 int ds_mfma_rate_probe(int bf16, int iters, float *sink, double *flop_out, void *stream);
+/* the same launch with fp16 operands taken from REAL tensors: A fragments (8 consecutive halfs each) from `a_f16` (n_a
+ * halfs, e.g. a packed filter bank), B fragments from `b_f16` (n_b halfs, e.g. an fp16 activation tensor); 16-byte
+ * aligned.  What the matrix cores sustain on the operand values the convolutions see (bench.py:
+ * roofline.mfma_register_only_real_operands_tflops). */
+int ds_mfma_rate_probe_data(const void *a_f16, long long n_a, const void *b_f16, long long n_b, int iters, float *sink,
+                            double *flop_out, void *stream);
 
 /* ---- layout ---------------------------------------------------------------------------------- */
 int ds_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);

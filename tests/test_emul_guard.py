@@ -64,12 +64,30 @@ def test_guard_rechecks_on_new_weights_rate_limited_and_takes_probe_samples(emul
         m.model.conv1.weight.data.mul_(1.0)             # (no version bump through .data: nothing to see)
         m(x)
         assert g.checks == 1
-        with torch.no_grad():
-            m.model.conv1.weight.mul_(1.0)              # a new weight generation ...
+        def bump():
+            with torch.no_grad():
+                m.model.conv1.weight.mul_(1.0)          # a new weight generation
+        bump()
         m(x)
-        assert g.checks == 1                            # ... inside the rate limit: the verdict stands
+        assert g.checks == 2                            # ONE change after a stable generation: measured at once
+        for _ in range(2):                              # the weights change on EVERY forward (evaluation interleaved with
+            bump()                                      # optimizer steps): rate limited, the verdict stands
+            m(x)
+            assert g.checks == 2
+        bump()
         m(x)
-        assert g.checks == 2                            # 3 forwards after the last check: measured again
+        assert g.checks == 3                            # 3 forwards after the last check: measured again
+        bump()
+        m(x)
+        assert g.checks == 3
+        m.load_state_dict(m.state_dict())               # a checkpoint load re-arms the check whatever the rate limit says
+        m(x)
+        assert g.checks == 4
+        m.train()
+        m.eval()                                        # ... and so does coming back from training (with new weights)
+        bump()
+        m(x)
+        assert g.checks == 5
     # the refinement's probes feed the same decision, upwards only
     from deepspeaker_pytorch_amd.mining import refine_policy
     pol = refine_policy(m)

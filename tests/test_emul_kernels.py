@@ -557,3 +557,10 @@ def test_mfma_rate_probe_entry_point():
         assert flop.value > 0 and flop.value % (4 * 4 * 2.0 * 32 * 32 * 16) == 0        # whole workgroups of four waves
     assert (sink == 7.0).all()
     assert lib.raw("ds_mfma_rate_probe")(0, 0, ptr(sink), ctypes.byref(flop), None) == -1
+    # operands from real tensors: reads inside the two arrays only (the emulator faults on a stray address)
+    a = to_aligned(np.random.RandomState(0).randn(64), np.float16)
+    b = to_aligned(np.abs(np.random.RandomState(1).randn(24)), np.float16)
+    flop = ctypes.c_double(0.0)
+    assert lib.raw("ds_mfma_rate_probe_data")(ptr(a), 64, ptr(b), 24, 1, ptr(sink), ctypes.byref(flop), None) == 0
+    assert flop.value > 0 and (sink == 7.0).all()
+    assert lib.raw("ds_mfma_rate_probe_data")(ptr(a), 4, ptr(b), 24, 1, ptr(sink), ctypes.byref(flop), None) == -1

@@ -324,15 +324,17 @@ def test_overflowing_loss_scale_raises_the_flag_and_the_optimizer_skips_the_step
            for n in names}
     pw = eng.pack_weights(tsd, n_stages, with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
     ge = torch.from_numpy(np.random.RandomState(6).randn(2, 512).astype(np.float32) * 1e-2)
-    flag = torch.full((1,), 7, dtype=torch.int32)                      # stale value: the pass must rewrite it
-    for scale, expect in ((1024.0, 0), (1e9, 1)):
+    flag = torch.zeros(1, dtype=torch.int32)
+    # passes only RAISE the flag (a step may be several backward passes -- three `model(x)` calls, gradient
+    # accumulation -- and a clean later pass must not hide an earlier overflow): clean -> 0, overflow -> 1, clean -> still 1
+    for scale, expect in ((1024.0, 0), (1e9, 1), (1024.0, 1)):
         embs, saved = forward_train_group_f16(eng, xs, pw, bns, save=True)
         grads = backward_train_f16(eng, {n: b.weight for n, b in bns.items()}, pw, saved, ge, loss_scale=scale,
                                    overflow_flag=flag)
         assert int(flag) == expect, (scale, int(flag))
         finite = all(bool(torch.isfinite(g).all()) for k, g in grads.items() if "conv" in k or "fc" in k)
-        assert finite == (expect == 0)
-    # the flag is still 1: every fused optimizer leaves parameter and state alone; cleared, they step
+        assert finite == (scale == 1024.0)
+    # the flag is still 1: every fused optimizer leaves parameter and state alone and CONSUMES the flag; cleared, they step
     for cls, kw in ((FusedAdagrad, dict(lr=0.1)), (FusedSGD, dict(lr=0.1, momentum=0.9, dampening=0.9)), (FusedAdam, dict(lr=0.1))):
         p = torch.nn.Parameter(torch.arange(40, dtype=torch.float32).reshape(5, 8).clone())
         p.grad = torch.ones_like(p)
@@ -345,10 +347,29 @@ def test_overflowing_loss_scale_raises_the_flag_and_the_optimizer_skips_the_step
         for v in opt.state[p].values():
             if torch.is_tensor(v) and v.numel() > 1:
                 assert float(v.abs().sum()) == 0.0, cls.__name__
-        flag.zero_()
+        assert int(flag) == 0, cls.__name__             # consumed by the step that honoured it
         opt.step()
         assert not torch.equal(p.detach(), before), cls.__name__
         flag.fill_(1)
+    # what create_optimizer wires: the flag resolved through the MODEL at every step (a weak reference), consumed by the
+    # step and latched for grad_overflow / update_loss_scale
+    from deepspeaker_pytorch_amd import model as M
+    from deepspeaker_pytorch_amd.optim import create_optimizer
+    mdl = M.DeepSpeakerModel(512, 4, n_stages=2, precision="f16", train_precision="f16")
+    opt = create_optimizer(mdl, 0.1, "adagrad")
+    opt._engine = eng
+    for p in mdl.parameters():
+        p.grad = torch.ones_like(p)
+    mflag = mdl.grad_overflow_flag()
+    assert opt.skip_flag.data_ptr() == mflag.data_ptr()
+    before = {n: p.detach().clone() for n, p in mdl.named_parameters()}
+    mflag.fill_(1)
+    opt.step()
+    assert all(torch.equal(p.detach(), before[n]) for n, p in mdl.named_parameters())
+    assert int(mflag) == 0 and mdl.grad_overflow and mdl.update_loss_scale() and mdl.loss_scale == 512.0
+    opt.step()
+    assert not any(torch.equal(p.detach(), before[n]) for n, p in mdl.named_parameters())
+    assert not mdl.grad_overflow and not mdl.update_loss_scale()
     # the detector itself: tail elements, NaN and -inf
     x = to_aligned(np.zeros(4099, np.float32))
     f = aligned(1, np.int32, fill=0)

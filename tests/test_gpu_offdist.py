@@ -63,16 +63,21 @@ def run_case(m, x, precision, ref_emb, ref_dp, ref_dn, ref_loss, ref_sel, tag, e
         raw = select_triplets(a, p, n, 0.1)                                   # the path's own distances, unrefined
         sel = select_triplets(a, p, n, 0.1, model=m, inputs=(x[:nt], x[nt:2 * nt], x[2 * nt:]))
     err = rel_err(e.cpu().numpy(), ref_emb)
+    # ... and the worst ROW's relative L2 error, as tests/test_gpu_bench_size.py asserts (max |d| / max |ref| alone lets a
+    # row whose every element is off by a little pass)
+    ref64 = torch.from_numpy(np.asarray(ref_emb)).double()
+    row = float(((e.cpu().double() - ref64).norm(dim=1) / ref64.norm(dim=1)).max())
     gap_ref = ref_dn - ref_dp - np.float32(0.1)
     gap_raw = raw.d_n.cpu().numpy() - raw.d_p.cpu().numpy() - np.float32(0.1)
     gap_err = float(np.abs(gap_raw - gap_ref).max())
     loss_rel = abs(float(loss) - float(ref_loss)) / max(abs(float(ref_loss)), 1e-6)
     obs = sel.observed_error
-    print(f"\n[{tag} {precision}] emb max|d|/max {err:.3e}; loss rel {loss_rel:.3e}; max |error of d_n - d_p| {gap_err:.3e}; "
+    print(f"\n[{tag} {precision}] emb max|d|/max {err:.3e}, worst row rel-L2 {row:.3e}; loss rel {loss_rel:.3e}; max |error of d_n - d_p| {gap_err:.3e}; "
           f"band used {sel.band:.3e}; near ties {sel.n_near_ties} in {sel.amb_cap} slots; probes saw {obs[0]} over {obs[1]} "
           f"slots; fell back: {sel.refined_all}; reference min |gap| {np.abs(gap_ref).min():.3e}, mean d_n "
           f"{float(ref_dn.mean()):.3f}")
     assert err < (emb_bar or EMB_BAR[precision]), err
+    assert row < (emb_bar or EMB_BAR[precision]), row
     assert loss_rel < CONTRACT
     guard = getattr(m, "f16_guard", None)
     on_f16 = precision in ("f16", "f16raw") and (guard is None or guard.verdict == "f16")      # fp16 kernels produced `e`

@@ -176,7 +176,7 @@ def test_overflowing_loss_scale_is_flagged_on_the_device_and_the_step_skipped():
     for scale, overflow in ((1024.0, False), (1e9, True)):
         m = build(sd, 16, loss_scale=scale)
         opt = create_optimizer(m, 0.01, "sgd")
-        assert opt.skip_flag is m.grad_overflow_flag()
+        assert opt.skip_flag.data_ptr() == m.grad_overflow_flag().data_ptr() and opt.skip_flag.is_cuda
         before = {n: p.detach().clone() for n, p in m.named_parameters()}
         loss = TripletMarginLoss(0.1).forward(*m.forward_triplet(*xs))
         opt.zero_grad(set_to_none=True)
@@ -191,3 +191,47 @@ def test_overflowing_loss_scale_is_flagged_on_the_device_and_the_step_skipped():
         else:
             assert len(changed) >= 38
             assert not m.update_loss_scale() and m.loss_scale == 1024.0
+
+
+def test_overflow_in_an_earlier_backward_pass_of_the_step_still_skips_it():
+    """the reference's canonical step is three `model(x)` calls (train_triplet.py:215), i.e. THREE backward
+    passes per `loss.backward()`.  Autograd runs them in reverse call order; only the pass executed FIRST (the negatives')
+    overflows here -- its member's inputs are scaled up until the scaled gradients leave fp16's range -- and the two clean
+    passes after it must not clear the flag: the optimizer skips the step and nothing becomes NaN.  Then a clean step on
+    the same model updates (the flag was consumed)."""
+    from deepspeaker_pytorch_amd.model import TripletMarginLoss
+    from deepspeaker_pytorch_amd.optim import create_optimizer
+    sd = O.make_state_dict(seed=34, num_classes=16)
+    xs = [torch.from_numpy(O.make_input(seed=46 + i, batch=8, frames=160)).cuda() for i in range(3)]
+    m = build(sd, 16, loss_scale=1024.0)
+    opt = create_optimizer(m, 0.01, "sgd")
+    flag = m.grad_overflow_flag()
+
+    class _Boost(torch.autograd.Function):          # identity forward; backward multiplies dL/de of ONE member by 1e9
+        @staticmethod
+        def forward(ctx, e):
+            return e.view_as(e)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 1e9
+
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    outs = [m(x) for x in xs]                       # three separate forwards: three backward passes
+    outs[2] = _Boost.apply(outs[2])                 # the LAST forward's pass runs first in the backward sweep
+    loss = TripletMarginLoss(0.1).forward(*outs)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    assert int(flag.item()) == 1                    # raised by the first-executed pass, kept by the two clean ones
+    opt.step()
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and m.grad_overflow        # consumed and latched
+    assert all(torch.equal(p.detach(), before[n]) for n, p in m.named_parameters())
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+    loss = TripletMarginLoss(0.1).forward(*[m(x) for x in xs])
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert not m.grad_overflow
+    assert sum(not torch.equal(p.detach(), before[n]) for n, p in m.named_parameters() if p.grad is not None) >= 38

@@ -45,8 +45,11 @@ def test_bench_line_contract_single_gpu():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "workload" in d["config"]
-    # round 4: the refinement window is reported, and the same region with two steps in flight as a secondary
-    assert d["refine"]["window_steps"] == 8 and d["config"]["steps_in_flight"] == 1
+    # round 6: `value` is measured at the library's refinement window of 1 (what a loop that reads every selection gets) over
+    # four resident batches in rotation; the window-8 figure and two steps in flight are secondaries
+    assert d["refine"]["window_steps"] == 1 and d["config"]["steps_in_flight"] == 1
+    assert d["config"]["refine_window_steps"] == 1 and d["config"]["resident_batches"].startswith("4 ")
+    assert d["refine_window_8"]["window_steps"] == 8 and d["refine_window_8"]["ms_per_step"] > 0
     p = d["pipelined"]
     assert p["steps_in_flight"] == 2 and p["ms_per_step"] > 0
     perf_note(p["ms_per_step"] < 1.05 * settled_ms(d), ("two steps in flight vs one", p["ms_per_step"], d["ms_per_step"]))
