@@ -50,6 +50,9 @@ _SIGNATURES = {
     "ds_launch_timing_arm": (c_int, [_P, _P]),
     "ds_launch_timing_end": (c_int, []),
     "ds_error_string": (c_char_p, [c_int]),
+    "ds_sched_workspace_bytes": (ctypes.c_size_t, []),
+    "ds_sched_set_workspace": (c_int, [_P, ctypes.c_size_t]),
+    "ds_sched_free_slots": (c_longlong, []),
     "ds_nchw_to_nhwc_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_nhwc_to_nchw_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_pack_conv_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -179,10 +182,22 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
-class NativeLib:
-    """A loaded copy of the C ABI with argument types declared."""
+DS_ERR_NO_WORKSPACE = -5
+# entry points that launch persistent kernels (tiles drawn from device-side counters in the caller's scheduler workspace)
+_PERSISTENT = ("ds_conv_fwd_f16", "ds_conv_fwd_f16_splitk", "ds_conv_block_f16", "ds_conv_block_f16_masked")
 
-    def __init__(self, path: str):
+
+class NativeLib:
+    """A loaded copy of the C ABI with argument types declared.
+
+    The library owns no device memory: the persistent kernels' tile-scheduling slots live in zeroed buffers this wrapper
+    allocates through torch's allocator (`add_sched_workspace`: one int32 tensor of ds_sched_workspace_bytes() per hand-
+    over, kept alive for the life of the process) -- eagerly when a model is moved to a device
+    (DeepSpeakerModel._apply), and on demand when a persistent launch reports DS_ERR_NO_WORKSPACE."""
+
+    def __init__(self, path: str, host_memory: bool = False):
+        # host_memory: tests only -- the library at `path` is the host emulator (tests/emul), its "device" memory is the host's
+        self.host_memory = host_memory
         if not os.path.exists(path):
             raise DeepSpeakerHipError(
                 f"{path} not found: build it with `make` (hipcc --offload-arch=gfx950); "
@@ -195,6 +210,58 @@ class NativeLib:
             fn.restype = res
             fn.argtypes = args
             setattr(self, "_" + name, fn)
+        self._sched_workspaces = []
+        for name in _PERSISTENT:
+            if name in _SIGNATURES:
+                setattr(self, "_" + name, self._with_workspace(name, getattr(self, "_" + name)))
+
+    def _with_workspace(self, name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc == DS_ERR_NO_WORKSPACE:       # first persistent launch on this device (or every slot taken by graphs)
+                self.add_sched_workspace()
+                rc = fn(*args)
+            return rc
+        call.__name__ = name
+        return call
+
+    def add_sched_workspace(self, device=None):
+        """Hand the tile scheduler one more zeroed buffer on `device` (default: the current device; the host under the
+        test emulator).  Not possible inside a stream capture (an allocation there belongs to the graph's pool and its
+        zeroing would be a graph node): move the model to its device, or run one forward, before capturing."""
+        import torch
+        n = int(self._ds_sched_workspace_bytes())
+        if not self.host_memory:
+            if not torch.cuda.is_available():
+                raise DeepSpeakerHipError("no ROCm device: deepspeaker-pytorch_amd computes only on an MI355X")
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            if torch.cuda.is_current_stream_capturing():
+                raise DeepSpeakerHipError("the persistent kernels' scheduler workspace on " + str(dev) + " is missing or used "
+                                          "up and cannot be allocated inside a stream capture: call "
+                                          "NativeLib.add_sched_workspace() (or run one eager forward) before capturing")
+            with torch.cuda.device(dev):
+                buf = torch.zeros(n // 4, dtype=torch.int32, device=dev)
+                torch.cuda.current_stream(dev).synchronize()        # the zeros must have landed before any launch reads them
+                rc = self._ds_sched_set_workspace(ctypes.c_void_p(buf.data_ptr()), n)
+        else:
+            buf = torch.zeros(n // 4 + 16, dtype=torch.int32)
+            off = (-buf.data_ptr() % 64) // 4
+            buf = buf[off:off + n // 4]
+            rc = self._ds_sched_set_workspace(ctypes.c_void_p(buf.data_ptr()), n)
+        if rc != 0:
+            raise DeepSpeakerHipError(f"ds_sched_set_workspace failed: {rc} ({self.error_string(rc)})")
+        self._sched_workspaces.append(buf)
+
+    def ensure_sched_workspace(self, device, min_free: int = 64):
+        """At least `min_free` unassigned slots on `device` (called when a model is moved there: a capture whose first
+        persistent launch was never warmed up then finds its slots)."""
+        import torch
+        dev = torch.device(device)
+        if dev.type != "cuda" or self.host_memory:
+            return
+        with torch.cuda.device(dev):
+            if int(self._ds_sched_free_slots()) < min_free:
+                self.add_sched_workspace(dev)
 
     def error_string(self, code: int) -> str:
         return self._ds_error_string(code).decode()

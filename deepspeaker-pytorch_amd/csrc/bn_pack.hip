@@ -325,37 +325,32 @@ extern "C" int ds_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H
 //     as before round 4, handed the slot of a kernel still queued on stream A to the 65th launch enqueued on stream B).
 //   * A launch that is being CAPTURED into a graph keeps a slot of its own for good: the node carries the pointer and
 //     can replay on any stream next to anything.
-// Slots are carved from per-device chunks (zeroed when allocated; a kernel leaves its slot zeroed).  Host side is
-// serialised by a mutex.  The emulator build has no HIP runtime: host memory.
+// THE MEMORY IS THE CALLER'S (round 6, SURVEY 8(b): "the library never hipMallocs ... no synchronise"): slots are carved
+// from zeroed device buffers the caller hands over with ds_sched_set_workspace (the Python wrapper: one torch.zeros of
+// ds_sched_workspace_bytes() per device, allocated when a model is moved to the device or on the first launch there);
+// a kernel leaves its slot zeroed.  Without a workspace -- or with every slot of it taken by captured launches -- a
+// persistent launch returns DS_ERR_NO_WORKSPACE and the caller hands over another buffer.  Host side is serialised by a
+// mutex; the only state the library keeps is the table of what has been carved.
 namespace {
 struct SchedPool {
     std::mutex mu;
-    struct Chunk { unsigned *base; size_t used; };
-    std::map<int, std::vector<Chunk>> chunks;                               // device -> chunks
+    struct Chunk { unsigned *base; size_t slots, used; };
+    std::map<int, std::vector<Chunk>> chunks;                               // device -> the caller's buffers
     std::map<std::pair<int, void *>, std::pair<unsigned *, unsigned>> rings;  // (device, stream) -> (ring base, next)
-    static constexpr size_t CHUNK_SLOTS = 1024;                             // 64 KiB per chunk
 
     unsigned *carve(int dev, size_t n_slots) {
-        auto &v = chunks[dev];
-        if (v.empty() || v.back().used + n_slots > CHUNK_SLOTS) {
-            const size_t bytes = CHUNK_SLOTS * DS_SCHED_WORDS * sizeof(unsigned);
-#ifdef DS_EMULATED
-            void *p = calloc(1, bytes);
-            if (!p) return nullptr;
-#else
-            void *p = nullptr;      // (fails inside a stream capture: a capture's first persistent launch must have
-            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }    // been warmed up eagerly)
-            if (hipMemset(p, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipFree(p);
-                return nullptr;
+        for (auto &c : chunks[dev])
+            if (c.used + n_slots <= c.slots) {
+                unsigned *r = c.base + c.used * DS_SCHED_WORDS;
+                c.used += n_slots;
+                return r;
             }
-#endif
-            v.push_back({(unsigned *)p, 0});
-        }
-        unsigned *r = v.back().base + v.back().used * DS_SCHED_WORDS;
-        v.back().used += n_slots;
-        return r;
+        return nullptr;
+    }
+    size_t free_slots(int dev) {
+        size_t n = 0;
+        for (auto &c : chunks[dev]) n += c.slots - c.used;
+        return n;
     }
 };
 SchedPool &sched_pool() { static SchedPool p; return p; }
@@ -364,13 +359,11 @@ SchedPool &sched_pool() { static SchedPool p; return p; }
 unsigned *ds_sched_slot(void *stream) {
     SchedPool &P = sched_pool();
     int dev = 0;
-    bool capturing = false;
-#ifndef DS_EMULATED
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    bool capturing = false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
     else (void)hipGetLastError();
-#endif
     std::lock_guard<std::mutex> lock(P.mu);
     if (capturing) return P.carve(dev, 1);
     auto key = std::make_pair(dev, stream);
@@ -384,37 +377,55 @@ unsigned *ds_sched_slot(void *stream) {
     return it->second.first + (size_t)k * DS_SCHED_WORDS;
 }
 
-extern "C" int ds_version(void) { return 500; }   // 500: round 5; 400: round 4 (fp16 training step, refinement probes, launch-bound timing); 30x: round-3 ABI (300: split grouped BatchNorm backward for data parallelism, grouped f64 sums; 301: + ds_conv_dgrad_bnbwd_bf16, ds_bn_bwd_group_finish_f32)
+// bytes of one scheduler workspace: 1024 slots of 64 bytes (a ring of 8 per stream that launches persistent kernels,
+// one per persistent launch captured into a graph)
+extern "C" size_t ds_sched_workspace_bytes(void) { return (size_t)1024 * DS_SCHED_WORDS * sizeof(unsigned); }
+
+// Hands `bytes` of ZEROED device memory on the CURRENT device to the persistent kernels' tile scheduler.  The buffer
+// must stay allocated for as long as the library may launch (the wrapper keeps the tensor alive for the life of the
+// process); it may be called again to add a buffer when DS_ERR_NO_WORKSPACE says the previous ones are used up.
+extern "C" int ds_sched_set_workspace(void *zeroed_device_memory, size_t bytes) {
+    DS_REQUIRE(zeroed_device_memory != nullptr, DS_ERR_NULL);
+    DS_REQUIRE(DS_ALIGNED16(zeroed_device_memory), DS_ERR_ALIGNMENT);
+    const size_t slots = bytes / (DS_SCHED_WORDS * sizeof(unsigned));
+    DS_REQUIRE(slots >= 2 * DS_SCHED_RING, DS_ERR_BAD_SHAPE);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return DS_ERR_UNSUPPORTED; }
+    SchedPool &P = sched_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.chunks[dev].push_back({(unsigned *)zeroed_device_memory, slots, 0});
+    return DS_OK;
+}
+
+// slots of the current device's workspaces that have not been handed out yet (0: ds_sched_set_workspace is due)
+extern "C" long long ds_sched_free_slots(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    SchedPool &P = sched_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    return (long long)P.free_slots(dev);
+}
+
+extern "C" int ds_version(void) { return 600; }   // 600: round 6 (caller-owned scheduler workspace, ds_mfma_rate_probe_data); 500: round 5; 400: round 4 (fp16 training step, refinement probes, launch-bound timing); 30x: round-3 ABI (300: split grouped BatchNorm backward for data parallelism, grouped f64 sums; 301: + ds_conv_dgrad_bnbwd_bf16, ds_bn_bwd_group_finish_f32)
 
 // ---- launch timing (see DS_LAUNCH_BIG_LDS in ds_device.h) ----
 extern "C" int ds_event_create(void **out_event) {
     DS_REQUIRE(out_event != nullptr, DS_ERR_NULL);
-#ifdef DS_EMULATED
-    return DS_ERR_UNSUPPORTED;
-#else
     hipEvent_t e = nullptr;
     const hipError_t rc = hipEventCreate(&e);
     if (rc != hipSuccess) return (int)rc;
     *out_event = (void *)e;
     return DS_OK;
-#endif
 }
 
 extern "C" int ds_event_destroy(void *event) {
     DS_REQUIRE(event != nullptr, DS_ERR_NULL);
-#ifdef DS_EMULATED
-    return DS_ERR_UNSUPPORTED;
-#else
     return (int)hipEventDestroy((hipEvent_t)event);
-#endif
 }
 
 // milliseconds between two events (waits for `stop` first, at most 2 s)
 extern "C" int ds_event_elapsed_ms(void *start, void *stop, float *ms) {
     DS_REQUIRE(start && stop && ms, DS_ERR_NULL);
-#ifdef DS_EMULATED
-    return DS_ERR_UNSUPPORTED;
-#else
     // bounded wait (2 s): an event that was armed but never bound to a launch must not hang the caller
     hipError_t rc = hipEventQuery((hipEvent_t)stop);
     for (int i = 0; rc == hipErrorNotReady && i < 20000; ++i) {
@@ -428,7 +439,6 @@ extern "C" int ds_event_elapsed_ms(void *start, void *stop, float *ms) {
     rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
     if (rc != hipSuccess) (void)hipGetLastError();
     return (int)rc;
-#endif
 }
 
 // The NEXT big-LDS kernel launch of this thread (the MFMA convolution / filter-gradient kernels) records its own
@@ -436,22 +446,14 @@ extern "C" int ds_event_elapsed_ms(void *start, void *stop, float *ms) {
 // (the caller expects 1: a call that launched several kernels timed only its first).
 extern "C" int ds_launch_timing_arm(void *start, void *stop) {
     DS_REQUIRE(start && stop, DS_ERR_NULL);
-#ifdef DS_EMULATED
-    return DS_ERR_UNSUPPORTED;
-#else
     ds_timing_arm_state = {(hipEvent_t)start, (hipEvent_t)stop, 1, 0};
     return DS_OK;
-#endif
 }
 
 extern "C" int ds_launch_timing_end(void) {
-#ifdef DS_EMULATED
-    return 0;
-#else
     const int n = ds_timing_arm_state.launches;
     ds_timing_arm_state = {nullptr, nullptr, 0, 0};
     return n;
-#endif
 }
 
 extern "C" const char *ds_error_string(int code) {
@@ -461,6 +463,7 @@ extern "C" const char *ds_error_string(int code) {
         case DS_ERR_ALIGNMENT: return "pointer not 16-byte aligned";
         case DS_ERR_NULL: return "null pointer";
         case DS_ERR_UNSUPPORTED: return "unsupported configuration";
+        case DS_ERR_NO_WORKSPACE: return "no free tile-scheduling slot on this device: hand over zeroed device memory with ds_sched_set_workspace";
         default: return code > 0 ? "HIP runtime error (hipError_t)" : "unknown error";
     }
 }

@@ -421,6 +421,14 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
         ds_lds_barrier();                           // every wave is done reading the intermediate tile
         DS_BLK_STAMP(5);
         const int t_after = ds_uniform(*sched_word);
+        // bn2's scale / shift rows are requested BEFORE the next tile's pixels: loads retire through one in-order counter,
+        // and the epilogue's first fma would otherwise wait for the whole HBM prefetch issued ahead of them (round 6:
+        // `s_waitcnt vmcnt(0)` behind 12 prefetch + 4 table loads in the ISA of the round-5 kernel)
+#ifndef DS_EPI_TABLES_LATE          // (A/B builds, tools/f16_ab.py: the round-5 order -- prefetch first)
+        const f32x4 sc[2] = {*(const f32x4 *)(p.sb + col), *(const f32x4 *)(p.sb + col + 4)};
+        const f32x4 sh[2] = {*(const f32x4 *)(p.hb + col), *(const f32x4 *)(p.hb + col + 4)};
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         int nb = b, nr0 = r0;
         {
             const bool has_next = t_next < t_end;
@@ -435,8 +443,11 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_block3
             for (int it = 0; it < NIT; ++it) st[it] = ds_buffer_load_f32x4(xbuf, g_rel[it] - x_lo);
         }
         const int lin_kept = (h_valid - r0) * W;                          // MASKED: pixels of the tile below the extent
+#ifdef DS_EPI_TABLES_LATE
+        __builtin_amdgcn_sched_barrier(0);
         const f32x4 sc[2] = {*(const f32x4 *)(p.sb + col), *(const f32x4 *)(p.sb + col + 4)};
         const f32x4 sh[2] = {*(const f32x4 *)(p.hb + col), *(const f32x4 *)(p.hb + col + 4)};
+#endif
         auto put_tile = [&](int ms) {
             float *dst = tb + (ms & 1) * (32 * TP);
 #pragma unroll
@@ -577,7 +588,7 @@ static int conv_block_f16(const void *x_f16, const void *wa_f16, const void *wb_
     k.xcd_slots = 0;
     if (B >= 8 && grid == resident && resident % 8 == 0) k.xcd_slots = resident / 8;
     k.sched = ds_sched_slot(stream);
-    DS_REQUIRE(k.sched != nullptr, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(k.sched != nullptr, DS_ERR_NO_WORKSPACE);     // ds_sched_set_workspace is due
     k.sched_lds = (int)block_lds_bytes(W, C, 2) - 16;
     if (C == 64) {          // W = 32: 2 x 1 waves, 12 x 32 x 4 items over 128 threads
         if (lens) DS_LAUNCH_BIG_LDS((conv_block3x3_f16_kernel<2, 1, 12, true>), grid, 128, block_lds_bytes(W, C, 2), stream, k);

@@ -542,7 +542,7 @@ static int conv_fwd_f16(const ds_conv_shape *s, const void *x_f16, const void *w
     if (persistent) {
         if (!(flags & DS_CONV_HINT_NO_WIDE)) widen_persistent(pl, s);
         k.sched = ds_sched_slot(stream);
-        DS_REQUIRE(k.sched != nullptr, DS_ERR_UNSUPPORTED);
+        DS_REQUIRE(k.sched != nullptr, DS_ERR_NO_WORKSPACE);     // ds_sched_set_workspace is due
         // one tile queue per XCD where the tiles of a queue (t = 8 j + q) then all belong to one n tile
         k.sched_queues = (pl.grid % 8 == 0 && 8 % k.n_ntiles == 0 && !(flags & DS_CONV_HINT_ONE_QUEUE)) ? 8 : 1;
         k.sched_lds = (int)pl.lds_bytes - 16;       // the plan's LDS size ends with tables the persistent kernel does not use

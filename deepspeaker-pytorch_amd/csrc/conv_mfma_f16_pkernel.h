@@ -391,7 +391,14 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
 #pragma unroll
             for (int it = 0; it < NIT; ++it) st[it] = ds_buffer_load_f32x4(xb, g_rel(it) - n_lo);
         };
+        // The BatchNorm scale / shift rows are requested BEFORE the next tile's pixels: loads retire through one in-order
+        // counter, so the first fma of the epilogue -- which needs these rows -- would otherwise wait for the whole HBM
+        // prefetch issued ahead of them (round 6: `s_waitcnt vmcnt(2)` behind 8 prefetch + 4 table loads in the ISA;
+        // a tile's epilogue stood still for one HBM round trip).
+#ifdef DS_EPI_TABLES_LATE
         if constexpr (EARLY_PREFETCH) prefetch_next();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         f32x4 sc[NH][2], sh[NH][2];
 #pragma unroll
         for (int nh = 0; nh < NH; ++nh)
@@ -404,6 +411,10 @@ __global__ void __launch_bounds__(WM * WN * 64) DS_ONE_WAVE_PER_SIMD conv_mfma_f
                     sh[nh][hq] = *(const f32x4 *)(p.shift + col + 64 * nh + 4 * hq);
                 }
             }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef DS_EPI_TABLES_LATE          // (A/B builds, tools/f16_ab.py: the round-5 order -- prefetch first)
+        if constexpr (EARLY_PREFETCH) prefetch_next();
+#endif
         auto put_tile = [&](int e) {                // accumulators of step e -> this wave's buffer e & 1
             float *dst = tb + (e & 1) * (32 * TP);
             const int ms = e / NH, nh = e % NH;

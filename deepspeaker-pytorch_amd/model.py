@@ -725,6 +725,18 @@ class DeepSpeakerModel(nn.Module):
                                                               low_latency=self.low_latency)
         return self.features
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.cuda()` / `.to(device)`: the library owns no device memory, so the zeroed buffer the persistent fp16 kernels draw
+        their tile counters from is allocated here, through torch's allocator, for every device the model now lives on --
+        eagerly, so that a stream capture whose first forward was never warmed up still finds its slots."""
+        result = super()._apply(fn, *args, **kwargs)
+        devices = {p.device for p in self.parameters() if p.is_cuda}
+        if devices and not torch.cuda.is_current_stream_capturing():
+            lib = get_engine().lib
+            for dev in devices:
+                lib.ensure_sched_workspace(dev)
+        return result
+
     # new weights / a model coming back from training re-arm the fp16 path's precision check (precision_guard.py)
     def load_state_dict(self, *args, **kwargs):
         result = super().load_state_dict(*args, **kwargs)

@@ -13,13 +13,16 @@
  *     entry point synchronises the device or a stream (ds_event_elapsed_ms, a
  *     read-out helper, waits for its `stop` event), so calls are re-entrant and
  *     hipGraph-capturable.
- *   - the caller owns all tensor buffers (inputs, outputs, scratch).  State the
- *     LIBRARY owns -- all of it, each item behind its own lock or thread-local:
- *       (1) tile-scheduling slots of the persistent fp16 kernels: device memory in
- *           64 KiB chunks, hipMalloc'ed on first use per device under a mutex and
- *           never freed; a ring of 8 slots per (device, stream) for eager launches,
- *           one slot for good per launch captured into a graph (csrc/bn_pack.hip
- *           ds_sched_slot).  The first launch on a new device therefore allocates;
+ *   - the caller owns ALL device memory: tensor buffers (inputs, outputs, scratch)
+ *     and the tile-scheduling workspace of the persistent fp16 kernels
+ *     (ds_sched_workspace_bytes / ds_sched_set_workspace below).  The library never
+ *     allocates, frees, memsets or synchronises.  State the LIBRARY keeps -- all of
+ *     it host-side, each item behind its own lock or thread-local:
+ *       (1) the table of which 64-byte slots of the caller's scheduler workspaces
+ *           have been handed out: a ring of 8 per (device, stream) for eager
+ *           launches, one slot for good per launch captured into a graph
+ *           (csrc/bn_pack.hip ds_sched_slot); a launch that finds no free slot
+ *           returns DS_ERR_NO_WORKSPACE;
  *       (2) the armed event pair of ds_launch_timing_arm: thread-local, consumed by
  *           the calling thread's next MFMA launch (csrc/ds_device.h);
  *       (3) process-wide tuning hooks, ds_conv_f16_set_layout_padding and
@@ -52,6 +55,7 @@ extern "C" {
 #define DS_ERR_ALIGNMENT   (-2)
 #define DS_ERR_NULL        (-3)
 #define DS_ERR_UNSUPPORTED (-4)
+#define DS_ERR_NO_WORKSPACE (-5)    /* a persistent launch found no free tile-scheduling slot: ds_sched_set_workspace */
 
 /* epilogue flags of the convolution entry points */
 #define DS_EPI_AFFINE   1   /* y = acc * scale[c] + shift[c]   (BatchNorm with fixed statistics) */
@@ -91,6 +95,15 @@ int ds_event_elapsed_ms(void *start, void *stop, float *ms);     /* waits for `s
 int ds_launch_timing_arm(void *start, void *stop);
 int ds_launch_timing_end(void);
 const char *ds_error_string(int code);
+
+/* ---- tile-scheduling workspace of the persistent kernels (ds_conv_fwd_f16, ds_conv_block_f16) ----
+ * Those kernels draw tiles from device-side counters ("slots", 64 bytes each, left zeroed by the kernel that used them).
+ * The memory is the caller's: hand over ZEROED device memory of ds_sched_workspace_bytes() on the current device before
+ * the first such launch there (again whenever a launch returns DS_ERR_NO_WORKSPACE: every launch captured into a graph
+ * keeps one slot for good) and keep it allocated.  ds_sched_free_slots(): slots of the current device not handed out yet. */
+size_t ds_sched_workspace_bytes(void);
+int ds_sched_set_workspace(void *zeroed_device_memory, size_t bytes);
+long long ds_sched_free_slots(void);
 /* measurement only: one launch of independent fp16 (bf16 != 0: bf16) 32x32x16 MFMAs issued back to back from registers on
  * every SIMD, random operand bits -- the matrix cores' power- / clock-limited rate on THIS chip.  *flop_out receives the
  * floating-point operations of the launch; the caller times it with its own events (bench.py:

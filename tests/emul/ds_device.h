@@ -197,3 +197,9 @@ static inline int ds_uniform(int v) { return v; }
 static inline float ds_bn_affine(float z, float scale, float shift) { return __builtin_fmaf(z, scale, shift); }
 
 static inline int ds_last_launch_error() { return 0; }
+
+// launch timing does not exist on the host: the armed pair is kept (the entry points compile unchanged) and no launch
+// ever counts itself
+#include <unistd.h>
+struct ds_timing_arm_t { hipEvent_t start, stop; int armed, launches; };
+inline thread_local ds_timing_arm_t ds_timing_arm_state = {nullptr, nullptr, 0, 0};

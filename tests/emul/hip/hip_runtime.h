@@ -44,5 +44,19 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 typedef void *hipStream_t;
+// ---- the handful of HIP runtime calls the C-ABI translation units make besides launching: on the host there is one
+// "device", nothing is ever being captured, and timing events do not exist (the product sources carry no emulator
+// branches: round 6)
+typedef int hipError_t;
+typedef void *hipEvent_t;
+enum : int { hipSuccess = 0, hipErrorNotReady = 600, hipErrorNotSupported = 801 };
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+static inline hipError_t hipGetDevice(int *dev) { *dev = 0; return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *) { return hipErrorNotSupported; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipErrorNotSupported; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipErrorNotSupported; }
+static inline hipError_t hipEventElapsedTime(float *, hipEvent_t, hipEvent_t) { return hipErrorNotSupported; }
 // scheduling hints are no-ops on the host
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

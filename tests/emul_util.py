@@ -35,7 +35,7 @@ def emul_lib():
                 if _stale():
                     subprocess.run([os.path.join(EMUL_DIR, "build_emul.sh")], check=True, capture_output=True)
         from deepspeaker_pytorch_amd._native import NativeLib
-        _lib = NativeLib(EMUL_LIB)
+        _lib = NativeLib(EMUL_LIB, host_memory=True)
     return _lib
 
 

@@ -75,6 +75,52 @@ def test_graph_replay_next_to_eager_f16_launches():
         assert torch.equal(e, ref_b)
 
 
+def test_cold_capture_first_persistent_launch_inside_a_graph():
+    """the library owns no device memory and never synchronises, so a stream capture whose FIRST persistent
+    launch was never warmed up must work: the scheduler workspace is the wrapper's (allocated through torch when the model
+    is moved to the device).  Fresh process (the slot table is per process): capture the very first fp16 forward, replay it,
+    compare with the eager forward; then an eager forward on a stream the process has not used yet."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r]
+import deepspeaker_oracle as O
+from deepspeaker_pytorch_amd.model import DeepSpeakerModel, get_engine
+sd = O.make_state_dict(seed=11, num_classes=16)
+m = DeepSpeakerModel(512, 16, precision="f16", f16_guard=None)
+m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+m = m.cuda().eval()
+lib = get_engine().lib
+free0 = int(lib.raw("ds_sched_free_slots")())
+assert free0 >= 64, free0                                   # handed over by .cuda(), before any launch
+x = torch.from_numpy(O.make_input(seed=905, batch=32, frames=160)).cuda()
+sx = x.clone()
+g = torch.cuda.CUDAGraph()
+with torch.no_grad(), torch.cuda.graph(g):                  # no warm-up of any kind
+    se = m(sx)
+free1 = int(lib.raw("ds_sched_free_slots")())
+assert free0 - 9 <= free1 < free0, (free0, free1)           # every captured persistent launch keeps one slot for good
+g.replay()
+torch.cuda.synchronize()
+got = se.clone()
+with torch.no_grad():
+    ref = m(x).clone()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ref2 = m(x).clone()
+torch.cuda.synchronize()
+assert torch.equal(got, ref) and torch.equal(ref2, ref)
+g.replay(); torch.cuda.synchronize()
+assert torch.equal(se, ref)
+print("cold capture ok", free0, int(lib.raw("ds_sched_free_slots")()))
+""" % (root, os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "cold capture ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_launch_bound_events_read_the_kernel_and_leave_results_alone():
     """Per-launch timing of the bench's live roofline: events bound to the launch itself (ds_launch_timing_arm ->
     hipExtLaunchKernelGGL) instead of an event pair recorded around it.  Same results bit for bit, one timed launch per

@@ -29,7 +29,10 @@ def test_hip_library_exports_every_declared_symbol():
         import __graft_entry__
         __graft_entry__.build()
     lib = _native.NativeLib(path)            # resolves every symbol or raises AttributeError
-    assert lib.raw("ds_version")() >= 500            # round 5 (include/deepspeaker_hip.h)
+    assert lib.raw("ds_version")() >= 600            # round 6 (include/deepspeaker_hip.h)
+    # the library owns no device memory: the persistent kernels' scheduler workspace is the caller's
+    assert lib.raw("ds_sched_workspace_bytes")() == 1024 * 64
+    assert lib.raw("ds_sched_set_workspace")(None, 65536) == -3 and lib.error_string(-5).startswith("no free tile-scheduling slot")
     assert lib.error_string(-1) == "bad shape"
     # argument validation happens before any launch, so it is testable without a GPU
     shp = _native.ConvShape(1, 8, 8, 7, 64, 3, 1)
@@ -68,6 +71,16 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 1, 160, 64))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         PairwiseDistance(2).forward(torch.zeros(2, 8), torch.zeros(2, 8))
+
+
+def test_library_sources_do_not_allocate_or_synchronise():
+    """caller-owned buffers, no hipMalloc / hipFree / memset / synchronise inside the library, and no
+    emulator branches in product source (the host stand-ins live in tests/emul/)."""
+    csrc = os.path.join(ROOT, "deepspeaker-pytorch_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        txt = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+        for banned in ("hipMalloc", "hipFree", "hipMemset", "hipDeviceSynchronize", "hipStreamSynchronize", "DS_EMULATED"):
+            assert banned not in txt, (f, banned)
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -45,6 +45,12 @@ import numpy as np
 import torch
 
 dll = ctypes.CDLL(OUT)
+# the probe copy of the library draws its tile counters from a zeroed buffer of ours, like the product wrapper does
+dll.ds_sched_workspace_bytes.restype = ctypes.c_size_t
+dll.ds_sched_set_workspace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+_sched_ws = torch.zeros(dll.ds_sched_workspace_bytes() // 4, dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+assert dll.ds_sched_set_workspace(_sched_ws.data_ptr(), _sched_ws.numel() * 4) == 0
 stock = ctypes.CDLL(os.path.join(ROOT, "deepspeaker-pytorch_amd", "libdeepspeaker_hip.so"))
 dev = torch.device("cuda", 0)
 B = 768

@@ -39,6 +39,12 @@ import torch
 from deepspeaker_pytorch_amd._native import ConvShape, DS_CONV_IN_PLANES16, DS_EPI_AFFINE, DS_EPI_CLIP, DS_EPI_RESIDUAL
 
 dll = ctypes.CDLL(OUT)
+# the probe copy of the library draws its tile counters from a zeroed buffer of ours, like the product wrapper does
+dll.ds_sched_workspace_bytes.restype = ctypes.c_size_t
+dll.ds_sched_set_workspace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+_sched_ws = torch.zeros(dll.ds_sched_workspace_bytes() // 4, dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+assert dll.ds_sched_set_workspace(_sched_ws.data_ptr(), _sched_ws.numel() * 4) == 0
 dev = torch.device("cuda", 0)
 B = 768
 P = ctypes.c_void_p
