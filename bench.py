@@ -780,6 +780,8 @@ def main():
             tfl = emb_per_step * args.steps / elapsed * 3 * FWD_FLOPS_PER_EMB / 1e12
             line["algorithmic_tflops"] = round(tfl, 1)         # ~3x the forward's FLOPs per utterance
             line["frac_of_mfma_peak"] = round(tfl / (157.3 if tprec == "f32" else 2500.0), 4)
+            if tprec == "f16":      # train-mode embeddings 1.2e-3 - 1.3e-3, gradients 4e-3 - 6e-3: outside north_star's 1e-3
+                line["outside_contract"] = True
             if ar_per_step is not None:
                 # 12 BatchNorm layers x {forward, backward} + 5 gradient buckets + the logged loss
                 line["all_reduce_per_step"] = ar_per_step
@@ -822,7 +824,10 @@ def main():
         varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=4096, dev=dev)
         # the training legs: >= 20 steps per region after >= 10 warm-ups, the median of 3 regions (5 steps after 2
         # warm-ups could not tell a 20 % regression from box spread)
-        kt, wt_, regions_t = max(20, args.steps), 10, 3
+        # 30 warm-ups: the first ~20 steps of a fresh process are HOST-bound (allocator pools, launch plans, pinned staging:
+        # 10 ms of enqueue per fp16 step instead of 3.8), which is what made the driver's first region read 10.02 ms next
+        # to 8.72 / 8.72 in round 5
+        kt, wt_, regions_t = max(20, args.steps), 30, 3
         # The training legs run in FRESH PROCESSES (`bench.py --train ...`): HIP deals streams to its 4 hardware queues
         # round-robin in creation order and two streams on one queue serialise, so inside this process the legs' stream
         # overlap depends on how many streams the eval part happened to create before them (measured, same box, same
@@ -904,6 +909,14 @@ def main():
         for prec, (e2, p2, k2) in secondary.items():
             out[prec + "_path"] = {"value": round(emb_per_step * k2 / e2, 1), "unit": "embeddings/s", "steps": k2,
                                    "roofline": roofline_of(prec, p2, k2)}
+        if "precision_guard" in out and "bf16x3_path" in out and eff_prec == "f16":
+            # `value` is the fp16 kernels' rate BECAUSE the guard measured this network inside its threshold.  On a network it
+            # escalates -- measured: an SGD-trained one whose embeddings have spread, raw fp16 8.6e-4 -- every eval forward
+            # runs the f32-class kernels, and the same step runs at this rate instead:
+            out["precision_guard"]["value_if_escalated"] = out["bf16x3_path"]["value"]
+            out["precision_guard"]["value_if_escalated_what"] = (
+                "embeddings/s of this step when the guard escalates (a trained network whose fp16 error estimate passes "
+                f"{out['precision_guard']['threshold']:g}): the split-operand bf16 path, measured in this run (`bf16x3_path`)")
         if world == 1 and not args.no_secondary:
             out["train_step"] = {"value": round(emb_per_step * kt / et, 1), "unit": "utterances/s", "steps": kt,
                                  "ms_per_step": round(et / kt * 1e3, 3), "dtype": "bf16x3",
@@ -917,10 +930,15 @@ def main():
                                      "warmup": wt_, "regions_ms_per_step": regs_t16,
                                      "algorithmic_tflops": round(emb_per_step * kt / et16 * 3 * FWD_FLOPS_PER_EMB / 1e12, 1),
                                      "frac_of_f16_peak": round(emb_per_step * kt / et16 * 3 * FWD_FLOPS_PER_EMB / 1e12 / 2500.0, 4),
+                                     # north_star's contract is 1e-3 on embeddings and loss: this mode's TRAIN-mode embeddings
+                                     # measure 1.2e-3 - 1.3e-3 (bar 2e-3), its gradients 4e-3 - 6e-3 (bar 8e-3)
+                                     "outside_contract": True,
                                      "what": "the same step in the OPT-IN fp16 mode (DeepSpeakerModel(train_precision='f16')): fp16 "
                                              "activations and loss-scaled gradients in HBM, forward and data-gradient convolutions "
-                                             "on the fp16 matrix-core kernels; stated tolerance: embeddings / loss 1e-3, gradients "
-                                             "3e-3 vs the masked oracle (tests/test_gpu_train_f16.py)"}
+                                             "on the fp16 matrix-core kernels.  OUTSIDE north_star's 1e-3: loss 3.5e-4, train-mode "
+                                             "embeddings 1.2e-3 - 1.3e-3 (bar 2e-3), gradients 4e-3 - 6e-3 vs the masked oracle "
+                                             "(bar 8e-3; tests/test_gpu_train_f16.py); the default step (`train_step`) is the "
+                                             "in-contract one"}
             out["varlen"] = varlen
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_np)

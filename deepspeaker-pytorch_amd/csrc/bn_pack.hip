@@ -30,6 +30,9 @@ __global__ void __launch_bounds__(256) bn_fold_kernel(const float *gamma, const 
 // FOLD_R row-lanes stride over the partial rows (stage-1 layers have thousands of rows and only 64 channels --
 // a channel-per-thread layout left the chip idle; 8 channels x 32 lanes still meant 8 workgroups walking 64 rows
 // each: 27 us, now 8), then lane 0 folds the lane sums.
+// Round 6: the lane sums are folded by an xor tree of shuffles inside each wave (lane = 2 * row lane + channel: offsets
+// 2 .. 32) and the four waves' results by one thread -- the last step used to be ONE thread adding 128 LDS values per
+// channel in sequence (14 - 18 us per launch, 48 launches per training step).
 constexpr int FOLD_C = 2, FOLD_R = 128;
 __device__ __forceinline__ bool fold_partials(const float *partial, int n_partial, int C, double *red, int &c,
                                               double &t1, double &t2, int cgroup = -1) {
@@ -43,13 +46,21 @@ __device__ __forceinline__ bool fold_partials(const float *partial, int n_partia
             s2 += (double)src[1];
         }
     }
-    red[(rl * FOLD_C + cl) * 2 + 0] = s1;
-    red[(rl * FOLD_C + cl) * 2 + 1] = s2;
+#pragma unroll
+    for (int m = 2; m <= 32; m <<= 1) {
+        s1 += ds_shfl_xor_f64(s1, m);
+        s2 += ds_shfl_xor_f64(s2, m);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < FOLD_C) {
+        red[(wave * FOLD_C + cl) * 2 + 0] = s1;
+        red[(wave * FOLD_C + cl) * 2 + 1] = s2;
+    }
     __syncthreads();
     if (rl != 0 || c >= C) return false;
     t1 = 0.0;
     t2 = 0.0;
-    for (int k = 0; k < FOLD_R; ++k) {
+    for (int k = 0; k < 4; ++k) {
         t1 += red[(k * FOLD_C + cl) * 2 + 0];
         t2 += red[(k * FOLD_C + cl) * 2 + 1];
     }

@@ -4,7 +4,7 @@
 //
 // for the two shallow stages (64 channels on 80x32 maps, 128 channels on 40x16 maps at T = 160).  There the contraction
 // of one 3x3 layer is only K = 576 / 1152 deep and a workgroup of conv_mfma_f16_kernel spends more clocks in its
-// prologue and epilogue than in its MFMA stream.  Fusing the block's two convolutions pays one prologue
+// prologue and epilogue than in its MFMA stream (DESIGN_LOG.md 3.1).  Fusing the block's two convolutions pays one prologue
 // and one HBM epilogue for two MFMA streams: the intermediate activation (rows r0-1 .. r0+R of the image, the halo
 // rows recomputed) goes from the accumulators straight into LDS in the pixel-record layout the second convolution
 // reads its fragments from -- it never exists in HBM.  Arithmetic, rounding points (the intermediate is rounded to fp16

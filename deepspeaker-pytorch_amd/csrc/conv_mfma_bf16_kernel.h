@@ -1,7 +1,7 @@
 // conv_mfma_bf16_kernel.h -- the bf16 / bf16x3 implicit-GEMM convolution kernel template and its launch
 // dispatch.  Included by the per-(kernel size, arithmetic) translation units conv_mfma_bf16_k*.hip, which
 // exist only so that the ~50 instantiations compile in parallel; the planner and the C ABI live in
-// conv_mfma_bf16.hip.  Design notes: DESIGN.md section 3.3.
+// conv_mfma_bf16.hip.  Design notes: DESIGN_LOG.md section 3.3.
 #pragma once
 #include <ds_device.h>
 #include "ds_common.h"

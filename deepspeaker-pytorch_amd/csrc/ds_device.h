@@ -50,6 +50,7 @@ __device__ __forceinline__ f32x16 ds_mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 
 // cross-lane exchange inside one 64-lane wavefront
 __device__ __forceinline__ float ds_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float ds_shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ double ds_shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int ds_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ unsigned long long ds_ballot(int pred) { return __ballot(pred); }
 // orders this wavefront's LDS traffic: writes issued before it are visible to every lane's reads after it

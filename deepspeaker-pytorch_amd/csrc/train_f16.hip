@@ -83,9 +83,14 @@ __global__ void __launch_bounds__(256) bn_stats_f16_kernel(const h16 *z, float *
     block_fold(red, s1, s2, slot, slots, cg, C, partial);
 }
 
-// fold of one member's partial rows for TF_FOLD_C channels per workgroup, double precision, fixed order
+// fold of one member's partial rows for TF_FOLD_C channels per workgroup, double precision, fixed order: a thread adds
+// its rows (rl, rl + TF_FOLD_R, ...), the 32 row lanes of a wave are folded by an xor tree of shuffles (lane = 2 rl + cl:
+// offsets 2 .. 32), the four waves' results meet in LDS.  (Round 6: the last step used to be ONE thread adding 128 LDS
+// values per channel and member in sequence -- 16 - 35 us for a launch that moves a few hundred KB, 24 of them on the
+// critical path of every fp16 training step.)
 __device__ __forceinline__ bool fold_rows(const float *partial, int n_partial, int C, double *red, int c0, int &c, double &t1,
                                           double &t2) {
+    static_assert(TF_FOLD_C == 2 && TF_FOLD_R == 128, "lane = 2 * row lane + channel; four waves");
     const int cl = threadIdx.x % TF_FOLD_C, rl = threadIdx.x / TF_FOLD_C;
     c = c0 + cl;
     double s1 = 0.0, s2 = 0.0;
@@ -95,13 +100,21 @@ __device__ __forceinline__ bool fold_rows(const float *partial, int n_partial, i
             s1 += (double)src[0];
             s2 += (double)src[1];
         }
+#pragma unroll
+    for (int m = 2; m <= 32; m <<= 1) {
+        s1 += ds_shfl_xor_f64(s1, m);
+        s2 += ds_shfl_xor_f64(s2, m);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();                                        // (the previous member's fold has been read)
-    red[(rl * TF_FOLD_C + cl) * 2 + 0] = s1;
-    red[(rl * TF_FOLD_C + cl) * 2 + 1] = s2;
+    if (lane < TF_FOLD_C) {
+        red[(wave * TF_FOLD_C + cl) * 2 + 0] = s1;
+        red[(wave * TF_FOLD_C + cl) * 2 + 1] = s2;
+    }
     __syncthreads();
     if (rl != 0 || c >= C) return false;
     t1 = t2 = 0.0;
-    for (int k = 0; k < TF_FOLD_R; ++k) {
+    for (int k = 0; k < 4; ++k) {
         t1 += red[(k * TF_FOLD_C + cl) * 2 + 0];
         t2 += red[(k * TF_FOLD_C + cl) * 2 + 1];
     }

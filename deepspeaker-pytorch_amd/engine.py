@@ -4,12 +4,13 @@
 into the sequence of C-ABI launches declared in include/deepspeaker_hip.h.  It owns no arithmetic:
 every tensor op is a kernel in libdeepspeaker_hip.so; torch supplies buffers and the stream.
 
-Data layout in HBM (see DESIGN.md): activations are channels-last fp32 `[B, T', F', C]`; the network
+Data layout in HBM (see DESIGN.md section 2): activations are channels-last fp32 `[B, T', F', C]`; the network
 input `[B,1,T,64]` is consumed in place (C = 1).  Filters are packed once per weight version.
 """
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -117,6 +118,30 @@ class LaunchEvent:
                 self._lib.raw("ds_event_destroy")(self.handle)
         except Exception:
             pass
+
+
+class _Range:
+    """roctx range (SURVEY section 5 tracing): `DS_ROCTX=1` brackets the phases of a step -- eval forward, each timed
+    convolution launch, train forward / backward / optimizer -- with roctxRangePush / Pop (torch.cuda.nvtx is roctx on
+    ROCm), so that `rocprofv3 --marker-trace` shows them next to the kernels.  Off by default: a no-op object."""
+    enabled = os.environ.get("DS_ROCTX", "0") not in ("", "0")
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if _Range.enabled:
+            torch.cuda.nvtx.range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if _Range.enabled:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
+def trace_range(name: str) -> _Range:
+    return _Range(name)
 
 
 class Engine:
@@ -672,7 +697,12 @@ class Engine:
             self._profile_calls[precision] = turn + 1
             if turn % self.profile_every:
                 prof = None
+        roctx = _Range.enabled and x.is_cuda
+        if roctx:
+            torch.cuda.nvtx.range_push(f"ds.forward_eval[{precision}] B={x.shape[0]} T={x.shape[2]}")
         for fn, args, label, flops in plan["calls"]:
+            if roctx:
+                torch.cuda.nvtx.mark(label or fn.__name__)
             if prof is not None and label is not None:
                 if self.self_timed_launches and fn.__name__ in _SELF_TIMED:    # one MFMA kernel per call: the launch carries its own events
                     ev0, ev1 = LaunchEvent(self.lib), LaunchEvent(self.lib)
@@ -689,7 +719,11 @@ class Engine:
             else:
                 rc = fn(*args)
             if rc != 0:
+                if roctx:
+                    torch.cuda.nvtx.range_pop()
                 raise RuntimeError(f"{fn.__name__} failed: {rc} ({self.lib.error_string(rc)})")
+        if roctx:
+            torch.cuda.nvtx.range_pop()
         return e
 
     # ------------------------------------------------------------------ forward passes

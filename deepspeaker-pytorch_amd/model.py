@@ -398,17 +398,19 @@ class _ResCNNTripletFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xa, xp, xn, model, *params):
+        from .engine import trace_range
         eng = get_engine()
         prec = model._train_arith(xa, members=3)
-        if prec == "f16":
-            from .train_f16 import forward_train_group_f16
-            pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
-            embs, saved = forward_train_group_f16(eng, [xa, xp, xn], pw, model._bn_params(), save=True,
-                                                  reducer=model._reducer)
-        else:
-            pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
-            embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
-                                                  precision=prec)
+        with trace_range(f"ds.train.forward_triplet[{prec}]"):
+            if prec == "f16":
+                from .train_f16 import forward_train_group_f16
+                pw = model._packed(with_dgrad=True, with_f16=True, f32_banks=False, with_f16_dgrad=True)
+                embs, saved = forward_train_group_f16(eng, [xa, xp, xn], pw, model._bn_params(), save=True,
+                                                      reducer=model._reducer)
+            else:
+                pw = model._packed(with_dgrad=True, with_bf16=(prec == "bf16x3"), f32_banks=(prec != "bf16x3"))
+                embs, saved = eng.forward_train_group([xa, xp, xn], pw, model._bn_params(), save=True, reducer=model._reducer,
+                                                      precision=prec)
         model._bump_batches_tracked(3)        # nn.BatchNorm2d.train() bookkeeping, one launch
         model._stat_updates += 3
         ctx.precision, ctx.saved_forward, ctx.model, ctx.pw = prec, saved, model, pw
@@ -421,14 +423,16 @@ class _ResCNNTripletFn(torch.autograd.Function):
         ref = next(g for g in (ga, gp, gn) if g is not None)
         ge = torch.cat([g if g is not None else torch.zeros_like(ref) for g in (ga, gp, gn)]).contiguous().float()
         bn_w = {n: m.weight for n, m in zip(ctx.model._bn_names(), ctx.model._bn_modules())}
-        if ctx.precision == "f16":
-            from .train_f16 import backward_train_f16
-            grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, loss_scale=ctx.model.loss_scale,
-                                       reducer=ctx.model._reducer, reduce_gradients=ctx.model._reducer is not None,
-                                       overflow_flag=ctx.model.grad_overflow_flag(ge.device))
-        else:
-            grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, reducer=ctx.model._reducer,
-                                   precision=ctx.precision, reduce_gradients=ctx.model._reducer is not None)
+        from .engine import trace_range
+        with trace_range(f"ds.train.backward_triplet[{ctx.precision}]"):
+            if ctx.precision == "f16":
+                from .train_f16 import backward_train_f16
+                grads = backward_train_f16(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, loss_scale=ctx.model.loss_scale,
+                                           reducer=ctx.model._reducer, reduce_gradients=ctx.model._reducer is not None,
+                                           overflow_flag=ctx.model.grad_overflow_flag(ge.device))
+            else:
+                grads = backward_train(get_engine(), bn_w, ctx.pw, ctx.saved_forward, ge, reducer=ctx.model._reducer,
+                                       precision=ctx.precision, reduce_gradients=ctx.model._reducer is not None)
         ctx.saved_forward = None
         return (None, None, None, None) + tuple(grads.get(n) for n in ctx.param_names)
 

@@ -14,6 +14,7 @@ from typing import List
 
 import torch
 
+from .engine import trace_range
 from .model import _require_cuda, get_engine
 
 
@@ -163,6 +164,12 @@ class FusedAdagrad(_FusedBase):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         eng = self._eng()
+        with trace_range("ds.optimizer.step"):
+            self._step_groups(eng)
+        self._consume_skip()
+        return loss
+
+    def _step_groups(self, eng):
         for group in self.param_groups:
             for part in self._partitions(group).values():
                 params, states, c = self._tables(group, ["sum"], False, params=part)
@@ -173,8 +180,6 @@ class FusedAdagrad(_FusedBase):
                 eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
                              self._skip(eng, params), eng._stream(params[0]))
                 self._bump_versions(params)
-        self._consume_skip()
-        return loss
 
 
 class FusedSGD(_FusedBase):
@@ -187,6 +192,12 @@ class FusedSGD(_FusedBase):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         eng = self._eng()
+        with trace_range("ds.optimizer.step"):
+            self._step_groups(eng)
+        self._consume_skip()
+        return loss
+
+    def _step_groups(self, eng):
         for group in self.param_groups:
             for fresh, part in self._partitions(group, fresh_key="momentum_buffer").items():
                 params, states, c = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False,
@@ -194,8 +205,6 @@ class FusedSGD(_FusedBase):
                 eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
                              group["weight_decay"], int(fresh), self._skip(eng, params), eng._stream(params[0]))
                 self._bump_versions(params)
-        self._consume_skip()
-        return loss
 
 
 class FusedAdam(_FusedBase):
@@ -208,6 +217,12 @@ class FusedAdam(_FusedBase):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         eng = self._eng()
+        with trace_range("ds.optimizer.step"):
+            self._step_groups(eng)
+        self._consume_skip()
+        return loss
+
+    def _step_groups(self, eng):
         for group in self.param_groups:
             for part in self._partitions(group).values():
                 params, states, c = self._tables(group, ["exp_avg", "exp_avg_sq"], True, params=part)
@@ -219,8 +234,6 @@ class FusedAdam(_FusedBase):
                              group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), self._skip(eng, params),
                              eng._stream(params[0]))
                 self._bump_versions(params)
-        self._consume_skip()
-        return loss
 
 
 def create_optimizer(model, new_lr, optimizer="adagrad", lr_decay=1e-4, wd=0.0):

@@ -6,7 +6,7 @@ small latency-bound launches (temporal mean, projection, norm, ...) behind; one 
 and that whole latency-bound end leave the matrix cores idle.  Consecutive batches are independent (eval-mode BatchNorm:
 per-utterance results do not depend on the batch, reference model.py:185-213), so the next batch's kernels can fill those
 holes: with two batches in flight the bench step (forward + loss + filter + search) runs at 1.82 - 1.90 ms instead of
-2.02 - 2.12 (`pipelined` in the bench line).  More than two buys nothing (3: -4 %, 4: +0 %).
+2.02 - 2.12 (`pipelined` in the bench line, DESIGN_LOG.md section 5).  More than two buys nothing (3: -4 %, 4: +0 %).
 
 Every stream has launch plans and activation buffers of its own (`Engine.forward_eval_planned` keys its plans by stream),
 so batches in flight never share a buffer; results are the tensors `model(x)` returns, in order.

@@ -89,6 +89,19 @@ static inline float ds_shfl_xor(float v, int mask) {
     emu::wave_exchange(v, all);
     return all[(threadIdx.x & 63) ^ mask];
 }
+static inline double ds_shfl_xor_f64(double v, int mask) {         // the two dwords travel separately, bit for bit
+    unsigned w[2];
+    memcpy(w, &v, 8);
+    for (int h = 0; h < 2; ++h) {
+        float f, all[64];
+        memcpy(&f, &w[h], 4);
+        emu::wave_exchange(f, all);
+        memcpy(&w[h], &all[(threadIdx.x & 63) ^ mask], 4);
+    }
+    double r;
+    memcpy(&r, w, 8);
+    return r;
+}
 static inline float ds_shfl_down(float v, int d) {
     float all[64];
     emu::wave_exchange(v, all);

@@ -1,7 +1,7 @@
 """CPU simulation of reduced-precision operand rounding at the bench configuration (BASELINE configs[1]: 768 utterances):
 the stage convolutions are evaluated by ATen with their operands rounded to fp16 / bf16 (f32 accumulation), everything
 else in f32 -- embedding error, error of d_n - d_p and flipped filter decisions against the f32 run.  This is what
-the choice of the fp16 arithmetic was made on before the kernel existed.  python tools/arith_sim.py"""
+the choice of the fp16 arithmetic (DESIGN_LOG.md 3.1) was made on before the kernel existed.  python tools/arith_sim.py"""
 import os, sys, time, numpy as np, torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
