@@ -269,6 +269,9 @@ def main():
                     help="--train: arithmetic of the training step: the f32-class default (split-operand bf16, gradients 1e-4 "
                          "from the masked oracle), exact f32, or the OPT-IN fp16 step (fp16 activations and loss-scaled "
                          "gradients in HBM, one fp16 MFMA per product; embeddings / loss 1e-3, gradients 3e-3)")
+    ap.add_argument("--train-settle-seconds", type=float, default=3.0,
+                    help="--train: untimed steps for at least this long before the W warm-ups (reported as `settle_steps`): a "
+                         "fresh process needs seconds of sustained load, not a step count, before its regions agree")
     ap.add_argument("--grad-comm", default=None, choices=["shared", "separate"],
                     help="--train: gradient buckets on the BatchNorm collectives' communicator, exchanged after the backward "
                          "pass (default; one program-ordered collective sequence per rank), or on a communicator of their "
@@ -398,7 +401,7 @@ def main():
         """untimed settle-in steps run BEFORE the W contract warm-ups (reported as `pre_steps` in the line)"""
         return max(0, PRE_STEPS - warmup)
 
-    def timed(step, steps, warmup, repeats=0, profile=True, finish=None, profile_every=1):
+    def timed(step, steps, warmup, repeats=0, profile=True, finish=None, profile_every=1, settle_s=0.0):
         # profile: per-launch events around the convolutions of the timed region (the live roofline of the eval line); the
         # training steps are timed without them (a pair of events per launch is ~70 per fp16 training step -- measured
         # 12.7 ms per step with them, 9.6 without)
@@ -409,6 +412,25 @@ def main():
         for _ in range(pre_steps(warmup)):      # timing events of a process cost ~40 ms to create; and a fresh
             step()                              # box needs ~0.2 s of work before clocks / caches settle (setup,
         fence()                                 # not part of the W contract warm-up steps that follow)
+        # the training legs: settle by TIME -- the first K-step region of a process measured 8 - 15 % slow however many
+        # warm-up steps preceded it (r05 driver: 10.02 / 8.72 / 8.72 ms after 10 steps; r06: 20.7 / 18.25 / 18.05 after
+        # 30): what has to pass is a couple of seconds of sustained load, not a step count
+        n_settle = 0
+        if settle_s > 0:
+            t_settle = time.perf_counter()
+            for _ in range(5):
+                step()
+            fence()
+            dt = torch.tensor([time.perf_counter() - t_settle], dtype=torch.float64, device=dev)
+            if multi:                           # every rank must run the same number of steps (they meet in collectives)
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            batches = min(400, max(0, int(np.ceil(settle_s / max(float(dt.item()), 1e-3))) - 1))
+            for _ in range(batches):
+                for _ in range(5):
+                    step()
+            fence()
+            n_settle = 5 * (1 + batches)
+        extras["settle_steps"] = n_settle
         prof_on()
         for _ in range(warmup):
             step()
@@ -628,7 +650,7 @@ def main():
                 red.all_reduce_sum_(loss.detach())
             return loss
 
-        elapsed, prof, again = timed(step, steps, warmup, repeats, profile=False)
+        elapsed, prof, again = timed(step, steps, warmup, repeats, profile=False, settle_s=args.train_settle_seconds)
         per_step = None
         if red is not None:
             red_modes[:] = [red.grad_comm, red.grad_reduce]
@@ -770,6 +792,7 @@ def main():
                 "metric": "training utterances/sec (64-fbank x 160-frame utterances)",
                 "value": round(emb_per_step * args.steps / elapsed, 1), "unit": "utterances/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "pre_steps": pre_steps(args.warmup),
+                "settle_steps": extras.get("settle_steps", 0),
                 "world_size": dist.get_world_size() if multi else 1,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": tprec, "data": "synthetic",
@@ -824,10 +847,8 @@ def main():
         varlen = varlen_bench.run(load_model(args.precision).eval(), n_utt=4096, dev=dev)
         # the training legs: >= 20 steps per region after >= 10 warm-ups, the median of 3 regions (5 steps after 2
         # warm-ups could not tell a 20 % regression from box spread)
-        # 30 warm-ups: the first ~20 steps of a fresh process are HOST-bound (allocator pools, launch plans, pinned staging:
-        # 10 ms of enqueue per fp16 step instead of 3.8), which is what made the driver's first region read 10.02 ms next
-        # to 8.72 / 8.72 in round 5
-        kt, wt_, regions_t = max(20, args.steps), 30, 3
+        # (each leg also settles for --train-settle-seconds of untimed steps first: see `timed`)
+        kt, wt_, regions_t = max(20, args.steps), 10, 3
         # The training legs run in FRESH PROCESSES (`bench.py --train ...`): HIP deals streams to its 4 hardware queues
         # round-robin in creation order and two streams on one queue serialise, so inside this process the legs' stream
         # overlap depends on how many streams the eval part happened to create before them (measured, same box, same

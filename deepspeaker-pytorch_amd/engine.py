@@ -600,16 +600,16 @@ class Engine:
                            ALPHA, L2_EPS, st_slot), None, 0.0))
             keep += [pw, folded]
             return {"calls": calls, "keep": keep, "x": x_slot, "e": e_slot, "st": st_slot, "n_out": n_out, "lens": lens_dev}
+        ws_floats = self.lib.raw("ds_fc_workspace_floats")(B, k, n_out)
+        if ws_floats <= 0:
+            raise RuntimeError(f"ds_fc_workspace_floats({B},{k},{n_out}) failed: {ws_floats}")
+        ws, f = buf(ws_floats), buf(B, n_out)
         pooled = buf(B, k)
         if masked:
             calls.append((self.lib.raw("ds_avgpool_time_masked_f32"),
                           (self._p(a), self._p(lens_dev[len(pw.stages) - 1]), self._p(pooled), B, h, w, cin, st_slot), None, 0.0))
         else:
             calls.append((self.lib.raw("ds_avgpool_time_f32"), (self._p(a), self._p(pooled), B, h, w, cin, st_slot), None, 0.0))
-        ws_floats = self.lib.raw("ds_fc_workspace_floats")(B, k, n_out)
-        if ws_floats <= 0:
-            raise RuntimeError(f"ds_fc_workspace_floats({B},{k},{n_out}) failed: {ws_floats}")
-        ws, f = buf(ws_floats), buf(B, n_out)
         calls.append((self.lib.raw("ds_fc_l2norm_fwd_f32"),
                       (self._p(pooled), self._p(pw.fc), self._p(pw.fc_bias.detach()), self._p(ws), self._p(f), e_slot, B,
                        k, n_out, ALPHA, L2_EPS, st_slot), None, 0.0))

@@ -70,7 +70,8 @@ def test_train_bench_two_ranks_end_to_end_on_the_emulator(tprec):
     grouped training step with its 30 exchanges per step (12 BatchNorm layers x 2 directions + 5 gradient buckets + the
     logged loss), barrier + max over ranks, the one line -- with two real ranks (gloo; the eval line's self-launch test
     above only reaches the rendezvous)."""
-    d = _run_emulated("--train", "--train-precision", tprec, "--steps", "1", "--warmup", "0", "--repeats", "0")
+    d = _run_emulated("--train", "--train-precision", tprec, "--steps", "1", "--warmup", "0", "--repeats", "0",
+                      "--train-settle-seconds", "0")
     assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
     assert d["unit"] == "utterances/s" and d["dtype"] == tprec and d["value"] > 0
     assert d["all_reduce_per_step"] == 2 * 12 + 5 + 1
