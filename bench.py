@@ -269,6 +269,9 @@ def main():
                     help="--train: arithmetic of the training step: the f32-class default (split-operand bf16, gradients 1e-4 "
                          "from the masked oracle), exact f32, or the OPT-IN fp16 step (fp16 activations and loss-scaled "
                          "gradients in HBM, one fp16 MFMA per product; embeddings / loss 1e-3, gradients 3e-3)")
+    ap.add_argument("--graph", action="store_true",
+                    help="--train: the whole step (forward of a / p / n, loss, backward, optimizer) captured into ONE HIP graph "
+                         "and replayed per step (train_graph.GraphedTripletStep): no host work in the timed region")
     ap.add_argument("--train-settle-seconds", type=float, default=3.0,
                     help="--train: untimed steps for at least this long before the W warm-ups (reported as `settle_steps`): a "
                          "fresh process needs seconds of sustained load, not a step count, before its regions agree")
@@ -650,6 +653,16 @@ def main():
                 red.all_reduce_sum_(loss.detach())
             return loss
 
+        if args.graph:
+            if multi:
+                raise SystemExit("--graph: collectives inside a captured step are not supported")
+            from deepspeaker_pytorch_amd.train_graph import GraphedTripletStep
+            gstep = GraphedTripletStep(model, opt, margin=0.1, example=batches[0]["apn"])
+
+            def step(slot=0):                   # noqa: F811  (the replay: three input copies + one graph launch)
+                d_ = batches[tstep_no[0] % n_batches]["apn"]
+                tstep_no[0] += 1
+                return gstep(d_[0], d_[1], d_[2])
         elapsed, prof, again = timed(step, steps, warmup, repeats, profile=False, settle_s=args.train_settle_seconds)
         per_step = None
         if red is not None:
@@ -803,6 +816,9 @@ def main():
             tfl = emb_per_step * args.steps / elapsed * 3 * FWD_FLOPS_PER_EMB / 1e12
             line["algorithmic_tflops"] = round(tfl, 1)         # ~3x the forward's FLOPs per utterance
             line["frac_of_mfma_peak"] = round(tfl / (157.3 if tprec == "f32" else 2500.0), 4)
+            if args.graph:
+                line["graph"] = ("the whole step replayed from ONE HIP graph (train_graph.GraphedTripletStep): ~330 (fp16) / ~400 "
+                                 "(f32-class) launches over two to four streams, filter re-pack and optimizer included")
             if tprec == "f16":      # train-mode embeddings 1.2e-3 - 1.3e-3, gradients 4e-3 - 6e-3: outside north_star's 1e-3
                 line["outside_contract"] = True
             if ar_per_step is not None:
@@ -853,10 +869,10 @@ def main():
         # round-robin in creation order and two streams on one queue serialise, so inside this process the legs' stream
         # overlap depends on how many streams the eval part happened to create before them (measured, same box, same
         # code: 18.1 / 8.9 ms or 19.4 / 9.7 ms).  A fresh process has one alignment -- the one `--train` is measured in.
-        def train_leg(tp):
+        def train_leg(tp, graph=False):
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--train", "--train-precision", tp, "--steps", str(kt),
-                   "--warmup", str(wt_), "--repeats", str(regions_t - 1), "--no-cpu-baseline"]
+                   "--warmup", str(wt_), "--repeats", str(regions_t - 1), "--no-cpu-baseline"] + (["--graph"] if graph else [])
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -866,11 +882,15 @@ def main():
                 print(f"[bench] training leg {tp} in a fresh process failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
             except Exception as exc:            # (no subprocess: measure here after all)
                 print(f"[bench] training leg {tp} in a fresh process failed: {exc}", file=sys.stderr)
+            if graph:
+                return None, "failed", []
             e_, _, again_, _ = measure_train(tp, kt, wt_, regions_t - 1)
             regs = [e_ / kt * 1e3] + list(again_)
             return float(np.median(regs)) * 1e-3 * kt, "this process", [round(v, 3) for v in regs]
         et, leg_where, regs_t = train_leg("bf16x3")
         et16, _, regs_t16 = train_leg("f16")
+        etg, _, regs_tg = train_leg("bf16x3", graph=True)
+        etg16, _, regs_tg16 = train_leg("f16", graph=True)
     # the arithmetic the timed forwards really ran in: the requested one, unless the fp16 guard escalated
     eff_prec = extras.get("precision_guard", {}).get("verdict", args.precision)
     if rank == 0 and dev.type == "cuda" and not args.no_secondary:
@@ -960,6 +980,15 @@ def main():
                                              "embeddings 1.2e-3 - 1.3e-3 (bar 2e-3), gradients 4e-3 - 6e-3 vs the masked oracle "
                                              "(bar 8e-3; tests/test_gpu_train_f16.py); the default step (`train_step`) is the "
                                              "in-contract one"}
+            for key_, e_, regs_, dt_ in (("train_step_graph", etg, regs_tg, "bf16x3"), ("train_step_f16_graph", etg16, regs_tg16, "f16")):
+                if e_ is not None:
+                    out[key_] = {"value": round(emb_per_step * kt / e_, 1), "unit": "utterances/s", "steps": kt,
+                                 "ms_per_step": round(e_ / kt * 1e3, 3), "dtype": dt_, "regions_ms_per_step": regs_,
+                                 "what": "the same step replayed from ONE HIP graph (train_graph.GraphedTripletStep: forward of "
+                                         "a / p / n, loss, backward on its streams, filter re-pack, fused optimizer with a "
+                                         "device-side step count); no host work in the timed region"}
+                    if dt_ == "f16":
+                        out[key_]["outside_contract"] = True
             out["varlen"] = varlen
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd_np)

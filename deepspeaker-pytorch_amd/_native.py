@@ -165,6 +165,13 @@ _SIGNATURES = {
     "ds_roc_sweep_f32": (c_int, [_P, _P, c_int, c_float, c_float, c_int, c_int, c_int, _P, _P, _P, _P]),
     "ds_assemble_crops_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_optim_chunk_elems": (c_int, []),
+    "ds_fill_bytes": (c_int, [_P, _P, c_int, _P]),
+    "ds_optim_step_inc": (c_int, [_P, _P, _P]),
+    "ds_adagrad_step_dev_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, ctypes.c_double, ctypes.c_double, c_float, c_float, _P,
+                                        _P, _P]),
+    "ds_sgd_step_dev_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, c_float, _P, _P, _P]),
+    "ds_adam_step_dev_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, ctypes.c_double, ctypes.c_double, c_float,
+                                     c_float, _P, _P, _P]),
     "ds_adagrad_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P, _P]),
     "ds_sgd_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "ds_nonfinite_flag_f32": (c_int, [_P, c_longlong, _P, _P]),

@@ -7,6 +7,7 @@
 // through registers once (HBM-bound: 16 B read + 8 B written per element for Adagrad).
 // Arithmetic follows the single-tensor torch implementations exactly (same operation order).
 #include <ds_device.h>
+#include <string.h>
 #include "ds_common.h"
 
 namespace {
@@ -25,9 +26,14 @@ struct OptTables {
                              // loss-scaled step, ds_nonfinite_flag_f32) -- decided on the device, no host round trip
 };
 
-// torch.optim.Adagrad (single-tensor path): grad += wd*p; sum += grad*grad; p -= clr * grad / (sqrt(sum) + eps)
-__global__ void __launch_bounds__(256) adagrad_kernel(const OptTables t, float clr, float wd, float eps) {
+// torch.optim.Adagrad (single-tensor path): grad += wd*p; sum += grad*grad; p -= clr * grad / (sqrt(sum) + eps).
+// `step` (nullable): the step count lives ON THE DEVICE (a captured step replays with the count of that replay, not of the
+// capture: ds_optim_step_inc bumps it once per optimizer step); clr = lr / (1 + (step - 1) lr_decay) is then taken from it
+// in double precision, the way the host computes the `clr` it passes otherwise.
+__global__ void __launch_bounds__(256) adagrad_kernel(const OptTables t, float clr, float wd, float eps, const int *step,
+                                                      double lr, double lr_decay) {
     if (t.skip != nullptr && *t.skip != 0) return;
+    if (step != nullptr) clr = (float)(lr / (1.0 + ((double)*step - 1.0) * lr_decay));
     const int ti = t.chunk_tensor[blockIdx.x];
     const long long n = t.numel[ti];
     const long long i0 = (long long)t.chunk_index[blockIdx.x] * OPT_CHUNK;
@@ -48,8 +54,9 @@ __global__ void __launch_bounds__(256) adagrad_kernel(const OptTables t, float c
 
 // torch.optim.SGD: grad += wd*p; buf = first ? grad : momentum*buf + (1-dampening)*grad; p -= lr*buf
 __global__ void __launch_bounds__(256) sgd_kernel(const OptTables t, float lr, float momentum, float dampening, float wd,
-                                                  int first) {
+                                                  int first, const int *step) {
     if (t.skip != nullptr && *t.skip != 0) return;
+    if (step != nullptr) first = *step == 1;   // device-side step count: the momentum buffers start with the first COUNTED step
     const int ti = t.chunk_tensor[blockIdx.x];
     const long long n = t.numel[ti];
     const long long i0 = (long long)t.chunk_index[blockIdx.x] * OPT_CHUNK;
@@ -74,8 +81,12 @@ __global__ void __launch_bounds__(256) sgd_kernel(const OptTables t, float lr, f
 // torch.optim.Adam (no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 __global__ void __launch_bounds__(256) adam_kernel(const OptTables t, float lr, float b1, float b2, float eps, float wd,
-                                                   float bc1, float bc2_sqrt) {
+                                                   float bc1, float bc2_sqrt, const int *step, double b1d, double b2d) {
     if (t.skip != nullptr && *t.skip != 0) return;
+    if (step != nullptr) {                      // bias corrections from the device-side step count (see adagrad_kernel)
+        bc1 = (float)(1.0 - pow(b1d, (double)*step));
+        bc2_sqrt = (float)sqrt(1.0 - pow(b2d, (double)*step));
+    }
     const int ti = t.chunk_tensor[blockIdx.x];
     const long long n = t.numel[ti];
     const long long i0 = (long long)t.chunk_index[blockIdx.x] * OPT_CHUNK;
@@ -115,7 +126,31 @@ __global__ void __launch_bounds__(256) nonfinite_flag_kernel(const float *x, lon
     if (bad) *flag = 1;
 }
 
+// Small host tables -> device memory WITHOUT a host buffer the copy engine must read later: the values travel as kernel
+// arguments (by value, up to 2 KiB per launch), so the call is legal inside a stream capture and a replayed graph
+// re-writes the same values.  (A pinned staging buffer + asynchronous copy -- what the fused optimizers used for their
+// pointer tables until round 6 -- records an event torch's host allocator later queries: "operation not permitted on an
+// event last recorded in a capturing stream".)
+__global__ void __launch_bounds__(64) step_inc_kernel(int *step, const int *skip) {
+    if (threadIdx.x == 0 && !(skip != nullptr && *skip != 0)) *step += 1;
+}
+
+struct FillArg { unsigned v[512]; };
+__global__ void __launch_bounds__(256) fill_words_kernel(const FillArg a, unsigned *dst, int n_words) {
+    for (int i = threadIdx.x; i < n_words; i += 256) dst[i] = a.v[i];
+}
+
 }  // namespace
+
+extern "C" int ds_fill_bytes(void *dst, const void *host_src, int bytes, void *stream) {
+    DS_REQUIRE(dst && host_src, DS_ERR_NULL);
+    DS_REQUIRE(bytes > 0 && bytes <= (int)sizeof(FillArg) && (bytes & 3) == 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((((size_t)dst) & 3) == 0, DS_ERR_ALIGNMENT);
+    FillArg a;
+    memcpy(a.v, host_src, (size_t)bytes);
+    DS_LAUNCH(fill_words_kernel, 1, 256, 0, stream, a, (unsigned *)dst, bytes / 4);
+    return ds_last_launch_error();
+}
 
 extern "C" int ds_nonfinite_flag_f32(const float *x, long long n, int *flag, void *stream) {
     DS_REQUIRE(x && flag, DS_ERR_NULL);
@@ -153,7 +188,27 @@ extern "C" int ds_adagrad_step_f32(DS_OPT_ARGS, float clr, float weight_decay, f
     if (rc) return rc;
     DS_REQUIRE(state1, DS_ERR_NULL);
     t.skip = skip_flag;
-    DS_LAUNCH(adagrad_kernel, n_chunks, 256, 0, stream, t, clr, weight_decay, eps);
+    DS_LAUNCH(adagrad_kernel, n_chunks, 256, 0, stream, t, clr, weight_decay, eps, (const int *)nullptr, 0.0, 0.0);
+    return ds_last_launch_error();
+}
+
+// the same step with the step count read on the device (`step_count`, int32 [1], see ds_optim_step_inc): for steps that
+// are captured into a HIP graph and replayed
+extern "C" int ds_adagrad_step_dev_f32(DS_OPT_ARGS, double lr, double lr_decay, float weight_decay, float eps,
+                                       const int *step_count, const int *skip_flag, void *stream) {
+    OptTables t;
+    int rc = opt_tables(t, params, grads, state1, state2, numel, chunk_tensor, chunk_index, n_chunks);
+    if (rc) return rc;
+    DS_REQUIRE(state1 && step_count, DS_ERR_NULL);
+    t.skip = skip_flag;
+    DS_LAUNCH(adagrad_kernel, n_chunks, 256, 0, stream, t, 0.0f, weight_decay, eps, step_count, lr, lr_decay);
+    return ds_last_launch_error();
+}
+
+// *step_count += 1 unless *skip_flag is set (torch.amp.GradScaler does not count a skipped step either)
+extern "C" int ds_optim_step_inc(int *step_count, const int *skip_flag, void *stream) {
+    DS_REQUIRE(step_count, DS_ERR_NULL);
+    DS_LAUNCH(step_inc_kernel, 1, 64, 0, stream, step_count, skip_flag);
     return ds_last_launch_error();
 }
 
@@ -164,7 +219,18 @@ extern "C" int ds_sgd_step_f32(DS_OPT_ARGS, float lr, float momentum, float damp
     if (rc) return rc;
     DS_REQUIRE(momentum == 0.0f || state1, DS_ERR_NULL);
     t.skip = skip_flag;
-    DS_LAUNCH(sgd_kernel, n_chunks, 256, 0, stream, t, lr, momentum, dampening, weight_decay, first_step);
+    DS_LAUNCH(sgd_kernel, n_chunks, 256, 0, stream, t, lr, momentum, dampening, weight_decay, first_step, (const int *)nullptr);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_sgd_step_dev_f32(DS_OPT_ARGS, float lr, float momentum, float dampening, float weight_decay,
+                                   const int *step_count, const int *skip_flag, void *stream) {
+    OptTables t;
+    int rc = opt_tables(t, params, grads, state1, state2, numel, chunk_tensor, chunk_index, n_chunks);
+    if (rc) return rc;
+    DS_REQUIRE((momentum == 0.0f || state1) && step_count, DS_ERR_NULL);
+    t.skip = skip_flag;
+    DS_LAUNCH(sgd_kernel, n_chunks, 256, 0, stream, t, lr, momentum, dampening, weight_decay, 0, step_count);
     return ds_last_launch_error();
 }
 
@@ -176,6 +242,18 @@ extern "C" int ds_adam_step_f32(DS_OPT_ARGS, float lr, float beta1, float beta2,
     DS_REQUIRE(state1 && state2, DS_ERR_NULL);
     t.skip = skip_flag;
     DS_LAUNCH(adam_kernel, n_chunks, 256, 0, stream, t, lr, beta1, beta2, eps, weight_decay, bias_correction1,
-              bias_correction2_sqrt);
+              bias_correction2_sqrt, (const int *)nullptr, 0.0, 0.0);
+    return ds_last_launch_error();
+}
+
+extern "C" int ds_adam_step_dev_f32(DS_OPT_ARGS, float lr, double beta1, double beta2, float eps, float weight_decay,
+                                    const int *step_count, const int *skip_flag, void *stream) {
+    OptTables t;
+    int rc = opt_tables(t, params, grads, state1, state2, numel, chunk_tensor, chunk_index, n_chunks);
+    if (rc) return rc;
+    DS_REQUIRE(state1 && state2 && step_count, DS_ERR_NULL);
+    t.skip = skip_flag;
+    DS_LAUNCH(adam_kernel, n_chunks, 256, 0, stream, t, lr, (float)beta1, (float)beta2, eps, weight_decay, 1.0f, 1.0f, step_count,
+              beta1, beta2);
     return ds_last_launch_error();
 }

@@ -31,6 +31,37 @@ class _FusedBase(torch.optim.Optimizer):
     # torch.amp.GradScaler, which does not call optimizer.step() at all: undoing them would need the flag on the host.
     _skip_tensor = None
     skip_source = None
+    # Device-side step count (enable_device_step): Adagrad's decayed learning rate and Adam's bias corrections are computed
+    # inside the kernels from an int32 counter on the device that every step() bumps there -- a step captured into a HIP
+    # graph (train_graph.GraphedTripletStep) then replays with the count of the replay, not of the capture.
+    _dev_step = None
+
+    def enable_device_step(self):
+        """From now on the step count that enters the update lives on the device (initialised from the host-side counts;
+        all parameters must share one count).  Host-side `state[p]["step"]` keeps advancing in eager steps; after graph
+        replays `sync_host_steps()` brings it up to date (one host synchronisation)."""
+        params = [p for g in self.param_groups for p in g["params"]]
+        counts = {float(self.state[p]["step"]) for p in params if "step" in self.state.get(p, {})}
+        if len(counts) > 1:
+            raise RuntimeError(f"device-side step count needs one count for all parameters, found {sorted(counts)}")
+        start = int(counts.pop()) if counts else 0
+        if start == 0 and any("momentum_buffer" in self.state.get(p, {}) for p in params):
+            start = 1                           # SGD keeps no step count: buffers that exist are past their first step
+        self._dev_step = torch.full((1,), start, dtype=torch.int32, device=params[0].device)
+        return self
+
+    def sync_host_steps(self):
+        if self._dev_step is None:
+            return
+        n = float(self._dev_step.item())
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = self.state.get(p)
+                if st is not None and "step" in st:
+                    st["step"].fill_(n)
+
+    def _bump_dev_step(self, eng, params):
+        eng.lib.call("ds_optim_step_inc", eng._p(self._dev_step), self._skip(eng, params), eng._stream(params[0]))
 
     @property
     def skip_flag(self):
@@ -104,42 +135,53 @@ class _FusedBase(torch.optim.Optimizer):
                 if k not in st:
                     st[k] = torch.zeros_like(p, memory_format=torch.preserve_format)
             states.append(st)
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) + tuple(st[k].data_ptr() for k in state_keys)
-                    for p, st in zip(params, states))
+        # Two caches.  STATIC: pointer tables of the parameters and their state, element counts, the chunk table -- rebuilt
+        # only when the set of tensors / their storage changes.  PER STEP: the gradients' pointers (fresh tensors after every
+        # zero_grad(set_to_none=True); the caching allocator usually hands the same blocks back, then nothing is written).
+        # Tables are written by ds_fill_bytes -- values as kernel arguments, no pinned staging buffer: nothing blocks the
+        # host, and the step can be captured into a HIP graph (a pinned asynchronous copy leaves an event behind that
+        # torch's host allocator later queries: illegal for an event recorded in a capturing stream).
+        eng = self._eng()
+        dev = params[0].device
+        skey = tuple((p.data_ptr(),) + tuple(st[k].data_ptr() for k in state_keys) for p, st in zip(params, states))
         caches = group.setdefault("_ds_cache", {})
         cache = caches.get(len(params))
-        if cache is None or cache["key"] != key:
-            dev = params[0].device
-            chunk = self._eng().lib.raw("ds_optim_chunk_elems")()
 
-            pinned = []                 # staging copies stay alive in the cache until the async uploads have run
+        def fill(values, dtype, out=None):
+            import numpy as np
+            host = np.ascontiguousarray(np.asarray(values, dtype=np.int64 if dtype == torch.int64 else np.int32))
+            if out is None:
+                out = torch.empty(host.size, dtype=dtype, device=dev)
+            if dev.type != "cuda" and not getattr(eng.lib, "host_memory", False):
+                raise RuntimeError("fused optimizers need parameters on a ROCm device")
+            raw, nbytes, st_ = host.ctypes.data, host.nbytes, eng._stream(out)
+            for off in range(0, nbytes, 2048):
+                eng.lib.call("ds_fill_bytes", ctypes.c_void_p(out.data_ptr() + off), ctypes.c_void_p(raw + off),
+                             min(2048, nbytes - off), st_)
+            return out
 
-            def upload(values, dtype):
-                # Gradients are fresh tensors every step (zero_grad(set_to_none=True)), so these tables are rebuilt
-                # per step: from pinned memory and without blocking -- a pageable .to(device) would make the host
-                # wait for the whole backward pass before it can enqueue anything else.
-                h = torch.tensor(values, dtype=dtype).pin_memory() if dev.type == "cuda" else torch.tensor(values, dtype=dtype)
-                pinned.append(h)
-                return h.to(dev, non_blocking=True)
-
-            def ptr_table(ts):
-                return upload([t.data_ptr() for t in ts], torch.int64)
-
+        if cache is None or cache["key"] != skey:
+            chunk = eng.lib.raw("ds_optim_chunk_elems")()
             ct, ci = [], []
             for i, p in enumerate(params):
                 for c in range((p.numel() + chunk - 1) // chunk):
                     ct.append(i)
                     ci.append(c)
             cache = {
-                "key": key,
-                "params": ptr_table(params), "grads": ptr_table([p.grad for p in params]),
-                "s1": ptr_table([st[state_keys[0]] for st in states]) if state_keys else None,
-                "s2": ptr_table([st[state_keys[1]] for st in states]) if need_state2 else None,
-                "numel": upload([p.numel() for p in params], torch.int64),
-                "ct": upload(ct, torch.int32), "ci": upload(ci, torch.int32),
-                "n_chunks": len(ct), "pinned": pinned,
+                "key": skey,
+                "params": fill([p.data_ptr() for p in params], torch.int64),
+                "s1": fill([st[state_keys[0]].data_ptr() for st in states], torch.int64) if state_keys else None,
+                "s2": fill([st[state_keys[1]].data_ptr() for st in states], torch.int64) if need_state2 else None,
+                "numel": fill([p.numel() for p in params], torch.int64),
+                "ct": fill(ct, torch.int32), "ci": fill(ci, torch.int32),
+                "n_chunks": len(ct), "grads": None, "gkey": None,
             }
             caches[len(params)] = cache
+        gkey = tuple(p.grad.data_ptr() for p in params)
+        if cache["gkey"] != gkey or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            # (inside a capture the write is always enqueued: the graph must own a node that sets the table it replays with)
+            cache["grads"] = fill(list(gkey), torch.int64, out=cache["grads"])
+            cache["gkey"] = gkey
         return params, states, cache
 
     @staticmethod
@@ -171,14 +213,23 @@ class FusedAdagrad(_FusedBase):
 
     def _step_groups(self, eng):
         for group in self.param_groups:
-            for part in self._partitions(group).values():
+            parts = self._partitions(group)
+            if self._dev_step is not None and len(parts) > 1:
+                raise RuntimeError("device-side step count: parameters with different step counts in one group")
+            for part in parts.values():
                 params, states, c = self._tables(group, ["sum"], False, params=part)
                 for st in states:
                     st["step"] += 1
-                step = float(states[0]["step"])
-                clr = group["lr"] / (1 + (step - 1) * group["lr_decay"])
-                eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
-                             self._skip(eng, params), eng._stream(params[0]))
+                if self._dev_step is not None:
+                    self._bump_dev_step(eng, params)
+                    eng.lib.call("ds_adagrad_step_dev_f32", *self._args(eng, c), float(group["lr"]), float(group["lr_decay"]),
+                                 group["weight_decay"], group["eps"], eng._p(self._dev_step), self._skip(eng, params),
+                                 eng._stream(params[0]))
+                else:
+                    step = float(states[0]["step"])
+                    clr = group["lr"] / (1 + (step - 1) * group["lr_decay"])
+                    eng.lib.call("ds_adagrad_step_f32", *self._args(eng, c), clr, group["weight_decay"], group["eps"],
+                                 self._skip(eng, params), eng._stream(params[0]))
                 self._bump_versions(params)
 
 
@@ -199,11 +250,19 @@ class FusedSGD(_FusedBase):
 
     def _step_groups(self, eng):
         for group in self.param_groups:
-            for fresh, part in self._partitions(group, fresh_key="momentum_buffer").items():
+            parts = self._partitions(group, fresh_key="momentum_buffer")
+            if self._dev_step is not None and len(parts) > 1:
+                raise RuntimeError("device-side step count: parameters with and without momentum buffers in one group")
+            for fresh, part in parts.items():
                 params, states, c = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False,
                                                  with_step=False, params=part)
-                eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
-                             group["weight_decay"], int(fresh), self._skip(eng, params), eng._stream(params[0]))
+                if self._dev_step is not None:          # "first step" = the step that counts 1 on the device
+                    self._bump_dev_step(eng, params)
+                    eng.lib.call("ds_sgd_step_dev_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
+                                 group["weight_decay"], eng._p(self._dev_step), self._skip(eng, params), eng._stream(params[0]))
+                else:
+                    eng.lib.call("ds_sgd_step_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
+                                 group["weight_decay"], int(fresh), self._skip(eng, params), eng._stream(params[0]))
                 self._bump_versions(params)
 
 
@@ -224,15 +283,23 @@ class FusedAdam(_FusedBase):
 
     def _step_groups(self, eng):
         for group in self.param_groups:
-            for part in self._partitions(group).values():
+            parts = self._partitions(group)
+            if self._dev_step is not None and len(parts) > 1:
+                raise RuntimeError("device-side step count: parameters with different step counts in one group")
+            for part in parts.values():
                 params, states, c = self._tables(group, ["exp_avg", "exp_avg_sq"], True, params=part)
                 for st in states:
                     st["step"] += 1
                 step = float(states[0]["step"])
                 b1, b2 = group["betas"]
-                eng.lib.call("ds_adam_step_f32", *self._args(eng, c), group["lr"], b1, b2, group["eps"],
-                             group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), self._skip(eng, params),
-                             eng._stream(params[0]))
+                if self._dev_step is not None:
+                    self._bump_dev_step(eng, params)
+                    eng.lib.call("ds_adam_step_dev_f32", *self._args(eng, c), group["lr"], float(b1), float(b2), group["eps"],
+                                 group["weight_decay"], eng._p(self._dev_step), self._skip(eng, params), eng._stream(params[0]))
+                else:
+                    eng.lib.call("ds_adam_step_f32", *self._args(eng, c), group["lr"], b1, b2, group["eps"],
+                                 group["weight_decay"], 1 - b1 ** step, math.sqrt(1 - b2 ** step), self._skip(eng, params),
+                                 eng._stream(params[0]))
                 self._bump_versions(params)
 
 

@@ -586,6 +586,25 @@ int ds_assemble_crops_f32(const float *features, const long long *row_start, con
  *      the same arithmetic.  `params`, `grads`, `state1`, `state2` are DEVICE arrays of device pointers
  *      (one per tensor), `numel` a device int64 array; workgroup b updates elements
  *      [chunk_index[b]*ds_optim_chunk_elems(), +ds_optim_chunk_elems()) of tensor chunk_tensor[b]. ---- */
+/* Steps that are captured into a HIP graph and replayed: the step count lives on the device (`step_count`, int32 [1],
+ * bumped by ds_optim_step_inc once per optimizer step unless the skip flag is set) and Adagrad's decayed learning rate /
+ * Adam's bias corrections are computed from it inside the kernel, in double precision as the host computes them. */
+int ds_optim_step_inc(int *step_count, const int *skip_flag, void *stream);
+int ds_adagrad_step_dev_f32(const void *params, const void *grads, const void *state1, const void *state2,
+                            const long long *numel, const int *chunk_tensor, const int *chunk_index, int n_chunks,
+                            double lr, double lr_decay, float weight_decay, float eps, const int *step_count,
+                            const int *skip_flag, void *stream);
+int ds_sgd_step_dev_f32(const void *params, const void *grads, const void *state1, const void *state2,
+                        const long long *numel, const int *chunk_tensor, const int *chunk_index, int n_chunks, float lr,
+                        float momentum, float dampening, float weight_decay, const int *step_count, const int *skip_flag,
+                        void *stream);      /* the momentum buffers start at the step that counts 1 */
+int ds_adam_step_dev_f32(const void *params, const void *grads, const void *state1, const void *state2,
+                         const long long *numel, const int *chunk_tensor, const int *chunk_index, int n_chunks, float lr,
+                         double beta1, double beta2, float eps, float weight_decay, const int *step_count,
+                         const int *skip_flag, void *stream);
+/* `bytes` (<= 2048, a multiple of 4) of a HOST table -> device memory as kernel arguments: no staging buffer, legal inside a
+ * stream capture (a replayed graph writes the same values again).  The fused optimizers' pointer tables travel this way. */
+int ds_fill_bytes(void *dst, const void *host_src, int bytes, void *stream);
 int ds_optim_chunk_elems(void);
 int ds_adagrad_step_f32(const void *params, const void *grads, const void *state1, const void *state2,
                         const long long *numel, const int *chunk_tensor, const int *chunk_index,

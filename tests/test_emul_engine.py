@@ -297,6 +297,49 @@ def test_fused_optimizers_match_torch(kind):
     ref.load_state_dict(sd)
 
 
+@pytest.mark.parametrize("kind", ["adagrad", "sgd", "adam"])
+def test_fused_optimizers_device_side_step_count(kind):
+    """enable_device_step() (what train_graph.GraphedTripletStep uses: a captured step must replay with the step count of
+    the replay): Adagrad's decayed learning rate, Adam's bias corrections and SGD's "first step" come from an int32 counter
+    on the device that each step() bumps there.  Same trajectories as torch.optim over five steps; a step skipped by the
+    overflow flag neither updates nor counts; sync_host_steps() brings state[p]['step'] up to date."""
+    from deepspeaker_pytorch_amd import optim as fo
+    eng = Engine(emul_lib())
+    rs = np.random.RandomState(5)
+    shapes = [(64, 1, 5, 5), (17,), (20000,)]
+    ref_p = [torch.nn.Parameter(torch.from_numpy(rs.randn(*s).astype(np.float32))) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    if kind == "adagrad":
+        ref, ours = torch.optim.Adagrad(ref_p, lr=0.1, lr_decay=1e-2), fo.FusedAdagrad(our_p, lr=0.1, lr_decay=1e-2)
+    elif kind == "sgd":
+        ref = torch.optim.SGD(ref_p, lr=0.1, momentum=0.9, dampening=0.9)
+        ours = fo.FusedSGD(our_p, lr=0.1, momentum=0.9, dampening=0.9)
+    else:
+        ref, ours = torch.optim.Adam(ref_p, lr=0.01), fo.FusedAdam(our_p, lr=0.01)
+    ours._engine = eng
+    ours.enable_device_step()
+    flag = torch.zeros(1, dtype=torch.int32)
+    ours.skip_flag = flag
+    for it in range(6):
+        for a, b in zip(ref_p, our_p):
+            g = torch.from_numpy(rs.randn(*a.shape).astype(np.float32))
+            a.grad, b.grad = g.clone(), g.clone()
+        if it == 2:                             # an overflowed step: skipped on the device, and NOT counted there
+            flag.fill_(1)
+            before = [b.detach().clone() for b in our_p]
+            ours.step()
+            assert all(torch.equal(b.detach(), k) for b, k in zip(our_p, before)) and int(ours._dev_step) == 2 and int(flag) == 0
+            continue
+        ref.step()
+        ours.step()
+        for k, (a, b) in enumerate(zip(ref_p, our_p)):
+            assert rel_err(b.detach().numpy(), a.detach().numpy()) < 2e-6, (kind, it, k)
+    assert int(ours._dev_step) == 5
+    ours.sync_host_steps()
+    if kind != "sgd":
+        assert all(float(ours.state[p]["step"]) == 5.0 for p in our_p)
+
+
 def test_scoring_and_roc(golden):
     from deepspeaker_pytorch_amd import scoring
     scoring._engine_override = Engine(emul_lib())

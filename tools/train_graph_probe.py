@@ -62,7 +62,11 @@ le = []
 step = make_step(m, opt, le)
 for _ in range(10):
     step()
-print(f"[{tp} {optn}] eager ms/step:", [round(v, 3) for v in regions(step)])
+if "--no-eager-timing" not in sys.argv:
+    print(f"[{tp} {optn}] eager ms/step:", [round(v, 3) for v in regions(step)])
+else:
+    for _ in range(4):
+        step()
 eager_losses = [float(v) for v in le[:14]]
 
 # graph
@@ -84,7 +88,10 @@ try:
         make_step(m, opt, step_losses)()
         static_loss.append(step_losses[0])
 except Exception as exc:
-    print("CAPTURE FAILED:", type(exc).__name__, str(exc)[:600])
+    import traceback
+    print("CAPTURE FAILED:", type(exc).__name__, str(exc)[:300])
+    tb = traceback.format_exc().splitlines()
+    print("\n".join(l for l in tb if "File" in l or "Error" in l)[-3000:])
     sys.exit(1)
 torch.cuda.synchronize()
 traj = [float(v) for v in lg[:3]]
