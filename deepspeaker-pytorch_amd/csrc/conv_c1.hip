@@ -109,15 +109,12 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_kernel(const Conv1K p) {
 // OUT16 / STATS (the output type and the BatchNorm partial sums) are compile-time: the store loop is straight-line
 // code; the affine is data (identity when off) and the clip a select.
 template <bool OUT16, bool STATS>
-__global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, unsigned y_bytes, int n_tiles) {
-    // PERSISTENT (round 6): the grid is what the chip holds (three workgroups per CU) and a workgroup walks tiles
-    // (image, 16 output rows) with a static stride.  What is tile-invariant -- 32 scalar filter loads and 16 conversions
-    // per lane for the hi / lo fragments, the tap offsets, the BatchNorm rows -- is built once per workgroup instead of
-    // once per tile (3840 tiles at 768 utterances), and the NEXT tile's input rows (one contiguous span) are requested
-    // before the current tile is computed.  Same arithmetic per output element: results are unchanged bit for bit.
+__global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, unsigned y_bytes) {
     float *lds = ds_dynamic_lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.x / p.tiles_per_img;
+    const int r0 = (blockIdx.x - b * p.tiles_per_img) * C1_RT;
     constexpr int ROWS_IN = 2 * (C1_RT - 1) + 5;
     constexpr int TP = C1_COUT + 4;                         // transposition-buffer row pitch (floats)
     const int n_in = ROWS_IN * p.cols_in;
@@ -148,6 +145,48 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
             const int t = 16 * ks + 8 * lhi + i;
             toff[ks][i] = t < 25 ? (t / 5) * p.cols_in + (t % 5) : 0;      // padding taps: any finite word (x 0)
         }
+
+    // stage the zero-padded input tile.  The tile's image rows are whole rows of x, i.e. ONE contiguous span:
+    // every thread requests its 16-byte pieces up front (a few independent loads instead of a chain of ~10
+    // dependent word loads), zero-fills the tile meanwhile, then drops the pieces into the padded rows.
+    const float *xb = p.x + (size_t)b * p.H * p.W;
+    if ((p.W & 3) == 0 && ROWS_IN * p.W <= 4 * 256 * C1_VSLOTS) {
+        const int h_first = 2 * r0 - 2;
+        const int h_lo = h_first < 0 ? 0 : h_first;
+        const int h_hi = (h_first + ROWS_IN < p.H) ? h_first + ROWS_IN : p.H;          // image rows [h_lo, h_hi)
+        const int n4 = (h_hi - h_lo) * (p.W >> 2);
+        const f32x4 *src = (const f32x4 *)(xb + (size_t)h_lo * p.W);
+        f32x4 piece[C1_VSLOTS];
+#pragma unroll
+        for (int it = 0; it < C1_VSLOTS; ++it) {
+            const int i = tid + it * 256;
+            piece[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < n4) piece[it] = src[i];
+        }
+        for (int i = tid; i < n_in; i += 256) lds[i] = 0.0f;
+        __syncthreads();
+        const int w4 = p.W >> 2;
+        const float rcp_w4 = 1.0f / (float)w4;
+#pragma unroll
+        for (int it = 0; it < C1_VSLOTS; ++it) {
+            const int i = tid + it * 256;
+            if (i < n4) {
+                const int rr = ds_div_small(i, w4, rcp_w4), q = i - rr * w4;
+                float *dst = lds + (h_lo - h_first + rr) * p.cols_in + 2 + 4 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j] = piece[it][j];
+            }
+        }
+    } else {
+        const float rcp_ci = 1.0f / (float)p.cols_in;
+        for (int i = tid; i < n_in; i += 256) {
+            const int rr = ds_div_small(i, p.cols_in, rcp_ci), cc = i - rr * p.cols_in;
+            const int h = 2 * r0 - 2 + rr, w = cc - 2;
+            lds[i] = (h >= 0 && h < p.H && w >= 0 && w < p.W) ? xb[(size_t)h * p.W + w] : 0.0f;
+        }
+    }
+    __syncthreads();
+
     const int n_pix = C1_RT * p.Wo, n_sub = (n_pix + 31) >> 5;
     const float rcp_wo = 1.0f / (float)p.Wo;
     // lanes per pixel row, rows per store instruction: a lane owns 4 channels (16 bytes of f32) or 8 (16 bytes of fp16)
@@ -164,171 +203,112 @@ __global__ void __launch_bounds__(256) conv5x5s2_c1_bf16_kernel(const Conv1K p, 
     }
     const bool clip = p.flags & DS_EPI_CLIP;
     const ds_buffer ybuf = ds_make_buffer(p.y, y_bytes);
-
-    // The tile's image rows are whole rows of x, i.e. ONE contiguous span: every thread requests its 16-byte pieces up
-    // front (a few independent loads instead of a chain of ~10 dependent word loads) -- one tile AHEAD of their use.
-    const bool spans = (p.W & 3) == 0 && ROWS_IN * p.W <= 4 * 256 * C1_VSLOTS;
-    const int w4 = p.W >> 2;
-    const float rcp_w4 = 1.0f / (float)(w4 > 0 ? w4 : 1), rcp_tpi = 1.0f / (float)p.tiles_per_img;
-    f32x4 piece[C1_VSLOTS];
-    auto request = [&](int t) {
-        const int b = ds_div_small(t, p.tiles_per_img, rcp_tpi);
-        const int r0 = (t - b * p.tiles_per_img) * C1_RT;
-        const int h_first = 2 * r0 - 2;
-        const int h_lo = h_first < 0 ? 0 : h_first;
-        const int h_hi = (h_first + ROWS_IN < p.H) ? h_first + ROWS_IN : p.H;          // image rows [h_lo, h_hi)
-        const int n4 = (h_hi - h_lo) * w4;
-        const f32x4 *src = (const f32x4 *)(p.x + (size_t)b * p.H * p.W + (size_t)h_lo * p.W);
+    const int pix0 = (b * p.Ho + r0) * p.Wo;               // first output pixel of the tile
+    const int rows_left = p.Ho - r0;
+    const int pix_lim = (rows_left < C1_RT ? rows_left : C1_RT) * p.Wo;
+    float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sub = wave; sub < n_sub; sub += 4) {
+        // ---- B fragments: 16 taps of this lane's pixel ----
+        const int m = sub * 32 + l31;
+        const int r = ds_div_small(m, p.Wo, rcp_wo), c = m - r * p.Wo;
+        const float *in = lds + ((m < n_pix) ? (2 * r) * p.cols_in + 2 * c : 0);
+        ds_u32x4 xh[2], xl[2];
 #pragma unroll
-        for (int it = 0; it < C1_VSLOTS; ++it) {
-            const int i = tid + it * 256;
-            piece[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < n4) piece[it] = src[i];
-        }
-    };
-    if (spans && (int)blockIdx.x < n_tiles) request((int)blockIdx.x);
-
-    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
-        const int b = ds_div_small(tile, p.tiles_per_img, rcp_tpi);
-        const int r0 = (tile - b * p.tiles_per_img) * C1_RT;
-        // ---- stage the zero-padded input tile ----
-        if (spans) {
-            const int h_first = 2 * r0 - 2;
-            const int h_lo = h_first < 0 ? 0 : h_first;
-            const int h_hi = (h_first + ROWS_IN < p.H) ? h_first + ROWS_IN : p.H;
-            const int n4 = (h_hi - h_lo) * w4;
-            for (int i = tid; i < n_in; i += 256) lds[i] = 0.0f;
-            __syncthreads();
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int it = 0; it < C1_VSLOTS; ++it) {
-                const int i = tid + it * 256;
-                if (i < n4) {
-                    const int rr = ds_div_small(i, w4, rcp_w4), q = i - rr * w4;
-                    float *dst = lds + (h_lo - h_first + rr) * p.cols_in + 2 + 4 * q;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dst[j] = piece[it][j];
-                }
+            for (int i = 0; i < 8; i += 2) {            // two taps per packed conversion
+                unsigned hi2, lo2;
+                ds_split_bf16x2(in[toff[ks][i]], in[toff[ks][i + 1]], hi2, lo2);
+                xh[ks][i >> 1] = hi2;
+                xl[ks][i >> 1] = lo2;
             }
-        } else {
-            const float *xb = p.x + (size_t)b * p.H * p.W;
-            const float rcp_ci = 1.0f / (float)p.cols_in;
-            for (int i = tid; i < n_in; i += 256) {
-                const int rr = ds_div_small(i, p.cols_in, rcp_ci), cc = i - rr * p.cols_in;
-                const int h = 2 * r0 - 2 + rr, w = cc - 2;
-                lds[i] = (h >= 0 && h < p.H && w >= 0 && w < p.W) ? xb[(size_t)h * p.W + w] : 0.0f;
+        f32x16 acc[2];
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[ns][q] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], __builtin_bit_cast(bf16x8, xl[ks]), acc[ns]);
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_lo[ks][ns], __builtin_bit_cast(bf16x8, xh[ks]), acc[ns]);
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], __builtin_bit_cast(bf16x8, xh[ks]), acc[ns]);
+        }
+        // ---- epilogue of the sub-tile: lane = pixel, register quad g = channels 8g + 4*lhi .. +3 ----
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[ns][4 * g + j];
+                *(f32x4 *)(tb + l31 * TP + ns * 32 + 8 * g + 4 * lhi) = v;
+            }
+        ds_wave_sync();
+#pragma unroll
+        for (int k = 0; k < NRI; ++k) {
+            // the tile's pixels are consecutive rows of one image: pixel pm of the tile is pixel pix0 + pm of y
+            const int pm = sub * 32 + k * PPI + my_p;
+            const bool live = pm < pix_lim;
+            const unsigned eoff = (unsigned)((pix0 + pm) * C1_COUT + my_c);
+            const unsigned voff = live ? eoff * 4u : DS_BUFFER_OOB;
+            f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c);
+            if (OUT16) {
+                // fp16 activations for the fp16 convolution path: packed f32 affine, packed conversion, packed fp16 clip
+                // (0 and 20 are fp16 numbers and rounding is monotonic: clip(round(t)) == round(clip(t)))
+                const f32x4 vb = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c + 4);
+                const f32x4 ta = v * sc4 + sh4, tb4 = vb * sc4b + sh4b;
+                f16x8 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = (_Float16)ta[j];
+                    h[4 + j] = (_Float16)tb4[j];
+                }
+                const f16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {20, 20, 20, 20, 20, 20, 20, 20};
+                const f16x8 hc = __builtin_elementwise_min(__builtin_elementwise_max(h, lo), hi);
+                h = clip ? hc : h;
+                ds_buffer_store_out_f32x4(ybuf, live ? eoff * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[j];
+                if (STATS) {
+                    ps1[j] += live ? t : 0.0f;
+                    ps2[j] += live ? t * t : 0.0f;
+                }
+                t = t * sc4[j] + sh4[j];
+                v[j] = clip ? fminf(fmaxf(t, 0.0f), 20.0f) : t;       // a select, not a branch (NaN passes when off)
+            }
+            ds_buffer_store_out_f32x4(ybuf, voff, v);
+        }
+        ds_wave_sync();
+    }
+    if (STATS && !OUT16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ps1[j] += ds_shfl_xor(ps1[j], 16);
+            ps2[j] += ds_shfl_xor(ps2[j], 16);
+            ps1[j] += ds_shfl_xor(ps1[j], 32);
+            ps2[j] += ds_shfl_xor(ps2[j], 32);
+            if (my_p == 0) {
+                red[(wave * C1_COUT + my_c + j) * 2 + 0] = ps1[j];
+                red[(wave * C1_COUT + my_c + j) * 2 + 1] = ps2[j];
             }
         }
         __syncthreads();
-        if (spans && tile + (int)gridDim.x < n_tiles) request(tile + (int)gridDim.x);   // in flight while this tile is computed
-
-        const int pix0 = (b * p.Ho + r0) * p.Wo;               // first output pixel of the tile
-        const int rows_left = p.Ho - r0;
-        const int pix_lim = (rows_left < C1_RT ? rows_left : C1_RT) * p.Wo;
-        float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int sub = wave; sub < n_sub; sub += 4) {
-            // ---- B fragments: 16 taps of this lane's pixel ----
-            const int m = sub * 32 + l31;
-            const int r = ds_div_small(m, p.Wo, rcp_wo), c = m - r * p.Wo;
-            const float *in = lds + ((m < n_pix) ? (2 * r) * p.cols_in + 2 * c : 0);
-            ds_u32x4 xh[2], xl[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {            // two taps per packed conversion
-                    unsigned hi2, lo2;
-                    ds_split_bf16x2(in[toff[ks][i]], in[toff[ks][i + 1]], hi2, lo2);
-                    xh[ks][i >> 1] = hi2;
-                    xl[ks][i >> 1] = lo2;
-                }
-            f32x16 acc[2];
-#pragma unroll
-            for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[ns][q] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], __builtin_bit_cast(bf16x8, xl[ks]), acc[ns]);
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_lo[ks][ns], __builtin_bit_cast(bf16x8, xh[ks]), acc[ns]);
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns) acc[ns] = ds_mfma_32x32x16_bf16(w_hi[ks][ns], __builtin_bit_cast(bf16x8, xh[ks]), acc[ns]);
+        if (tid < C1_COUT) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int s = 0; s < 4; ++s) {
+                a1 += red[(s * C1_COUT + tid) * 2 + 0];
+                a2 += red[(s * C1_COUT + tid) * 2 + 1];
             }
-            // ---- epilogue of the sub-tile: lane = pixel, register quad g = channels 8g + 4*lhi .. +3 ----
-#pragma unroll
-            for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[ns][4 * g + j];
-                    *(f32x4 *)(tb + l31 * TP + ns * 32 + 8 * g + 4 * lhi) = v;
-                }
-            ds_wave_sync();
-#pragma unroll
-            for (int k = 0; k < NRI; ++k) {
-                // the tile's pixels are consecutive rows of one image: pixel pm of the tile is pixel pix0 + pm of y
-                const int pm = sub * 32 + k * PPI + my_p;
-                const bool live = pm < pix_lim;
-                const unsigned eoff = (unsigned)((pix0 + pm) * C1_COUT + my_c);
-                const unsigned voff = live ? eoff * 4u : DS_BUFFER_OOB;
-                f32x4 v = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c);
-                if (OUT16) {
-                    // fp16 activations for the fp16 convolution path: packed f32 affine, packed conversion, packed fp16 clip
-                    // (0 and 20 are fp16 numbers and rounding is monotonic: clip(round(t)) == round(clip(t)))
-                    const f32x4 vb = *(const f32x4 *)(tb + (k * PPI + my_p) * TP + my_c + 4);
-                    const f32x4 ta = v * sc4 + sh4, tb4 = vb * sc4b + sh4b;
-                    f16x8 h;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        h[j] = (_Float16)ta[j];
-                        h[4 + j] = (_Float16)tb4[j];
-                    }
-                    const f16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {20, 20, 20, 20, 20, 20, 20, 20};
-                    const f16x8 hc = __builtin_elementwise_min(__builtin_elementwise_max(h, lo), hi);
-                    h = clip ? hc : h;
-                    ds_buffer_store_out_f32x4(ybuf, live ? eoff * 2u : DS_BUFFER_OOB, __builtin_bit_cast(f32x4, h));
-                    continue;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = v[j];
-                    if (STATS) {
-                        ps1[j] += live ? t : 0.0f;
-                        ps2[j] += live ? t * t : 0.0f;
-                    }
-                    t = t * sc4[j] + sh4[j];
-                    v[j] = clip ? fminf(fmaxf(t, 0.0f), 20.0f) : t;       // a select, not a branch (NaN passes when off)
-                }
-                ds_buffer_store_out_f32x4(ybuf, voff, v);
-            }
-            ds_wave_sync();
+            float *dst = p.stats + ((size_t)blockIdx.x * C1_COUT + tid) * 2;
+            dst[0] = a1;
+            dst[1] = a2;
         }
-        if (STATS && !OUT16) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ps1[j] += ds_shfl_xor(ps1[j], 16);
-                ps2[j] += ds_shfl_xor(ps2[j], 16);
-                ps1[j] += ds_shfl_xor(ps1[j], 32);
-                ps2[j] += ds_shfl_xor(ps2[j], 32);
-                if (my_p == 0) {
-                    red[(wave * C1_COUT + my_c + j) * 2 + 0] = ps1[j];
-                    red[(wave * C1_COUT + my_c + j) * 2 + 1] = ps2[j];
-                }
-            }
-            __syncthreads();
-            if (tid < C1_COUT) {
-                float a1 = 0.f, a2 = 0.f;
-                for (int s = 0; s < 4; ++s) {
-                    a1 += red[(s * C1_COUT + tid) * 2 + 0];
-                    a2 += red[(s * C1_COUT + tid) * 2 + 1];
-                }
-                float *dst = p.stats + ((size_t)tile * C1_COUT + tid) * 2;     // one statistics row per TILE
-                dst[0] = a1;
-                dst[1] = a2;
-            }
-        }
-        __syncthreads();            // every wave is done with the input tile (and `red`) before the next one is staged
     }
 }
 
@@ -389,14 +369,11 @@ extern "C" int ds_conv5x5s2_c1_fwd_bf16(const float *x, const float *w_packed, c
     const size_t n_in = (size_t)(2 * (C1_RT - 1) + 5) * k.cols_in;
     const size_t lds = (((n_in + 3) & ~(size_t)3) + 4 * 32 * (C1_COUT + 4) + 4 * C1_COUT * 2) * 4;
     const unsigned y_bytes = (unsigned)((long long)B * k.Ho * k.Wo * C1_COUT * ((flags & DS_EPI_OUT_F16) ? 2 : 4));
-    // persistent: as many workgroups as the chip holds at once (46 KB of LDS each: three per CU), tiles by static stride
-    const int n_tiles = B * k.tiles_per_img;
-    const int resident = 3 * ds_cu_count();
-    const int grid = n_tiles < resident ? n_tiles : resident;
+    const int grid = B * k.tiles_per_img;
     const bool h16 = flags & DS_EPI_OUT_F16, st = flags & DS_EPI_STATS;
     DS_REQUIRE(!(h16 && st), DS_ERR_UNSUPPORTED);          // statistics come with the f32 (training) output
-    if (h16) DS_LAUNCH((conv5x5s2_c1_bf16_kernel<true, false>), grid, 256, lds, stream, k, y_bytes, n_tiles);
-    else if (st) DS_LAUNCH((conv5x5s2_c1_bf16_kernel<false, true>), grid, 256, lds, stream, k, y_bytes, n_tiles);
-    else DS_LAUNCH((conv5x5s2_c1_bf16_kernel<false, false>), grid, 256, lds, stream, k, y_bytes, n_tiles);
+    if (h16) DS_LAUNCH((conv5x5s2_c1_bf16_kernel<true, false>), grid, 256, lds, stream, k, y_bytes);
+    else if (st) DS_LAUNCH((conv5x5s2_c1_bf16_kernel<false, true>), grid, 256, lds, stream, k, y_bytes);
+    else DS_LAUNCH((conv5x5s2_c1_bf16_kernel<false, false>), grid, 256, lds, stream, k, y_bytes);
     return ds_last_launch_error();
 }
