@@ -35,20 +35,31 @@ class _FusedBase(torch.optim.Optimizer):
     # inside the kernels from an int32 counter on the device that every step() bumps there -- a step captured into a HIP
     # graph (train_graph.GraphedTripletStep) then replays with the count of the replay, not of the capture.
     _dev_step = None
+    _dev_step_on = False
 
     def enable_device_step(self):
         """From now on the step count that enters the update lives on the device (initialised from the host-side counts;
         all parameters must share one count).  Host-side `state[p]["step"]` keeps advancing in eager steps; after graph
-        replays `sync_host_steps()` brings it up to date (one host synchronisation)."""
-        params = [p for g in self.param_groups for p in g["params"]]
-        counts = {float(self.state[p]["step"]) for p in params if "step" in self.state.get(p, {})}
-        if len(counts) > 1:
-            raise RuntimeError(f"device-side step count needs one count for all parameters, found {sorted(counts)}")
-        start = int(counts.pop()) if counts else 0
-        if start == 0 and any("momentum_buffer" in self.state.get(p, {}) for p in params):
-            start = 1                           # SGD keeps no step count: buffers that exist are past their first step
-        self._dev_step = torch.full((1,), start, dtype=torch.int32, device=params[0].device)
+        replays `sync_host_steps()` brings it up to date (one host synchronisation).  A step skipped by the overflow flag
+        does not count (as with torch.amp.GradScaler, which does not call step() at all)."""
+        self._dev_step_on = True                # (the counter itself is created at the first step, where the parameters are)
         return self
+
+    def _device_step(self, params):
+        """the counter, on the device the parameters are on NOW (created at first use; follows a model that was moved)"""
+        dev = params[0].device
+        if self._dev_step is None:
+            allp = [p for g in self.param_groups for p in g["params"]]
+            counts = {float(self.state[p]["step"]) for p in allp if "step" in self.state.get(p, {})}
+            if len(counts) > 1:
+                raise RuntimeError(f"device-side step count needs one count for all parameters, found {sorted(counts)}")
+            start = int(counts.pop()) if counts else 0
+            if start == 0 and any("momentum_buffer" in self.state.get(p, {}) for p in allp):
+                start = 1                       # SGD keeps no step count: buffers that exist are past their first step
+            self._dev_step = torch.full((1,), start, dtype=torch.int32, device=dev)
+        elif self._dev_step.device != dev:
+            self._dev_step = self._dev_step.to(dev)
+        return self._dev_step
 
     def sync_host_steps(self):
         if self._dev_step is None:
@@ -60,8 +71,23 @@ class _FusedBase(torch.optim.Optimizer):
                 if st is not None and "step" in st:
                     st["step"].fill_(n)
 
+    def _use_dev_step(self, parts) -> bool:
+        """The device-side count serves ONE step count for all parameters.  Parameters that joined later (the classifier
+        head when the regime switches: its own count / a fresh momentum buffer) make a step fall back to the host-side
+        counts -- except inside a stream capture, where host-side counts would be frozen into the graph."""
+        if not self._dev_step_on:
+            return False
+        if len(parts) <= 1 and len(self.param_groups) == 1:
+            if self._dev_step is None and parts:        # created from the host-side counts BEFORE this step bumps them
+                self._device_step(next(iter(parts.values())))
+            return True
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("device-side step count: parameters with different step counts (or several parameter groups) "
+                               "cannot share the one counter a captured step needs")
+        return False
+
     def _bump_dev_step(self, eng, params):
-        eng.lib.call("ds_optim_step_inc", eng._p(self._dev_step), self._skip(eng, params), eng._stream(params[0]))
+        eng.lib.call("ds_optim_step_inc", eng._p(self._device_step(params)), self._skip(eng, params), eng._stream(params[0]))
 
     @property
     def skip_flag(self):
@@ -214,13 +240,12 @@ class FusedAdagrad(_FusedBase):
     def _step_groups(self, eng):
         for group in self.param_groups:
             parts = self._partitions(group)
-            if self._dev_step is not None and len(parts) > 1:
-                raise RuntimeError("device-side step count: parameters with different step counts in one group")
+            dev_step = self._use_dev_step(parts)
             for part in parts.values():
                 params, states, c = self._tables(group, ["sum"], False, params=part)
                 for st in states:
                     st["step"] += 1
-                if self._dev_step is not None:
+                if dev_step:
                     self._bump_dev_step(eng, params)
                     eng.lib.call("ds_adagrad_step_dev_f32", *self._args(eng, c), float(group["lr"]), float(group["lr_decay"]),
                                  group["weight_decay"], group["eps"], eng._p(self._dev_step), self._skip(eng, params),
@@ -251,12 +276,11 @@ class FusedSGD(_FusedBase):
     def _step_groups(self, eng):
         for group in self.param_groups:
             parts = self._partitions(group, fresh_key="momentum_buffer")
-            if self._dev_step is not None and len(parts) > 1:
-                raise RuntimeError("device-side step count: parameters with and without momentum buffers in one group")
+            dev_step = self._use_dev_step(parts)
             for fresh, part in parts.items():
                 params, states, c = self._tables(group, ["momentum_buffer"] if group["momentum"] != 0 else [], False,
                                                  with_step=False, params=part)
-                if self._dev_step is not None:          # "first step" = the step that counts 1 on the device
+                if dev_step:                            # "first step" = the step that counts 1 on the device
                     self._bump_dev_step(eng, params)
                     eng.lib.call("ds_sgd_step_dev_f32", *self._args(eng, c), group["lr"], group["momentum"], group["dampening"],
                                  group["weight_decay"], eng._p(self._dev_step), self._skip(eng, params), eng._stream(params[0]))
@@ -284,15 +308,14 @@ class FusedAdam(_FusedBase):
     def _step_groups(self, eng):
         for group in self.param_groups:
             parts = self._partitions(group)
-            if self._dev_step is not None and len(parts) > 1:
-                raise RuntimeError("device-side step count: parameters with different step counts in one group")
+            dev_step = self._use_dev_step(parts)
             for part in parts.values():
                 params, states, c = self._tables(group, ["exp_avg", "exp_avg_sq"], True, params=part)
                 for st in states:
                     st["step"] += 1
                 step = float(states[0]["step"])
                 b1, b2 = group["betas"]
-                if self._dev_step is not None:
+                if dev_step:
                     self._bump_dev_step(eng, params)
                     eng.lib.call("ds_adam_step_dev_f32", *self._args(eng, c), group["lr"], float(b1), float(b2), group["eps"],
                                  group["weight_decay"], eng._p(self._dev_step), self._skip(eng, params), eng._stream(params[0]))
@@ -318,4 +341,8 @@ def create_optimizer(model, new_lr, optimizer="adagrad", lr_decay=1e-4, wd=0.0):
     if getattr(model, "train_precision", None) == "f16" and hasattr(model, "grad_overflow_flag"):
         import weakref
         opt.skip_source = weakref.ref(model)
+        # ... and its step count lives on the device, so that a step the flag skips does not advance Adagrad's decayed
+        # learning rate / Adam's bias corrections either (the counter is created on the parameters' device at
+        # the first step)
+        opt.enable_device_step()
     return opt

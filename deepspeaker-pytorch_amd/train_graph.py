@@ -45,12 +45,17 @@ class GraphedTripletStep:
             _require_cuda(t, "GraphedTripletStep")
         if not model.training:
             raise RuntimeError("GraphedTripletStep captures the TRAINING step: call model.train() first")
+        red = getattr(model, "_reducer", None)
+        if red is not None and getattr(red, "active", False):
+            raise RuntimeError("GraphedTripletStep: a data-parallel step has collectives on its critical path (BatchNorm "
+                               "statistics, gradient buckets); capturing those is not supported -- use the eager step")
         self.model, self.optimizer = model, optimizer
         self.loss_fn = TripletMarginLoss(margin)
         self.static_x = [t.detach().contiguous().float().clone() for t in example]
         dev = self.static_x[0].device
-        if hasattr(optimizer, "enable_device_step") and getattr(optimizer, "_dev_step", None) is None:
+        if hasattr(optimizer, "enable_device_step"):
             optimizer.enable_device_step()
+            optimizer._device_step([p for g in optimizer.param_groups for p in g["params"]])    # exists before the warm-up
         # ---- warm-up with real steps, then everything they touched is put back IN PLACE (pointers must not change) ----
         keep_p = [p.detach().clone() for p in model.parameters()]
         keep_b = [b.detach().clone() for b in model.buffers()]
