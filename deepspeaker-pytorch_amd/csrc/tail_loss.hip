@@ -631,10 +631,14 @@ extern "C" int ds_mine_semihard_f32(const float *anchor, const float *d_p, const
     DS_REQUIRE(D % 4 == 0 && DS_ALIGNED16(cand) && DS_ALIGNED16(anchor), DS_ERR_ALIGNMENT);
     const float eps = (float)(1e-4 / (double)D);
     const int n_ctiles = ds_ceil_div(M, MINE_C);
-    // 8 anchors per workgroup re-use every staged candidate slab 8 times; when that leaves fewer workgroups than the chip
-    // has CUs (256 anchors x 768 candidates: 96), 4 or 2 anchors per workgroup fill it instead (same sums, same order)
+    // 8 anchors per workgroup re-use every staged candidate slab 8 times; 4 or 2 anchors per workgroup give more
+    // workgroups (same sums, same order)
+    // ... but only when that leaves the chip nearly empty (fewer workgroups than a QUARTER of the CUs).  Round 6: the search
+    // runs on a side stream next to the next step's persistent convolutions, where what it costs is CU-time, not its own
+    // latency -- 256 anchors x 768 candidates as 96 workgroups of 8 anchors take 41 us (4 k CU-us), as 384 workgroups of 2
+    // anchors 35 us (13 k CU-us): the bench step ran 2.00 ms against 2.05 - 2.10 (`gpurun_out/r06_run11`).
     int A = MINE_A_MAX;
-    while (A > 2 && ds_ceil_div(N, A) * n_ctiles < ds_cu_count()) A /= 2;
+    while (A > 2 && ds_ceil_div(N, A) * n_ctiles < ds_cu_count() / 4) A /= 2;
     auto lds_of = [&](int a_) {
         const size_t tile_words = 256 * MINE_P > 4 * a_ * 256 ? 256 * MINE_P : 4 * a_ * 256;
         return ((size_t)a_ * D + tile_words) * 4;
