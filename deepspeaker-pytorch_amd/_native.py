@@ -110,6 +110,7 @@ _SIGNATURES = {
     "ds_triplet_tail_probe_f32": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
                                           c_int, _P]),
     "ds_refine_distances_probe_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "ds_refine_distances_fused_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "ds_pack_conv_dgrad_s2_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "ds_conv_dgrad_f32": (c_int, [POINTER(ConvShape), _P, _P, _P, _P]),
     "ds_conv_wgrad_workspace_floats": (c_longlong, [POINTER(ConvShape)]),

@@ -281,9 +281,16 @@ __global__ void __launch_bounds__(256) refine_distances_kernel(const float *e_re
                                                                const int *amb_count, int cap, float *d_p, float *d_n,
                                                                int D, float eps, float *err, const float *d_p0,
                                                                const float *d_n0, const float *emb_a, const float *emb_p,
-                                                               const float *emb_n) {
+                                                               const float *emb_n, int n_copy) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int live_n = err ? cap : (amb_count[0] < cap ? amb_count[0] : cap);
+    if (n_copy > 0) {           // (one workgroup) d_p / d_n start as copies of the unpatched distances: no clone launches
+        for (int i = threadIdx.x; i < n_copy; i += 256) {
+            d_p[i] = d_p0[i];
+            d_n[i] = d_n0[i];
+        }
+        __syncthreads();
+    }
     float worst = 0.f, ediff = 0.f, emax = 0.f;
     for (int s = blockIdx.x * 4 + wave; s < cap; s += gridDim.x * 4) {
         const float *a = e_ref + (size_t)s * D, *p = e_ref + (size_t)(cap + s) * D, *n = e_ref + (size_t)(2 * cap + s) * D;
@@ -328,6 +335,7 @@ __global__ void __launch_bounds__(256) refine_distances_kernel(const float *e_re
             err[1] = (float)cap;
             err[2] = fmaxf(fmaxf(scratch[4], scratch[5]), fmaxf(scratch[6], scratch[7]));
             err[3] = fmaxf(fmaxf(scratch[8], scratch[9]), fmaxf(scratch[10], scratch[11]));
+            if (n_copy > 0) err[4] = (float)amb_count[0];       // the near-tie count rides in the same read-back
         }
     }
 }
@@ -809,13 +817,13 @@ extern "C" int ds_triplet_scan_f32(const float *d_p, const float *d_n, float mar
 
 static int refine_distances(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
                             float *d_n, int D, float *err, const float *d_p0, const float *d_n0, const float *emb_a,
-                            const float *emb_p, const float *emb_n, void *stream) {
+                            const float *emb_p, const float *emb_n, void *stream, int n_copy = 0) {
     DS_REQUIRE(e_ref && amb_idx && amb_count && d_p && d_n, DS_ERR_NULL);
     DS_REQUIRE(cap > 0 && D > 0, DS_ERR_BAD_SHAPE);
     const float eps = (float)(1e-4 / (double)D);
     const int blocks = err ? 1 : ds_ceil_div(cap, 4);       // the error read-out folds inside one workgroup: no atomics
     DS_LAUNCH(refine_distances_kernel, blocks, 256, 64, stream, e_ref, amb_idx, amb_count, cap, d_p, d_n, D, eps, err, d_p0,
-              d_n0, emb_a, emb_p, emb_n);
+              d_n0, emb_a, emb_p, emb_n, n_copy);
     return ds_last_launch_error();
 }
 
@@ -838,6 +846,22 @@ extern "C" int ds_refine_distances_probe_f32(const float *e_ref, const long long
     DS_REQUIRE(d_p_before != d_p && d_n_before != d_n, DS_ERR_UNSUPPORTED);
     DS_REQUIRE((emb_a != nullptr) == (emb_p != nullptr) && (emb_a != nullptr) == (emb_n != nullptr), DS_ERR_NULL);
     return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, err, d_p_before, d_n_before, emb_a, emb_p, emb_n, stream);
+}
+
+// The same in ONE launch for what used to be five on the refinement's side stream (two clones, the patch, two read-back
+// copies; round 6: beside the persistent convolutions every side-stream launch waits for the drain of a main-stream
+// launch): d_p / d_n (N each) are WRITTEN -- copies of d_p_before / d_n_before with the cap slots patched -- and err holds
+// FIVE floats, err[4] = the near-tie count (amb_count[0]), so that one asynchronous copy brings everything back.
+extern "C" int ds_refine_distances_fused_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap,
+                                             float *d_p, float *d_n, const float *d_p_before, const float *d_n_before,
+                                             const float *emb_a, const float *emb_p, const float *emb_n, int N, int D,
+                                             float *err5, void *stream) {
+    DS_REQUIRE(err5 && d_p_before && d_n_before && amb_count, DS_ERR_NULL);
+    DS_REQUIRE(d_p_before != d_p && d_n_before != d_n, DS_ERR_UNSUPPORTED);
+    DS_REQUIRE(N > 0, DS_ERR_BAD_SHAPE);
+    DS_REQUIRE((emb_a != nullptr) == (emb_p != nullptr) && (emb_a != nullptr) == (emb_n != nullptr), DS_ERR_NULL);
+    return refine_distances(e_ref, amb_idx, amb_count, cap, d_p, d_n, D, err5, d_p_before, d_n_before, emb_a, emb_p, emb_n, stream,
+                            N);
 }
 
 // ---- softmax cross-entropy over the classifier logits (reference train_triplet.py:281-287:

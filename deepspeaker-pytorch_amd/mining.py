@@ -121,14 +121,21 @@ class RefinePolicy:
         pinned slot; the returned record carries the event after which `value()` is valid."""
         if self._ring is None:
             self._ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
-            self._ring_err = torch.zeros((self.RING, 4), dtype=torch.float32).pin_memory()
+            self._ring_err = torch.zeros((self.RING, 5), dtype=torch.float32).pin_memory()
         slot = self._next % self.RING
         self._next += 1
-        self._ring[slot:slot + 1].copy_(amb_count, non_blocking=True)
-        if err is not None:
+        if err is not None and err.numel() == 5:
+            # ds_refine_distances_fused_f32 put the near-tie count into err[4]: ONE copy brings everything back (beside the
+            # persistent convolutions every side-stream operation waits for the drain of a main-stream launch)
             self._ring_err[slot].copy_(err, non_blocking=True)
+            fused = True
+        else:
+            fused = False
+            self._ring[slot:slot + 1].copy_(amb_count, non_blocking=True)
+            if err is not None:
+                self._ring_err[slot, :4].copy_(err, non_blocking=True)
         rec = {"slot": slot, "serial": self._next, "event": torch.cuda.current_stream(amb_count.device).record_event(),
-               "device": amb_count, "device_err": err, "taken": False}
+               "device": amb_count, "device_err": err, "taken": False, "fused": fused}
         self.pending.append(rec)
         return rec
 
@@ -138,8 +145,9 @@ class RefinePolicy:
             cnt = int(rec["device"].item())
             e = rec["device_err"].tolist() if rec["device_err"] is not None else None
         else:
-            cnt = int(self._ring[rec["slot"]])
             e = self._ring_err[rec["slot"]].tolist() if rec["device_err"] is not None else None
+            # fused read-back (ds_refine_distances_fused_f32): the count travelled as err[4]
+            cnt = int(round(e[4])) if rec.get("fused") else int(self._ring[rec["slot"]])
         if e is None:
             return (cnt, None, 0, None)
         return (cnt, float(e[0]), int(e[1]), (float(e[2]) / float(e[3])) if e[3] > 0 else None)
@@ -237,11 +245,11 @@ class RefineWindow:
             for k, en in enumerate(ents):
                 t, a, p, n = en["t"], en["a"], en["p"], en["n"]
                 e_k = e_ref[k * 3 * cap:(k + 1) * 3 * cap]
-                d_p, d_n = t["d_p"].clone(), t["d_n"].clone()
-                err = torch.empty(4, dtype=torch.float32, device=dev)
-                eng.lib.call("ds_refine_distances_probe_f32", eng._p(e_k), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
+                d_p, d_n = torch.empty_like(t["d_p"]), torch.empty_like(t["d_n"])
+                err = torch.empty(5, dtype=torch.float32, device=dev)
+                eng.lib.call("ds_refine_distances_fused_f32", eng._p(e_k), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
                              eng._p(d_p), eng._p(d_n), eng._p(t["d_p"]), eng._p(t["d_n"]), eng._p(a), eng._p(p), eng._p(n),
-                             a.shape[1], eng._p(err), st)
+                             d_p.numel(), a.shape[1], eng._p(err), st)
                 rb = self.policy.readback(t["amb_count"], err)
                 idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
                 mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])
@@ -493,15 +501,16 @@ def select_triplets(out_a: torch.Tensor, out_p: torch.Tensor, out_n: torch.Tenso
             rows = xs[0][0].numel()
             xr = torch.empty((3 * cap,) + tuple(xs[0].shape[1:]), dtype=torch.float32, device=a.device)
             st = eng._stream(a)
-            for k, x in enumerate(xs):
-                eng.lib.call("ds_gather_rows_f32", eng._p(x), eng._p(t["amb_idx"]), eng._p(xr[k * cap:(k + 1) * cap]), cap,
-                             rows, st)
+            # (round 6: one gather, one patch kernel that also copies the distances and carries the count, one read-back
+            # copy -- 19 side-stream operations per call instead of 24)
+            eng.lib.call("ds_gather_rows3_f32", eng._p(xs[0]), eng._p(xs[1]), eng._p(xs[2]), eng._p(t["amb_idx"]), eng._p(xr), cap,
+                         rows, st)
             e_ref = eng.forward_eval_planned(xr, pw_ref, folded_ref, precision="bf16x3")
-            d_p, d_n = t["d_p"].clone(), t["d_n"].clone()
-            err = torch.empty(4, dtype=torch.float32, device=a.device)
-            eng.lib.call("ds_refine_distances_probe_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
+            d_p, d_n = torch.empty_like(t["d_p"]), torch.empty_like(t["d_n"])
+            err = torch.empty(5, dtype=torch.float32, device=a.device)
+            eng.lib.call("ds_refine_distances_fused_f32", eng._p(e_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap,
                          eng._p(d_p), eng._p(d_n), eng._p(t["d_p"]), eng._p(t["d_n"]), eng._p(a), eng._p(p), eng._p(n),
-                         a.shape[1], eng._p(err), st)
+                         d_p.numel(), a.shape[1], eng._p(err), st)
             rb = policy.readback(t["amb_count"], err)
             idx, count = torch.empty_like(t["idx"]), torch.empty_like(t["count"])
             mean_diff, loss = torch.empty_like(t["mean_diff"]), torch.empty_like(t["loss"])

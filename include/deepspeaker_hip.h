@@ -334,6 +334,11 @@ int ds_triplet_tail_probe_f32(const float *a, const float *p, const float *n, fl
 int ds_refine_distances_probe_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
                                   float *d_n, const float *d_p_before, const float *d_n_before, const float *emb_a,
                                   const float *emb_p, const float *emb_n, int D, float *err, void *stream);
+/* Round 6: the same in one launch instead of five (two clones, the patch, two read-back copies): d_p / d_n [N] are WRITTEN
+ * (= d_p_before / d_n_before with the cap slots patched) and err5 holds five floats, err5[4] = the near-tie count. */
+int ds_refine_distances_fused_f32(const float *e_ref, const long long *amb_idx, const int *amb_count, int cap, float *d_p,
+                                  float *d_n, const float *d_p_before, const float *d_n_before, const float *emb_a,
+                                  const float *emb_p, const float *emb_n, int N, int D, float *err5, void *stream);
 
 
 /* ---- backward of the convolution stack (torch autograd of nn.Conv2d / nn.BatchNorm2d under

@@ -190,6 +190,14 @@ def test_triplet_tail_probe_slots_and_error_readout(N, cap, base):
                                                       cap, eng._p(dp2), eng._p(dn2), eng._p(dp2), eng._p(dn2), None, None, None, D,
                                                       eng._p(err), None)
     assert rc != 0
+    # round 6: ds_refine_distances_fused_f32 = two clones + the call above + the count's read-back in ONE launch: the
+    # outputs are WRITTEN (garbage in), bitwise the patched clones; err5[:4] the same read-out, err5[4] the near-tie count
+    dp3, dn3 = torch.full((N,), float("nan")), torch.full((N,), float("nan"))
+    err5 = torch.full((5,), -1.0)
+    eng.lib.call("ds_refine_distances_fused_f32", eng._p(te_ref), eng._p(t["amb_idx"]), eng._p(t["amb_count"]), cap, eng._p(dp3),
+                 eng._p(dn3), eng._p(t["d_p"]), eng._p(t["d_n"]), eng._p(ta_), eng._p(tp_), eng._p(tn_), N, D, eng._p(err5), None)
+    assert torch.equal(dp3, dp2) and torch.equal(dn3, dn2) and torch.equal(err5[:4], err)
+    assert int(err5[4]) == int(t["amb_count"])
 
 
 @pytest.mark.parametrize("N", [1, 5, 256, 700])
