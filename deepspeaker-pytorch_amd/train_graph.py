@@ -21,6 +21,10 @@ that a replay cannot do -- autograd version counters, `state[p]["step"]`, `num_b
 IS updated -- is brought up to date by `sync()` (called automatically before the object hands the model back:
 `close()` / context exit), which is one host synchronisation.
 
+Frozen at capture (kernel arguments of the graph's nodes): the batch shape, the margin, the optimizer's hyper-parameters
+(learning rate, momentum, betas, weight decay -- Adagrad's DECAY of the learning rate is not frozen: it is computed from the
+device-side step count), the loss scale of the fp16 step.  Change any of them -> build a new GraphedTripletStep.
+
 The warm-up the capture needs (allocator pools, launch plans, LDS opt-ins) runs REAL steps; parameters, BatchNorm
 buffers, optimizer state and the loss-scale flag are restored in place afterwards, so constructing the object leaves the
 model where it was.  Measured on MI355X (tools/train_graph_probe.py): the replayed fp16 step reproduces the eager loss
